@@ -1,0 +1,106 @@
+/*
+ * lora_oracle.h -- CPU ORACLE for the gr-lora decoder hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke check
+ * in __graft_entry__.py and the `cpu_baseline` leg of bench.py may load it.
+ * The product path (gr_lora_amd/, include/lora_hip.h) never links, imports or
+ * executes anything in oracle/.
+ *
+ * It is a from-scratch plain-C restatement of the arithmetic and the state
+ * machine of the reference's gr::lora::decoder_impl (lib/decoder_impl.cc), each
+ * function citing the reference file:line it follows.  The reference itself
+ * cannot be compiled here (GNU Radio, liquid-dsp, VOLK, Boost absent), so the
+ * three third-party pieces are restated from their published behaviour:
+ *   - VOLK reductions   -> sequential float loops (summation order unpinned),
+ *   - liquid fft_execute -> iterative radix-2 FFT (any DFT agrees to rounding),
+ *   - liquid fec_decode(HAMMING84) -> nearest-codeword table; unique for <=1 bit
+ *     error, lowest-symbol tie-break for >=2 bit errors (PARITY UNPINNED there).
+ * Parity pinning: README.md:75-85 known-answer bytes and the SURVEY Appendix-C
+ * symbol list (tests/test_oracle_kat.py).
+ */
+#ifndef LORA_ORACLE_H
+#define LORA_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* demodulator selection inside demodulate() (decoder_impl.cc:499-500) */
+enum {
+    ORACLE_DEMOD_GRAD = 0,       /* max_frequency_gradient_idx  (reference default, :499) */
+    ORACLE_DEMOD_FFT = 1,        /* get_shift_fft (:430-464); bin_idx = (s-1) mod N        */
+    ORACLE_DEMOD_FFT_COMPAT = 2  /* as FFT, but s==0 -> bin_idx 0 (gradient quirk, :479-490) */
+};
+
+/* decoder states, same order as lib/decoder_impl.h:40-48 */
+enum { ST_DETECT = 0, ST_SYNC, ST_FIND_SFD, ST_PAUSE, ST_DECODE_HEADER, ST_DECODE_PAYLOAD, ST_STOP };
+
+typedef struct {
+    int32_t  state;      /* state on entry of this work() call                    */
+    int64_t  pos;        /* absolute sample index of input[0] for this call       */
+    int32_t  consumed;   /* consume_each() amount                                 */
+    int32_t  bin;        /* demodulated bin_idx before rate reduction, or -1       */
+    int32_t  fine;       /* d_fine_sync after the call                            */
+    float    value;      /* autocorr (DETECT), SYNC max corr, SFD corr, else 0     */
+} oracle_step_t;
+
+typedef struct lora_oracle lora_oracle_t;
+
+/* mirrors decoder::make (include/lora/decoder.h:705, lib/decoder_impl.cc:41-122);
+ * returns NULL where the reference would exit(1) (sf<6 || sf>13, :57-61).        */
+lora_oracle_t *lora_oracle_create(float samp_rate, uint32_t bandwidth, uint8_t sf, int implicit,
+                                  uint8_t cr, int crc, int reduced_rate,
+                                  int disable_drift_correction, int demod_mode);
+void lora_oracle_destroy(lora_oracle_t *o);
+
+/* Feed n complex samples (interleaved re,im).  Emulates the GNU Radio scheduler
+ * contract of set_output_multiple(2*sps) (:91): work() is called while at least
+ * 2*sps items remain.  Returns number of items consumed in total.               */
+size_t lora_oracle_run(lora_oracle_t *o, const float *iq, size_t n);
+
+int lora_oracle_num_frames(const lora_oracle_t *o);
+/* copies frame idx (loratap 15B | phy hdr 3B | payload) -> returns its length   */
+int lora_oracle_get_frame(const lora_oracle_t *o, int idx, uint8_t *buf, int cap);
+/* absolute sample position of the first header symbol of frame idx               */
+int64_t lora_oracle_frame_pos(const lora_oracle_t *o, int idx);
+void lora_oracle_clear_frames(lora_oracle_t *o);
+
+/* optional step trace (enable before run); returns pointer to internal array     */
+void lora_oracle_enable_trace(lora_oracle_t *o, int on);
+size_t lora_oracle_trace(const lora_oracle_t *o, const oracle_step_t **steps);
+
+/* geometry */
+uint32_t lora_oracle_sps(const lora_oracle_t *o);
+uint32_t lora_oracle_bins(const lora_oracle_t *o);
+/* tables built by build_ideal_chirps (:141-175): which = 0 downchirp(cf32, sps),
+ * 1 upchirp(cf32, sps), 2 downchirp_ifreq(f32, sps), 3 upchirp_ifreq(f32, sps),
+ * 4 upchirp_ifreq_v(f32, 3*sps + pad)                                            */
+const float *lora_oracle_table(const lora_oracle_t *o, int which, size_t *n_floats);
+
+/* primitives exposed for unit / parity tests (all take >= the window they read) */
+uint32_t lora_oracle_get_shift_fft(lora_oracle_t *o, const float *iq);               /* :430-464 */
+uint32_t lora_oracle_max_frequency_gradient_idx(lora_oracle_t *o, const float *iq); /* :466-491 */
+int32_t  lora_oracle_fine_sync(lora_oracle_t *o, const float *iq, int32_t bin_idx, int32_t search_space); /* :300-338, returns d_fine_sync */
+float    lora_oracle_detect_preamble_autocorr(lora_oracle_t *o, const float *iq);   /* :340-366 */
+float    lora_oracle_detect_downchirp(lora_oracle_t *o, const float *iq);           /* :385-390 */
+float    lora_oracle_detect_upchirp(lora_oracle_t *o, const float *iq, int32_t *index); /* :392-413 */
+void     lora_oracle_instantaneous_frequency(const float *iq, float *out, uint32_t window); /* :224-244 */
+/* per-symbol bins for a list of symbol start offsets (ground-truth timing, config 5) */
+void     lora_oracle_demod_at(lora_oracle_t *o, const float *iq, const int64_t *offsets, size_t n,
+                              int mode, uint32_t *bins_out);
+
+/* integer chain helpers (bit-exact) */
+uint32_t lora_oracle_rotl(uint32_t bits, uint32_t count, uint32_t size);   /* utilities.h:96-103 */
+uint8_t  lora_oracle_hamming_encode(uint8_t nibble);                      /* utilities.h:257-264 */
+uint8_t  lora_oracle_hamming84_decode(uint8_t codeword);                  /* liquid HAMMING84 restated */
+/* deinterleave one block of n_words words of ppm bits -> ppm codewords (:535-565) */
+void     lora_oracle_deinterleave(const uint32_t *words, uint32_t n_words, uint32_t ppm, uint8_t *out);
+uint8_t  lora_oracle_deshuffle_byte(uint8_t v);                            /* :611-621 */
+uint8_t  lora_oracle_snr_byte(float snr);                                  /* :597 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif
