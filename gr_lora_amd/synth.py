@@ -103,7 +103,7 @@ class TxConfig:
     reduced_rate: bool = False
     implicit: bool = False
     preamble_len: int = 8
-    sync_shifts: Tuple[int, int] = (24, 32)
+    sync_shifts: Optional[Tuple[int, int]] = None  # None -> (3N/16, N/4) = (24, 32) at SF7
     hdr_nibbles: Tuple[int, int] = (0, 4)  # (crc_msn, 5th header nibble); README vector has 0,4
 
     @property
@@ -178,7 +178,8 @@ def frame_shift_plan(hdr_shifts: Sequence[int], pay_shifts: Sequence[int], cfg: 
     """Symbol plan of one frame: list of (kind, shift, n_samples); kind 0 up, 1 down."""
     sps = cfg.sps
     plan = [(0, 0, sps)] * cfg.preamble_len
-    plan += [(0, cfg.sync_shifts[0] % cfg.nbins, sps), (0, cfg.sync_shifts[1] % cfg.nbins, sps)]
+    s1, s2 = cfg.sync_shifts if cfg.sync_shifts is not None else (3 * cfg.nbins // 16, cfg.nbins // 4)
+    plan += [(0, s1 % cfg.nbins, sps), (0, s2 % cfg.nbins, sps)]
     plan += [(1, 0, sps), (1, 0, sps), (1, 0, sps // 4)]
     plan += [(0, s, sps) for s in hdr_shifts]
     plan += [(0, s, sps) for s in pay_shifts]
