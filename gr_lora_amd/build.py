@@ -1,0 +1,40 @@
+"""Builds liblora_hip.so (HIP kernels + host runtime + C ABI) in-tree for gfx950."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB = os.path.join(_HERE, "liblora_hip.so")
+SOURCES = ["lora_kernels.hip", "lora_runtime.cpp"]
+DEPS = SOURCES + ["lora_device.h", "whitening_data.inc", os.path.join("..", "..", "include", "lora_hip.h")]
+
+
+def hipcc_path() -> str:
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 -> gr_lora_amd/liblora_hip.so (cross-compiles without a GPU)."""
+    if not force and not stale():
+        return LIB
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
+           "-Wall", "-Wno-unused-function", "-I", CSRC, "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    import sys
+    print(build_library(force=True, verbose="-v" in sys.argv))

@@ -1,0 +1,189 @@
+"""ctypes binding of the C ABI declared in include/lora_hip.h (liblora_hip.so).
+
+The library is loaded on first use; if it is missing or no MI355X is visible the
+calls raise -- there is no CPU fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblora_hip.so")
+
+DEMOD_GRAD, DEMOD_FFT, DEMOD_FFT_COMPAT = 0, 1, 2
+FLAG_TRACE = 1
+
+EXPORTS = [
+    "lora_hip_abi_version", "lora_hip_strerror", "lora_hip_last_error", "lora_hip_create", "lora_hip_destroy",
+    "lora_hip_get_geometry", "lora_hip_set_sf", "lora_hip_set_samp_rate", "lora_hip_work", "lora_hip_flush",
+    "lora_hip_decode_device", "lora_hip_frames_available", "lora_hip_poll_frame", "lora_hip_demod_symbols_device",
+    "lora_hip_last_timing", "lora_hip_trace", "lora_hip_trace_clear",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("samp_rate", C.c_float), ("bandwidth", C.c_uint32),
+                ("sf", C.c_uint8), ("implicit", C.c_uint8), ("cr", C.c_uint8), ("crc", C.c_uint8),
+                ("reduced_rate", C.c_uint8), ("disable_drift_correction", C.c_uint8), ("reserved0", C.c_uint8 * 2),
+                ("device", C.c_int32), ("demod", C.c_int32), ("flags", C.c_uint32),
+                ("segment_symbols", C.c_uint32), ("batch_items", C.c_uint32)]
+
+
+class FrameInfo(C.Structure):
+    _fields_ = [("stream", C.c_uint32), ("length", C.c_uint32), ("header_pos", C.c_int64), ("end_pos", C.c_int64)]
+
+
+class Step(C.Structure):
+    _fields_ = [("state", C.c_int32), ("consumed", C.c_int32), ("pos", C.c_int64), ("bin", C.c_int32),
+                ("fine", C.c_int32), ("value", C.c_float), ("stream", C.c_uint32)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("walker_ms", C.c_float), ("total_device_ms", C.c_float), ("walker_launches", C.c_uint32),
+                ("jobs", C.c_uint32), ("probes", C.c_uint32), ("slow_path_relaunches", C.c_uint32),
+                ("items", C.c_uint64)]
+
+
+class LoraHipError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__("lora_hip status %d: %s" % (status, msg))
+        self.status = status
+
+
+_lib = None
+
+
+def load():
+    """Loads liblora_hip.so; raises if it was not built (run __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # One HIP runtime per process: torch bundles its own libamdhip64.so (SONAME
+    # libamdhip64.so.7).  Importing torch first makes the dynamic loader bind this
+    # library to that same runtime; loading /opt/rocm's copy beside it leaves one
+    # of the two without devices.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("liblora_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.lora_hip_abi_version.restype = C.c_uint32
+    L.lora_hip_strerror.restype = C.c_char_p
+    L.lora_hip_strerror.argtypes = [C.c_int]
+    L.lora_hip_last_error.restype = C.c_char_p
+    L.lora_hip_last_error.argtypes = [vp]
+    L.lora_hip_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.lora_hip_destroy.argtypes = [vp]
+    L.lora_hip_destroy.restype = None
+    L.lora_hip_get_geometry.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.lora_hip_set_sf.argtypes = [vp, C.c_uint8]
+    L.lora_hip_set_samp_rate.argtypes = [vp, C.c_float]
+    L.lora_hip_work.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.lora_hip_flush.argtypes = [vp]
+    L.lora_hip_decode_device.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_uint32, vp]
+    L.lora_hip_frames_available.restype = C.c_size_t
+    L.lora_hip_frames_available.argtypes = [vp]
+    L.lora_hip_poll_frame.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(FrameInfo)]
+    L.lora_hip_demod_symbols_device.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int, vp, vp]
+    L.lora_hip_last_timing.argtypes = [vp, C.POINTER(Timing)]
+    L.lora_hip_trace.restype = C.c_size_t
+    L.lora_hip_trace.argtypes = [vp, C.POINTER(C.POINTER(Step))]
+    L.lora_hip_trace_clear.argtypes = [vp]
+    L.lora_hip_trace_clear.restype = None
+    _lib = L
+    return L
+
+
+class Handle:
+    """Thin RAII wrapper of lora_hip_decoder_t."""
+
+    def __init__(self, samp_rate=1e6, bandwidth=125000, sf=7, implicit=False, cr=4, crc=True, reduced_rate=False,
+                 disable_drift_correction=False, device=0, demod=DEMOD_FFT_COMPAT, flags=0, segment_symbols=0,
+                 batch_items=0):
+        self.L = load()
+        cfg = Config(struct_size=C.sizeof(Config), samp_rate=float(samp_rate), bandwidth=int(bandwidth), sf=int(sf),
+                     implicit=int(bool(implicit)), cr=int(cr), crc=int(bool(crc)), reduced_rate=int(bool(reduced_rate)),
+                     disable_drift_correction=int(bool(disable_drift_correction)), device=int(device), demod=int(demod),
+                     flags=int(flags), segment_symbols=int(segment_symbols), batch_items=int(batch_items))
+        h = C.c_void_p()
+        st = self.L.lora_hip_create(C.byref(cfg), C.byref(h))
+        if st != 0:
+            raise LoraHipError(st, "%s (%s)" % (self.L.lora_hip_strerror(st).decode(), self.L.lora_hip_last_error(None).decode()))
+        self.h = h
+        a, b, d = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self.L.lora_hip_get_geometry(self.h, C.byref(a), C.byref(b), C.byref(d))
+        self.sps, self.nbins, self.decim = a.value, b.value, d.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lora_hip_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _check(self, st: int):
+        if st != 0:
+            raise LoraHipError(st, "%s (%s)" % (self.L.lora_hip_strerror(st).decode(), self.L.lora_hip_last_error(self.h).decode()))
+
+    # streaming (host buffers)
+    def work(self, iq: np.ndarray) -> int:
+        a = np.ascontiguousarray(iq, dtype=np.complex64)
+        n = C.c_size_t(0)
+        self._check(self.L.lora_hip_work(self.h, a.ctypes.data, a.size, C.byref(n)))
+        return n.value
+
+    def flush(self):
+        self._check(self.L.lora_hip_flush(self.h))
+
+    # batched, device-resident
+    def decode_device(self, dev_ptr: int, total_items: int, offs: Sequence[int], lens: Sequence[int], stream: int = 0):
+        o = np.ascontiguousarray(offs, dtype=np.uint64)
+        l = np.ascontiguousarray(lens, dtype=np.uint64)
+        self._check(self.L.lora_hip_decode_device(self.h, dev_ptr, total_items, o.ctypes.data, l.ctypes.data, o.size, stream))
+
+    def demod_symbols_device(self, dev_ptr: int, total_items: int, offsets: Sequence[int], demod: int, stream: int = 0) -> np.ndarray:
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        out = np.zeros(off.size, dtype=np.uint32)
+        self._check(self.L.lora_hip_demod_symbols_device(self.h, dev_ptr, total_items, off.ctypes.data, off.size, demod, out.ctypes.data, stream))
+        return out
+
+    def frames_available(self) -> int:
+        return self.L.lora_hip_frames_available(self.h)
+
+    def poll_frame(self) -> Optional[Tuple[bytes, FrameInfo]]:
+        buf = (C.c_uint8 * 320)()
+        n = C.c_size_t(0)
+        info = FrameInfo()
+        self._check(self.L.lora_hip_poll_frame(self.h, buf, 320, C.byref(n), C.byref(info)))
+        if n.value == 0:
+            return None
+        return bytes(buf[: n.value]), info
+
+    def drain(self) -> List[Tuple[bytes, FrameInfo]]:
+        out = []
+        while True:
+            f = self.poll_frame()
+            if f is None:
+                return out
+            out.append(f)
+
+    def timing(self) -> Timing:
+        t = Timing()
+        self._check(self.L.lora_hip_last_timing(self.h, C.byref(t)))
+        return t
+
+    def trace(self):
+        p = C.POINTER(Step)()
+        n = self.L.lora_hip_trace(self.h, C.byref(p))
+        return [(p[i].state, p[i].pos, p[i].consumed, p[i].bin, p[i].fine, p[i].value, p[i].stream) for i in range(n)]
+
+    def trace_clear(self):
+        self.L.lora_hip_trace_clear(self.h)

@@ -1,0 +1,113 @@
+// lora_device.h -- structures shared between the host runtime and the HIP kernels.
+//
+// HBM data layout (all device-resident, allocated once per decoder handle):
+//   IQ stream      cf32[items]            caller-owned (or the handle's staging buffer), read-only
+//   chirp tables   down cf32[sps], up_ifreq f32[sps], down_ifreq f32[sps],
+//                  up_ifreq_v f32[3*sps+pad], twN cf32[N/2], tws cf32[sps]   (L2-resident, <= 1.2 MB)
+//   jobs           Job[n_jobs]            one workgroup each
+//   attempts       AttemptRec[n_jobs * recs_per_job]
+//   job results    JobResult[n_jobs]
+//   scratch        f32[n_jobs * 2*sps]    only when the ifreq window does not fit in LDS (SF >= 11)
+#pragma once
+#include <stdint.h>
+
+namespace lora_hip {
+
+constexpr int kWG = 256;              // threads per workgroup (4 wavefronts of 64)
+constexpr int kMaxBinsPerThread = 16; // N / kWG at SF12
+constexpr int kMaxFrame = 3 + 255 + 2;
+constexpr int kMaxCodewords = 640;    // (sf-7) + ceil(2*257/ppm)*ppm  <= 5 + 44*12
+
+enum DecState : int32_t { kDetect = 0, kSync, kFindSfd, kPause, kDecodeHeader, kDecodePayload, kStop };
+
+enum AttemptStatus : uint32_t {
+    kAttemptNone = 0,
+    kAttemptFrame = 1,       // packet decoded, frame[] valid
+    kAttemptLostSync = 2,    // d_corr_fails > 4 -> back to DETECT (decoder_impl.cc:808-813)
+    kAttemptOutOfData = 3,   // fewer than 2*sps items left mid-attempt (scheduler stops calling work())
+    kAttemptAtHeader = 4     // probe mode: stopped on entering DECODE_HEADER
+};
+
+struct DevParams {
+    uint32_t sf, nbins, nbins_hdr, sps, decim, log_nbins, delay_after_sync;
+    uint32_t implicit, reduced_rate, enable_fine_sync, demod_mode;
+    uint32_t ctor_cr, ctor_crc;
+    uint32_t fft_groups;        // passes over the symbol in get_shift_fft (1 for SF <= 10 at D = 8)
+    uint32_t fft_stride;        // LDS row stride (in cf32) of one polyphase array
+    uint32_t lds_work_bytes;    // size of the shared work area
+    uint32_t ifreq_in_lds_1;    // sps floats fit in LDS work area
+    uint32_t ifreq_in_lds_2;    // 2*sps floats fit in LDS work area
+    float    down_ifreq_avg;    // chirp_avg over sps-1 points (decoder_impl.cc:287)
+    float    down_ifreq_sd;     // stddev of ideal downchirp ifreq (decoder_impl.cc:289)
+    const float2 *down;         // d_downchirp
+    const float  *up_ifreq;     // d_upchirp_ifreq
+    const float  *down_ifreq;   // d_downchirp_ifreq
+    const float  *up_ifreq_v;   // d_upchirp_ifreq_v (+ guard tail)
+    const float2 *twN;          // e^{-2 pi i t / N},   t < N/2
+    const float2 *tws;          // e^{-2 pi i m / sps}, m < sps
+};
+
+struct Job {
+    uint64_t stream_off;   // item index of the stream's first sample inside the IQ buffer
+    uint64_t stream_len;   // items in the stream
+    int64_t  start;        // DETECT position where this job starts (relative to the stream)
+    int64_t  scan_limit;   // no new DETECT step is started at pos >= scan_limit
+    uint32_t stream_id;
+    uint32_t cr_prev;      // d_phdr.cr carried in (constructor value or previous packet's, :655)
+    uint32_t max_attempts; // stop after this many attempts (0 = unlimited up to capacity)
+    uint32_t stop_at_header; // probe mode
+};
+
+struct AttemptRec {
+    int64_t  start_pos;    // DETECT position where this attempt's scan began
+    int64_t  trig_pos;     // DETECT position that triggered (autocorr >= 0.90)
+    int64_t  hdr_pos;      // position entering DECODE_HEADER (-1 if never reached)
+    int64_t  end_pos;      // position after the attempt (next DETECT position)
+    uint32_t status;       // AttemptStatus
+    uint32_t npush;        // d_pwr_queue pushes during this attempt's DETECT scan (incl. trigger step)
+    float    push_tail[4]; // the last min(4, npush) pushed values, oldest first
+    uint32_t cr_prev;      // d_phdr.cr used for the header FEC branch
+    uint32_t hdr_ambig;    // header bytes differ between the {3,4} and {1,2} FEC branches
+    uint32_t frame_len;    // 3 + payload_length
+    uint32_t n_symbols;    // header + payload symbols demodulated
+    uint8_t  frame[kMaxFrame + 4];
+};
+
+struct JobResult {
+    int64_t  final_pos;    // DETECT position where the job stopped
+    uint32_t n_attempts;
+    uint32_t final_cr;     // d_phdr.cr after the last attempt
+    uint32_t npush;        // pushes of the trailing DETECT scan (after the last attempt)
+    float    push_tail[4];
+    uint32_t stop_reason;  // 0 scan_limit reached, 1 out of data, 2 attempt capacity, 3 max_attempts / probe stop
+    uint32_t n_steps;      // trace entries written
+    uint32_t pad;
+};
+
+struct StepRec {           // mirrors lora_hip_step_t
+    int32_t  state, consumed;
+    int64_t  pos;
+    int32_t  bin, fine;
+    float    value;
+    uint32_t stream;
+};
+
+// host-side launchers implemented in lora_kernels.hip
+struct LaunchCfg {
+    const float2 *iq;
+    const Job *jobs;
+    JobResult *results;
+    AttemptRec *recs;
+    uint32_t recs_per_job;
+    float *scratch;          // n_jobs * 2*sps floats or nullptr
+    StepRec *trace;          // n_jobs * trace_cap or nullptr
+    uint32_t trace_cap;
+    uint32_t n_jobs;
+};
+
+int launch_walker(const DevParams &p, const LaunchCfg &c, void *stream);
+int launch_demod_symbols(const DevParams &p, const float2 *iq, const int64_t *d_offsets, uint32_t n,
+                         int demod, uint32_t *d_bins, float *scratch, void *stream);
+uint32_t walker_lds_bytes(const DevParams &p);
+
+} // namespace lora_hip

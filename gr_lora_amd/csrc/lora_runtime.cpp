@@ -1,0 +1,590 @@
+// lora_runtime.cpp -- host side below the C ABI (include/lora_hip.h):
+// table construction (the reference constructor's work), job scheduling over
+// streams / stream segments, speculation stitching, frame assembly, streaming.
+//
+// Citations `:NNN` are lines of the reference's lib/decoder_impl.cc.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/lora_hip.h"
+#include "lora_device.h"
+
+using namespace lora_hip;
+
+namespace {
+
+constexpr int kLoratapLen = 15; // sizeof(loratap_header_t), include/lora/loratap.h:35-55
+constexpr uint32_t kWorkBudget = 64u * 1024u + 64u; // LDS work area cap (bytes)
+
+struct Frame {
+    std::vector<uint8_t> blob;
+    lora_hip_frame_info_t info;
+};
+
+// d_pwr_queue (boost::circular_buffer<float>(4)) + d_snr, kept on the host: the
+// device reports the values each DETECT step pushed (:360), the host replays them.
+struct PwrState {
+    float q[4];
+    int n = 0;
+    float snr = 0.0f; // uninitialised upstream (decoder_impl.h:101); pinned to 0
+    void push(float v)
+    {
+        if (n < 4) q[n++] = v;
+        else { q[0] = q[1]; q[1] = q[2]; q[2] = q[3]; q[3] = v; }
+    }
+    void apply(uint32_t npush, const float tail[4])
+    {
+        const uint32_t k = npush < 4u ? npush : 4u;
+        for (uint32_t i = 0; i < k; i++) push(tail[i]);
+    }
+    void determine_snr() // :377-383
+    {
+        if (n >= 2) snr = q[n - 1] / q[0];
+    }
+};
+
+// loratap_header.rssi.snr = (uint8_t)(10.0f * log10(d_snr) + 0.5) (:597).  The
+// narrowing is UB out of range upstream; pinned to the x86-64 result (cvttsd2si).
+uint8_t snr_byte(float snr)
+{
+    const double v = (double)(10.0f * log10f(snr)) + 0.5;
+    if (!(v > -2147483649.0 && v < 2147483648.0)) return 0;
+    return (uint8_t)(int32_t)v;
+}
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = n + n / 4 + 16;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+} // namespace
+
+struct lora_hip_decoder {
+    lora_hip_config_t cfg{};
+    DevParams P{};
+    int device = 0;
+    // device tables
+    float2 *d_down = nullptr, *d_twN = nullptr, *d_tws = nullptr;
+    float *d_up_ifreq = nullptr, *d_down_ifreq = nullptr, *d_up_ifreq_v = nullptr;
+    // per-pass buffers
+    DevBuf<Job> d_jobs;
+    DevBuf<JobResult> d_results;
+    DevBuf<AttemptRec> d_recs;
+    DevBuf<float> d_scratch;
+    DevBuf<StepRec> d_trace;
+    DevBuf<float2> d_staging;
+    DevBuf<int64_t> d_offsets;
+    DevBuf<uint32_t> d_bins;
+    std::vector<JobResult> h_results;
+    std::vector<AttemptRec> h_recs;
+    std::vector<StepRec> h_trace;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // outputs
+    std::deque<Frame> frames;
+    std::vector<lora_hip_step_t> trace;
+    lora_hip_timing_t timing{};
+    std::string err;
+    // streaming state (lora_hip_work)
+    std::vector<float> hostbuf; // interleaved
+    int64_t host_base = 0;      // absolute item index of hostbuf[0]
+    uint32_t stream_cr = 0;
+    PwrState stream_pwr;
+    size_t batch_items = 0, batch_need = 0;
+};
+
+namespace {
+
+thread_local std::string g_create_err; // lora_hip_last_error(NULL): why the last lora_hip_create failed
+
+lora_hip_status fail(lora_hip_decoder *h, lora_hip_status s, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    g_create_err = buf;
+    return s;
+}
+
+#define HIP_TRY(h, expr)                                                                                   \
+    do {                                                                                                   \
+        hipError_t e__ = (expr);                                                                           \
+        if (e__ != hipSuccess) return fail(h, LORA_HIP_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+// instantaneous_frequency (:224-244), used for the constructor's tables
+void host_ifreq(const float2 *x, float *out, uint32_t window)
+{
+    for (uint32_t i = 1; i < window; i++) {
+        const float p1 = std::atan2(x[i - 1].y, x[i - 1].x);
+        float p2 = std::atan2(x[i].y, x[i].x);
+        while ((double)(p2 - p1) > M_PI) p2 = (float)((double)p2 - 2.0 * M_PI);
+        while ((double)(p2 - p1) < -M_PI) p2 = (float)((double)p2 + 2.0 * M_PI);
+        out[i - 1] = p2 - p1;
+    }
+    out[window - 1] = out[window - 2];
+}
+
+template <typename T>
+lora_hip_status upload(lora_hip_decoder *h, T **dst, const std::vector<T> &src)
+{
+    HIP_TRY(h, hipMalloc((void **)dst, src.size() * sizeof(T)));
+    HIP_TRY(h, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return LORA_HIP_OK;
+}
+
+// decoder_impl constructor (:49-122) + build_ideal_chirps (:141-175)
+lora_hip_status build_tables(lora_hip_decoder *h)
+{
+    const lora_hip_config_t &c = h->cfg;
+    DevParams &P = h->P;
+    const uint32_t samples_per_second = (uint32_t)c.samp_rate;          // :74
+    const double dt = (double)(1.0f / (float)samples_per_second);       // :77 (float division)
+    const double symbols_per_second = (double)c.bandwidth / (double)(1u << c.sf); // :80
+    const uint32_t sps = (uint32_t)((double)samples_per_second / symbols_per_second); // :83
+    const uint32_t N = 1u << c.sf;
+    if (sps < N || (sps & (sps - 1u)) != 0u)
+        return fail(h, LORA_HIP_ERR_BAD_CONFIG, "samples per symbol (%u) must be a power-of-two multiple of 2^sf (%u)", sps, N);
+    const uint32_t D = sps / N;
+    if (D > 16u) return fail(h, LORA_HIP_ERR_BAD_CONFIG, "decimation %u > 16 is not supported", D);
+    P.sf = c.sf; P.nbins = N; P.nbins_hdr = 1u << (c.sf - 2); P.sps = sps; P.decim = D;
+    P.log_nbins = c.sf; P.delay_after_sync = sps / 4u;
+    P.implicit = c.implicit ? 1u : 0u; P.reduced_rate = c.reduced_rate ? 1u : 0u;
+    P.enable_fine_sync = c.disable_drift_correction ? 0u : 1u;
+    P.demod_mode = (uint32_t)c.demod;
+    P.ctor_cr = c.cr & 7u; P.ctor_crc = c.crc ? 1u : 0u;
+    // get_shift_fft working set: D/G polyphase rows of N points (+1 pad) must fit the LDS budget
+    uint32_t G = 1;
+    while ((size_t)(D / G) * (N + 1u) * sizeof(float2) > kWorkBudget && G < D) G <<= 1;
+    P.fft_groups = G;
+    P.fft_stride = (D / G > 1u) ? N + 1u : N;
+    uint32_t work = (uint32_t)((size_t)(D / G) * P.fft_stride * sizeof(float2));
+    if (work < 2u * sps * sizeof(float) && 2u * sps * sizeof(float) <= kWorkBudget) work = 2u * sps * (uint32_t)sizeof(float);
+    if (work < sps * sizeof(float) && sps * sizeof(float) <= kWorkBudget) work = sps * (uint32_t)sizeof(float);
+    work = (work + 15u) & ~15u;
+    P.lds_work_bytes = work;
+    P.ifreq_in_lds_1 = (sps * sizeof(float) <= work) ? 1u : 0u;
+    P.ifreq_in_lds_2 = (2u * sps * sizeof(float) <= work) ? 1u : 0u;
+
+    std::vector<float2> down(sps), up(sps), twN(N / 2u > 0 ? N / 2u : 1u), tws(sps);
+    const double T = -0.5 * c.bandwidth * symbols_per_second, f0 = c.bandwidth / 2.0, pre_dir = 2.0 * M_PI;
+    for (uint32_t i = 0; i < sps; i++) {
+        const double t = dt * i;
+        const float pd = (float)(pre_dir * t * (f0 + T * t));          // gr_expj takes a float (:159)
+        const float pu = (float)(pre_dir * t * (f0 + T * t) * -1.0f);  // :160
+        const float cd = std::cos(pd), sd = std::sin(pd), cu = std::cos(pu), su = std::sin(pu);
+        down[i] = make_float2(cd - sd, sd + cd);                       // (1+1j) * expj
+        up[i] = make_float2(cu - su, su + cu);
+    }
+    std::vector<float> down_ifreq(sps), up_ifreq(sps), up3(3u * (size_t)sps + 4u * D + 8u);
+    host_ifreq(down.data(), down_ifreq.data(), sps);
+    host_ifreq(up.data(), up_ifreq.data(), sps);
+    {
+        std::vector<float2> tmp(3u * (size_t)sps);
+        for (int r = 0; r < 3; r++) std::copy(up.begin(), up.end(), tmp.begin() + (size_t)r * sps);
+        host_ifreq(tmp.data(), up3.data(), 3u * sps);
+        // guard tail for bin_idx = N-1 (reference indexes past the vector there, :301,:310)
+        for (size_t i = 3u * (size_t)sps; i < up3.size(); i++) up3[i] = up3[3u * (size_t)sps - 1u];
+    }
+    { // chirp_avg and stddev of the ideal downchirp ifreq over sps-1 points (:287-289, :415-425)
+        const uint32_t n = sps - 1u;
+        float s = 0.0f;
+        for (uint32_t i = 0; i < n; i++) s += down_ifreq[i];
+        const float avg = s / (float)n;
+        float var = 0.0f;
+        for (uint32_t i = 0; i < n; i++) { const float t = down_ifreq[i] - avg; var += t * t; }
+        var /= (float)n;
+        P.down_ifreq_avg = avg;
+        P.down_ifreq_sd = std::sqrt(var);
+    }
+    for (uint32_t t = 0; t < N / 2u; t++) {
+        const double a = -2.0 * M_PI * (double)t / (double)N;
+        twN[t] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    for (uint32_t m = 0; m < sps; m++) {
+        const double a = -2.0 * M_PI * (double)m / (double)sps;
+        tws[m] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    lora_hip_status s;
+    if ((s = upload(h, &h->d_down, down)) != LORA_HIP_OK) return s;
+    if ((s = upload(h, &h->d_twN, twN)) != LORA_HIP_OK) return s;
+    if ((s = upload(h, &h->d_tws, tws)) != LORA_HIP_OK) return s;
+    if ((s = upload(h, &h->d_up_ifreq, up_ifreq)) != LORA_HIP_OK) return s;
+    if ((s = upload(h, &h->d_down_ifreq, down_ifreq)) != LORA_HIP_OK) return s;
+    if ((s = upload(h, &h->d_up_ifreq_v, up3)) != LORA_HIP_OK) return s;
+    P.down = h->d_down; P.twN = h->d_twN; P.tws = h->d_tws;
+    P.up_ifreq = h->d_up_ifreq; P.down_ifreq = h->d_down_ifreq; P.up_ifreq_v = h->d_up_ifreq_v;
+    return LORA_HIP_OK;
+}
+
+struct StreamDesc {
+    uint64_t off, len;
+    uint32_t id;
+    uint32_t cr_in;       // d_phdr.cr carried in
+    PwrState pwr;         // power queue / snr carried in
+    int64_t  abs_base;    // added to reported positions
+    // results
+    int64_t  final_pos = 0;
+    uint32_t cr_out = 0;
+    bool incomplete = false;
+};
+
+// Publishes the frame of one completed attempt (msg_lora_frame, :588-609).
+void publish(lora_hip_decoder *h, const AttemptRec &r, StreamDesc &sd)
+{
+    Frame f;
+    f.blob.assign((size_t)kLoratapLen + r.frame_len, 0);
+    f.blob[13] = snr_byte(sd.pwr.snr); // loratap_header.rssi.snr, byte offset 13
+    std::memcpy(f.blob.data() + kLoratapLen, r.frame, r.frame_len);
+    f.info.stream = sd.id;
+    f.info.length = (uint32_t)f.blob.size();
+    f.info.header_pos = sd.abs_base + r.hdr_pos;
+    f.info.end_pos = sd.abs_base + r.end_pos;
+    h->frames.push_back(std::move(f));
+}
+
+// Runs the walker over a set of jobs and brings results back to the host.
+lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vector<Job> &jobs, uint32_t recs_per_job,
+                         uint32_t trace_cap, hipStream_t st)
+{
+    const uint32_t nj = (uint32_t)jobs.size();
+    if (nj == 0) return LORA_HIP_OK;
+    HIP_TRY(h, h->d_jobs.reserve(nj));
+    HIP_TRY(h, h->d_results.reserve(nj));
+    HIP_TRY(h, h->d_recs.reserve((size_t)nj * recs_per_job));
+    const bool need_scratch = !h->P.ifreq_in_lds_2;
+    if (need_scratch) HIP_TRY(h, h->d_scratch.reserve((size_t)nj * 2u * h->P.sps));
+    if (trace_cap) HIP_TRY(h, h->d_trace.reserve((size_t)nj * trace_cap));
+    HIP_TRY(h, hipMemcpyAsync(h->d_jobs.p, jobs.data(), nj * sizeof(Job), hipMemcpyHostToDevice, st));
+    LaunchCfg c{};
+    c.iq = d_iq; c.jobs = h->d_jobs.p; c.results = h->d_results.p; c.recs = h->d_recs.p; c.recs_per_job = recs_per_job;
+    c.scratch = need_scratch ? h->d_scratch.p : nullptr;
+    c.trace = trace_cap ? h->d_trace.p : nullptr; c.trace_cap = trace_cap; c.n_jobs = nj;
+    HIP_TRY(h, hipEventRecord(h->ev0, st));
+    if (launch_walker(h->P, c, st) != 0) return fail(h, LORA_HIP_ERR_HIP, "walker launch failed: %s", hipGetErrorString(hipGetLastError()));
+    HIP_TRY(h, hipEventRecord(h->ev1, st));
+    h->h_results.resize(nj);
+    h->h_recs.resize((size_t)nj * recs_per_job);
+    HIP_TRY(h, hipMemcpyAsync(h->h_results.data(), h->d_results.p, nj * sizeof(JobResult), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    // copy back only the attempt records that were written
+    uint32_t max_att = 0;
+    for (uint32_t j = 0; j < nj; j++) max_att = std::max(max_att, h->h_results[j].n_attempts);
+    if (max_att > recs_per_job) max_att = recs_per_job;
+    if (max_att) {
+        HIP_TRY(h, hipMemcpy2DAsync(h->h_recs.data(), recs_per_job * sizeof(AttemptRec), h->d_recs.p,
+                                    recs_per_job * sizeof(AttemptRec), max_att * sizeof(AttemptRec), nj,
+                                    hipMemcpyDeviceToHost, st));
+    }
+    if (trace_cap) {
+        h->h_trace.resize((size_t)nj * trace_cap);
+        HIP_TRY(h, hipMemcpyAsync(h->h_trace.data(), h->d_trace.p, (size_t)nj * trace_cap * sizeof(StepRec), hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(h, hipStreamSynchronize(st));
+    float ms = 0.0f;
+    HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->timing.walker_ms += ms;
+    h->timing.walker_launches++;
+    return LORA_HIP_OK;
+}
+
+void append_trace(lora_hip_decoder *h, uint32_t job_index, uint32_t trace_cap, int64_t abs_base)
+{
+    const JobResult &jr = h->h_results[job_index];
+    for (uint32_t i = 0; i < jr.n_steps; i++) {
+        const StepRec &s = h->h_trace[(size_t)job_index * trace_cap + i];
+        lora_hip_step_t o;
+        o.state = s.state; o.consumed = s.consumed; o.pos = abs_base + s.pos; o.bin = s.bin; o.fine = s.fine;
+        o.value = s.value; o.stream = s.stream;
+        h->trace.push_back(o);
+    }
+}
+
+// Decodes a set of independent streams: one walker job per stream per round.
+// A round ends for a stream when its job reaches the end of the data; a job that
+// ran out of attempt-record capacity is continued in the next round.
+lora_hip_status decode_streams(lora_hip_decoder *h, const float2 *d_iq, std::vector<StreamDesc> &streams, hipStream_t st)
+{
+    const uint32_t sps = h->P.sps;
+    const bool tracing = (h->cfg.flags & LORA_HIP_FLAG_TRACE) != 0;
+    std::vector<uint32_t> active(streams.size());
+    std::vector<int64_t> cursor(streams.size(), 0);
+    for (size_t i = 0; i < streams.size(); i++) { active[i] = (uint32_t)i; streams[i].cr_out = streams[i].cr_in; }
+    bool first_round = true;
+    while (!active.empty()) {
+        std::vector<Job> jobs(active.size());
+        uint64_t max_len = 0;
+        for (size_t k = 0; k < active.size(); k++) {
+            const StreamDesc &sd = streams[active[k]];
+            Job &j = jobs[k];
+            j.stream_off = sd.off; j.stream_len = sd.len; j.start = cursor[active[k]];
+            j.scan_limit = (int64_t)sd.len; j.stream_id = sd.id; j.cr_prev = sd.cr_out;
+            j.max_attempts = 0; j.stop_at_header = 0;
+            max_len = std::max<uint64_t>(max_len, sd.len - (uint64_t)j.start);
+        }
+        // a completed attempt spans >= 13 symbols; lost-sync attempts >= 5 (+ DETECT steps)
+        uint32_t recs_per_job = (uint32_t)std::min<uint64_t>(max_len / (5ull * sps) + 4ull, 4096ull);
+        const uint32_t trace_cap = tracing ? (uint32_t)std::min<uint64_t>(2ull * (max_len / sps) + 64ull, 1ull << 22) : 0u;
+        if (first_round) { h->timing.jobs += (uint32_t)jobs.size(); first_round = false; }
+        lora_hip_status s = run_jobs(h, d_iq, jobs, recs_per_job, trace_cap, st);
+        if (s != LORA_HIP_OK) return s;
+        std::vector<uint32_t> next;
+        for (size_t k = 0; k < active.size(); k++) {
+            StreamDesc &sd = streams[active[k]];
+            const JobResult &jr = h->h_results[k];
+            const uint32_t n_done = jr.pad ? jr.n_attempts - 1u : jr.n_attempts;
+            for (uint32_t a = 0; a < n_done && a < recs_per_job; a++) {
+                const AttemptRec &r = h->h_recs[k * (size_t)recs_per_job + a];
+                sd.pwr.apply(r.npush, r.push_tail);
+                sd.pwr.determine_snr(); // at the DETECT trigger (:756)
+                if (r.status == kAttemptFrame) publish(h, r, sd);
+            }
+            if (!jr.pad) sd.pwr.apply(jr.npush, jr.push_tail);
+            sd.cr_out = jr.final_cr;
+            sd.final_pos = jr.final_pos;
+            sd.incomplete = jr.pad != 0;
+            if (tracing) append_trace(h, (uint32_t)k, trace_cap, sd.abs_base);
+            if (jr.stop_reason == 2u) { cursor[active[k]] = jr.final_pos; next.push_back(active[k]); }
+        }
+        active.swap(next);
+    }
+    return LORA_HIP_OK;
+}
+
+} // namespace
+
+// ============================================================== C ABI ========
+
+extern "C" {
+
+uint32_t lora_hip_abi_version(void) { return LORA_HIP_ABI_VERSION; }
+
+const char *lora_hip_strerror(lora_hip_status s)
+{
+    switch (s) {
+    case LORA_HIP_OK: return "ok";
+    case LORA_HIP_ERR_BAD_SF: return "spreading factor should be between 6 and 12 (inclusive)";
+    case LORA_HIP_ERR_BAD_CONFIG: return "unsupported configuration";
+    case LORA_HIP_ERR_NO_DEVICE: return "no usable HIP device (there is no CPU fallback)";
+    case LORA_HIP_ERR_HIP: return "HIP runtime error";
+    case LORA_HIP_ERR_NOMEM: return "out of memory";
+    case LORA_HIP_ERR_ARG: return "bad argument";
+    case LORA_HIP_ERR_OVERFLOW: return "buffer too small";
+    default: return "internal error";
+    }
+}
+
+const char *lora_hip_last_error(const lora_hip_decoder_t *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+lora_hip_status lora_hip_create(const lora_hip_config_t *cfg, lora_hip_decoder_t **out)
+{
+    if (!cfg || !out) return LORA_HIP_ERR_ARG;
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(lora_hip_config_t)) return LORA_HIP_ERR_ARG;
+    if (cfg->sf < 6 || cfg->sf > 12) return LORA_HIP_ERR_BAD_SF; // :57-61 (message says 6..12)
+    if (cfg->cr > 4 || cfg->demod < 0 || cfg->demod > 2 || cfg->bandwidth == 0 || !(cfg->samp_rate >= 1.0f)) return LORA_HIP_ERR_BAD_CONFIG;
+    int ndev = 0;
+    const hipError_t ec = hipGetDeviceCount(&ndev);
+    if (ec != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, LORA_HIP_ERR_NO_DEVICE, "hipGetDeviceCount: %s, %d device(s), requested %d", hipGetErrorString(ec), ndev, cfg->device);
+    lora_hip_decoder *h = new (std::nothrow) lora_hip_decoder();
+    if (!h) return LORA_HIP_ERR_NOMEM;
+    h->cfg = *cfg;
+    h->device = cfg->device;
+    lora_hip_status s = LORA_HIP_OK;
+    const hipError_t es = hipSetDevice(h->device);
+    if (es != hipSuccess) s = fail(nullptr, LORA_HIP_ERR_NO_DEVICE, "hipSetDevice(%d): %s", h->device, hipGetErrorString(es));
+    if (s == LORA_HIP_OK) s = build_tables(h);
+    if (s == LORA_HIP_OK && (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess)) s = LORA_HIP_ERR_HIP;
+    if (s != LORA_HIP_OK) { lora_hip_destroy(h); return s; }
+    h->stream_cr = h->P.ctor_cr;
+    h->batch_items = cfg->batch_items ? cfg->batch_items : std::max<size_t>(1u << 20, 64ull * h->P.sps);
+    h->batch_need = h->batch_items;
+    *out = h;
+    return LORA_HIP_OK;
+}
+
+void lora_hip_destroy(lora_hip_decoder_t *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->d_down) (void)hipFree(h->d_down);
+    if (h->d_twN) (void)hipFree(h->d_twN);
+    if (h->d_tws) (void)hipFree(h->d_tws);
+    if (h->d_up_ifreq) (void)hipFree(h->d_up_ifreq);
+    if (h->d_down_ifreq) (void)hipFree(h->d_down_ifreq);
+    if (h->d_up_ifreq_v) (void)hipFree(h->d_up_ifreq_v);
+    h->d_jobs.release(); h->d_results.release(); h->d_recs.release(); h->d_scratch.release();
+    h->d_trace.release(); h->d_staging.release(); h->d_offsets.release(); h->d_bins.release();
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    delete h;
+}
+
+lora_hip_status lora_hip_get_geometry(const lora_hip_decoder_t *h, uint32_t *sps, uint32_t *bins, uint32_t *decim)
+{
+    if (!h) return LORA_HIP_ERR_ARG;
+    if (sps) *sps = h->P.sps;
+    if (bins) *bins = h->P.nbins;
+    if (decim) *decim = h->P.decim;
+    return LORA_HIP_OK;
+}
+
+lora_hip_status lora_hip_set_sf(lora_hip_decoder_t *h, uint8_t sf)
+{ // :905-909 -- warn only
+    if (!h) return LORA_HIP_ERR_ARG;
+    (void)sf;
+    fprintf(stderr, "[LoRa Decoder] WARNING : Setting the spreading factor during execution is currently not supported.\n"
+                    "Nothing set, kept SF of %u.\n", (unsigned)h->P.sf);
+    return LORA_HIP_OK;
+}
+
+lora_hip_status lora_hip_set_samp_rate(lora_hip_decoder_t *h, float samp_rate)
+{ // :911-915 -- warn only
+    if (!h) return LORA_HIP_ERR_ARG;
+    (void)samp_rate;
+    fprintf(stderr, "[LoRa Decoder] WARNING : Setting the sample rate during execution is currently not supported.\n"
+                    "Nothing set, kept SR of %u.\n", (unsigned)h->cfg.samp_rate);
+    return LORA_HIP_OK;
+}
+
+lora_hip_status lora_hip_decode_device(lora_hip_decoder_t *h, const void *d_iq, size_t total_items,
+                                       const uint64_t *stream_off, const uint64_t *stream_len, uint32_t n_streams,
+                                       void *hip_stream)
+{
+    if (!h || (!d_iq && total_items) || (n_streams && (!stream_off || !stream_len))) return LORA_HIP_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    h->timing = lora_hip_timing_t{};
+    std::vector<StreamDesc> sds(n_streams);
+    for (uint32_t i = 0; i < n_streams; i++) {
+        if (stream_off[i] + stream_len[i] > total_items) return fail(h, LORA_HIP_ERR_ARG, "stream %u exceeds the buffer", i);
+        sds[i].off = stream_off[i]; sds[i].len = stream_len[i]; sds[i].id = i;
+        sds[i].cr_in = h->P.ctor_cr; sds[i].abs_base = 0;
+        h->timing.items += stream_len[i];
+    }
+    return decode_streams(h, (const float2 *)d_iq, sds, (hipStream_t)hip_stream);
+}
+
+static lora_hip_status stream_pass(lora_hip_decoder_t *h, bool flushing)
+{
+    const size_t items = h->hostbuf.size() / 2u;
+    if (items < 2u * (size_t)h->P.sps) return LORA_HIP_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, h->d_staging.reserve(items));
+    HIP_TRY(h, hipMemcpy(h->d_staging.p, h->hostbuf.data(), items * sizeof(float2), hipMemcpyHostToDevice));
+    std::vector<StreamDesc> sds(1);
+    sds[0].off = 0; sds[0].len = items; sds[0].id = 0; sds[0].cr_in = h->stream_cr; sds[0].pwr = h->stream_pwr;
+    sds[0].abs_base = h->host_base;
+    h->timing = lora_hip_timing_t{};
+    h->timing.items = items;
+    lora_hip_status s = decode_streams(h, h->d_staging.p, sds, nullptr);
+    if (s != LORA_HIP_OK) return s;
+    h->stream_cr = sds[0].cr_out;
+    h->stream_pwr = sds[0].pwr;
+    const size_t keep_from = (size_t)std::min<int64_t>(std::max<int64_t>(sds[0].final_pos, 0), (int64_t)items);
+    h->hostbuf.erase(h->hostbuf.begin(), h->hostbuf.begin() + 2 * keep_from);
+    h->host_base += (int64_t)keep_from;
+    // an attempt that ran out of data is re-run from its start once more input has
+    // arrived; wait for twice as much so the total work stays linear
+    if (sds[0].incomplete && !flushing) h->batch_need = std::max(h->batch_items, 2u * (items - keep_from));
+    else h->batch_need = h->batch_items;
+    return LORA_HIP_OK;
+}
+
+lora_hip_status lora_hip_work(lora_hip_decoder_t *h, const float *iq, size_t n_items, size_t *consumed)
+{
+    if (!h || (!iq && n_items)) return LORA_HIP_ERR_ARG;
+    h->hostbuf.insert(h->hostbuf.end(), iq, iq + 2 * n_items);
+    if (consumed) *consumed = n_items;
+    if (h->hostbuf.size() / 2u >= h->batch_need) return stream_pass(h, false);
+    return LORA_HIP_OK;
+}
+
+lora_hip_status lora_hip_flush(lora_hip_decoder_t *h)
+{
+    if (!h) return LORA_HIP_ERR_ARG;
+    return stream_pass(h, true);
+}
+
+size_t lora_hip_frames_available(const lora_hip_decoder_t *h) { return h ? h->frames.size() : 0; }
+
+lora_hip_status lora_hip_poll_frame(lora_hip_decoder_t *h, uint8_t *buf, size_t cap, size_t *len, lora_hip_frame_info_t *info)
+{
+    if (!h || !len) return LORA_HIP_ERR_ARG;
+    if (h->frames.empty()) { *len = 0; return LORA_HIP_OK; }
+    const Frame &f = h->frames.front();
+    *len = f.blob.size();
+    if (!buf || cap < f.blob.size()) return LORA_HIP_ERR_OVERFLOW;
+    std::memcpy(buf, f.blob.data(), f.blob.size());
+    if (info) *info = f.info;
+    h->frames.pop_front();
+    return LORA_HIP_OK;
+}
+
+lora_hip_status lora_hip_demod_symbols_device(lora_hip_decoder_t *h, const void *d_iq, size_t total_items,
+                                              const int64_t *offsets, size_t n, int demod, uint32_t *bins_out,
+                                              void *hip_stream)
+{
+    if (!h || !d_iq || (n && (!offsets || !bins_out)) || demod < 0 || demod > 2) return LORA_HIP_ERR_ARG;
+    if (n == 0) return LORA_HIP_OK;
+    for (size_t i = 0; i < n; i++)
+        if (offsets[i] < 0 || (uint64_t)offsets[i] + h->P.sps > total_items) return fail(h, LORA_HIP_ERR_ARG, "symbol %zu out of range", i);
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, h->d_offsets.reserve(n));
+    HIP_TRY(h, h->d_bins.reserve(n));
+    const uint32_t grid = (uint32_t)std::min<size_t>(n, 2048);
+    if (!h->P.ifreq_in_lds_1) HIP_TRY(h, h->d_scratch.reserve((size_t)grid * 2u * h->P.sps));
+    HIP_TRY(h, hipMemcpyAsync(h->d_offsets.p, offsets, n * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    if (launch_demod_symbols(h->P, (const float2 *)d_iq, h->d_offsets.p, (uint32_t)n, demod, h->d_bins.p,
+                             h->P.ifreq_in_lds_1 ? nullptr : h->d_scratch.p, st) != 0)
+        return fail(h, LORA_HIP_ERR_HIP, "demod launch failed: %s", hipGetErrorString(hipGetLastError()));
+    HIP_TRY(h, hipMemcpyAsync(bins_out, h->d_bins.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    return LORA_HIP_OK;
+}
+
+lora_hip_status lora_hip_last_timing(const lora_hip_decoder_t *h, lora_hip_timing_t *t)
+{
+    if (!h || !t) return LORA_HIP_ERR_ARG;
+    *t = h->timing;
+    return LORA_HIP_OK;
+}
+
+size_t lora_hip_trace(const lora_hip_decoder_t *h, const lora_hip_step_t **steps)
+{
+    if (!h || !steps) return 0;
+    *steps = h->trace.data();
+    return h->trace.size();
+}
+
+void lora_hip_trace_clear(lora_hip_decoder_t *h)
+{
+    if (h) h->trace.clear();
+}
+
+} // extern "C"

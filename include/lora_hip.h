@@ -1,0 +1,157 @@
+/*
+ * lora_hip.h -- C ABI of the MI355X-native LoRa PHY decoder (liblora_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of rpp0/gr-lora's
+ * gr::lora::decoder (reference: include/lora/decoder.h:693-709,
+ * lib/decoder_impl.cc).  Plain C types only: no GNU Radio, PMT, torch or HIP
+ * types cross it (device pointers and the HIP stream travel as void*).
+ * Every entry point names the reference interface it replaces.
+ *
+ * Error convention: the reference never returns errors -- fatal conditions
+ * exit(1) (decoder_impl.cc:57-61, 541-545, 602-605).  Here every call returns
+ * a lora_hip_status; a GNU Radio shim maps the fatal ones to the reference's
+ * exit(1).  One handle == one decoder instance == one
+ * caller thread at a time, exactly like one GNU Radio block; distinct handles
+ * are independent.
+ */
+#ifndef LORA_HIP_H
+#define LORA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LORA_HIP_ABI_VERSION 1
+
+typedef enum lora_hip_status {
+    LORA_HIP_OK = 0,
+    LORA_HIP_ERR_BAD_SF = -1,      /* sf < 6 || sf > 12: reference prints and exit(1)s (decoder_impl.cc:57-61) */
+    LORA_HIP_ERR_BAD_CONFIG = -2,  /* samples/symbol not a power-of-two multiple of 2^sf, cr > 4, ... */
+    LORA_HIP_ERR_NO_DEVICE = -3,   /* no HIP device / device id out of range -- there is NO CPU fallback */
+    LORA_HIP_ERR_HIP = -4,         /* a HIP runtime call failed; see lora_hip_last_error() */
+    LORA_HIP_ERR_NOMEM = -5,
+    LORA_HIP_ERR_ARG = -6,         /* NULL / out-of-range argument */
+    LORA_HIP_ERR_OVERFLOW = -7,    /* caller buffer too small */
+    LORA_HIP_ERR_INTERNAL = -8
+} lora_hip_status;
+
+/* Demodulator used inside demodulate() (decoder_impl.cc:499-500). */
+typedef enum lora_hip_demod {
+    LORA_HIP_DEMOD_GRAD = 0,        /* max_frequency_gradient_idx (:466-491), the reference's shipped default */
+    LORA_HIP_DEMOD_FFT = 1,         /* get_shift_fft (:430-464): dechirp x FFT x argmax; bin_idx = (s-1) mod N   */
+    LORA_HIP_DEMOD_FFT_COMPAT = 2   /* FFT, but s == 0 -> bin_idx 0: byte-identical to the default path's quirk */
+} lora_hip_demod;
+
+#define LORA_HIP_FLAG_TRACE 0x1u    /* record one lora_hip_step_t per state-machine step (tests / debugging) */
+
+/* Constructor arguments of gr::lora::decoder::make (include/lora/decoder.h:705;
+ * python/bindings/decoder_python.cc:36-66), plus the device-side knobs.        */
+typedef struct lora_hip_config {
+    uint32_t struct_size;            /* sizeof(lora_hip_config_t), for ABI growth                           */
+    float    samp_rate;              /* decoder::make arg 1                                                  */
+    uint32_t bandwidth;              /* arg 2                                                                */
+    uint8_t  sf;                     /* arg 3                                                                */
+    uint8_t  implicit;               /* arg 4                                                                */
+    uint8_t  cr;                     /* arg 5: initial d_phdr.cr (also decides the first header's FEC, :655) */
+    uint8_t  crc;                    /* arg 6                                                                */
+    uint8_t  reduced_rate;           /* arg 7                                                                */
+    uint8_t  disable_drift_correction; /* arg 8                                                              */
+    uint8_t  reserved0[2];
+    int32_t  device;                 /* HIP device ordinal                                                   */
+    int32_t  demod;                  /* lora_hip_demod                                                       */
+    uint32_t flags;                  /* LORA_HIP_FLAG_*                                                      */
+    uint32_t segment_symbols;        /* speculation segment length in symbols for long streams; 0 = auto     */
+    uint32_t batch_items;            /* streaming: items buffered before a device pass; 0 = auto             */
+} lora_hip_config_t;
+
+/* Where a published frame came from. */
+typedef struct lora_hip_frame_info {
+    uint32_t stream;                 /* index into the stream list of the producing call (0 for lora_hip_work) */
+    uint32_t length;                 /* blob length in bytes                                                   */
+    int64_t  header_pos;             /* sample index (within its stream) of the first header symbol           */
+    int64_t  end_pos;                /* sample index just after the last consumed payload symbol              */
+} lora_hip_frame_info_t;
+
+/* One state-machine step (one reference work() call), for position-exact tests. */
+typedef struct lora_hip_step {
+    int32_t state;                   /* DecoderState on entry (lib/decoder_impl.h:40-48 order)               */
+    int32_t consumed;                /* consume_each() amount                                                 */
+    int64_t pos;                     /* stream sample index of input[0]                                       */
+    int32_t bin;                     /* bin_idx before rate reduction, -1 if none                             */
+    int32_t fine;                    /* d_fine_sync after the step                                            */
+    float   value;                   /* autocorr / sync corr / SFD corr                                       */
+    uint32_t stream;
+} lora_hip_step_t;
+
+/* Device timing of the last lora_hip_decode_device()/lora_hip_flush() pass,
+ * measured with HIP events on the launch stream.                                                               */
+typedef struct lora_hip_timing {
+    float    walker_ms;              /* sum over the walker (decoder state-machine) kernel launches          */
+    float    total_device_ms;        /* first launch -> last device op of the pass                           */
+    uint32_t walker_launches;
+    uint32_t jobs;                   /* workgroups launched in the main pass                                  */
+    uint32_t probes;                 /* stitch probes launched                                                */
+    uint32_t slow_path_relaunches;   /* serial fix-ups after a failed speculation                             */
+    uint64_t items;                  /* IQ items covered                                                      */
+} lora_hip_timing_t;
+
+typedef struct lora_hip_decoder lora_hip_decoder_t;
+
+/* ---- lifetime: decoder::make / ~decoder_impl (decoder_impl.cc:41-44, 49-139) ---------------------------- */
+lora_hip_status lora_hip_create(const lora_hip_config_t *cfg, lora_hip_decoder_t **out);
+void            lora_hip_destroy(lora_hip_decoder_t *h);
+const char     *lora_hip_strerror(lora_hip_status s);
+const char     *lora_hip_last_error(const lora_hip_decoder_t *h);
+uint32_t        lora_hip_abi_version(void);
+
+/* derived rates the constructor prints (decoder_impl.cc:83-87, 93-96) */
+lora_hip_status lora_hip_get_geometry(const lora_hip_decoder_t *h, uint32_t *samples_per_symbol,
+                                      uint32_t *bins, uint32_t *decimation);
+
+/* warn-only no-ops in the reference (decoder_impl.cc:905-915); return OK and change nothing */
+lora_hip_status lora_hip_set_sf(lora_hip_decoder_t *h, uint8_t sf);
+lora_hip_status lora_hip_set_samp_rate(lora_hip_decoder_t *h, float samp_rate);
+
+/* ---- streaming: replaces decoder_impl::work() (decoder_impl.cc:740-903) --------------------------------- */
+/* Accepts n_items host cf32 items (interleaved re,im) in arbitrary chunking; all of them are consumed
+ * (buffered internally).  Frames become available through lora_hip_poll_frame in stream order and are
+ * identical to what symbol-at-a-time consumption publishes on the "frames" port (:607-608).               */
+lora_hip_status lora_hip_work(lora_hip_decoder_t *h, const float *iq, size_t n_items, size_t *consumed);
+/* Runs the device pass over everything buffered, honouring the scheduler rule that work() is only called
+ * while 2*samples_per_symbol items remain (set_output_multiple, :91).                                      */
+lora_hip_status lora_hip_flush(lora_hip_decoder_t *h);
+
+/* ---- batched, device-resident: many independent streams in one pass ------------------------------------- */
+/* d_iq: device pointer to cf32 items; stream i occupies items [stream_off[i], stream_off[i]+stream_len[i]).
+ * Each stream is decoded as by a fresh reference decoder instance constructed with this handle's config.
+ * hip_stream: hipStream_t to launch on (NULL = default stream).  Synchronous on return.                    */
+lora_hip_status lora_hip_decode_device(lora_hip_decoder_t *h, const void *d_iq, size_t total_items,
+                                       const uint64_t *stream_off, const uint64_t *stream_len,
+                                       uint32_t n_streams, void *hip_stream);
+
+/* ---- "frames" message port (decoder_impl.cc:120, 588-609) ----------------------------------------------- */
+size_t          lora_hip_frames_available(const lora_hip_decoder_t *h);
+/* Pops the oldest frame: blob = loratap_header_t (15 B, include/lora/loratap.h:35-55) | loraphy_header_t
+ * (3 B, include/lora/loraphy.h:25-32) | payload (+2 CRC bytes).  info may be NULL.                          */
+lora_hip_status lora_hip_poll_frame(lora_hip_decoder_t *h, uint8_t *buf, size_t cap, size_t *len,
+                                    lora_hip_frame_info_t *info);
+
+/* ---- symbol-level access for the +-1-bin tests (get_shift_fft :430-464, gradient :466-491) -------------- */
+/* offsets (host array, n entries): symbol start item indices into d_iq; bins_out (host, n entries):
+ * the raw return value of the selected demodulator (FFT: shift s; GRAD: s-1).                              */
+lora_hip_status lora_hip_demod_symbols_device(lora_hip_decoder_t *h, const void *d_iq, size_t total_items,
+                                              const int64_t *offsets, size_t n, int demod,
+                                              uint32_t *bins_out, void *hip_stream);
+
+/* ---- introspection --------------------------------------------------------------------------------------- */
+lora_hip_status lora_hip_last_timing(const lora_hip_decoder_t *h, lora_hip_timing_t *t);
+size_t          lora_hip_trace(const lora_hip_decoder_t *h, const lora_hip_step_t **steps);
+void            lora_hip_trace_clear(lora_hip_decoder_t *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LORA_HIP_H */
