@@ -39,7 +39,7 @@ class FrameInfo(C.Structure):
 
 class Step(C.Structure):
     _fields_ = [("state", C.c_int32), ("consumed", C.c_int32), ("pos", C.c_int64), ("bin", C.c_int32),
-                ("fine", C.c_int32), ("value", C.c_float), ("stream", C.c_uint32)]
+                ("fine", C.c_int32), ("value", C.c_float), ("stream", C.c_uint32), ("cycles", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Timing(C.Structure):
@@ -183,7 +183,7 @@ class Handle:
     def trace(self):
         p = C.POINTER(Step)()
         n = self.L.lora_hip_trace(self.h, C.byref(p))
-        return [(p[i].state, p[i].pos, p[i].consumed, p[i].bin, p[i].fine, p[i].value, p[i].stream) for i in range(n)]
+        return [(p[i].state, p[i].pos, p[i].consumed, p[i].bin, p[i].fine, p[i].value, p[i].stream, p[i].cycles) for i in range(n)]
 
     def trace_clear(self):
         self.L.lora_hip_trace_clear(self.h)

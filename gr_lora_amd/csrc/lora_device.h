@@ -90,6 +90,8 @@ struct StepRec {           // mirrors lora_hip_step_t
     int32_t  bin, fine;
     float    value;
     uint32_t stream;
+    uint32_t cycles;     // shader clocks spent in this step (s_memtime), tracing only
+    uint32_t pad;
 };
 
 // host-side launchers implemented in lora_kernels.hip

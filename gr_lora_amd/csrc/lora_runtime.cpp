@@ -319,7 +319,7 @@ void append_trace(lora_hip_decoder *h, uint32_t job_index, uint32_t trace_cap, i
         const StepRec &s = h->h_trace[(size_t)job_index * trace_cap + i];
         lora_hip_step_t o;
         o.state = s.state; o.consumed = s.consumed; o.pos = abs_base + s.pos; o.bin = s.bin; o.fine = s.fine;
-        o.value = s.value; o.stream = s.stream;
+        o.value = s.value; o.stream = s.stream; o.cycles = s.cycles; o.reserved = 0;
         h->trace.push_back(o);
     }
 }

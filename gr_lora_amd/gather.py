@@ -1,0 +1,64 @@
+"""Frame gather over torch.distributed (RCCL over xGMI on MI355X, gloo on CPU).
+
+Streams / packets are independent, so ranks never exchange IQ or intermediate
+state: the only collective on the path is this gather of decoded frames to every
+rank (rank 0 consumes it).  Fixed-size slots keep it to two all_gathers:
+  slot = { u32 stream, u32 length, i64 header_pos, u8 blob[280] }   (296 bytes)
+A frame blob is at most 15 + 3 + 257 = 275 bytes.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+SLOT_BLOB = 280
+SLOT_BYTES = 16 + SLOT_BLOB
+
+
+def pack_frames(frames: Sequence[Tuple[bytes, int, int]], capacity: int) -> np.ndarray:
+    """frames: (blob, stream, header_pos) -> uint8 [capacity, SLOT_BYTES]"""
+    out = np.zeros((capacity, SLOT_BYTES), dtype=np.uint8)
+    for i, (blob, stream, hpos) in enumerate(frames):
+        if i >= capacity:
+            raise ValueError("frame slot capacity exceeded")
+        if len(blob) > SLOT_BLOB:
+            raise ValueError("frame blob too long")
+        hdr = np.zeros(2, dtype=np.uint32)
+        hdr[0], hdr[1] = stream, len(blob)
+        out[i, 0:8] = hdr.view(np.uint8)
+        out[i, 8:16] = np.array([hpos], dtype=np.int64).view(np.uint8)
+        out[i, 16:16 + len(blob)] = np.frombuffer(blob, dtype=np.uint8)
+    return out
+
+
+def unpack_frames(slots: np.ndarray, count: int) -> List[Tuple[bytes, int, int]]:
+    out = []
+    for i in range(count):
+        stream, length = slots[i, 0:8].view(np.uint32)
+        hpos = int(slots[i, 8:16].view(np.int64)[0])
+        out.append((bytes(slots[i, 16:16 + int(length)]), int(stream), hpos))
+    return out
+
+
+def gather_frames(frames: Sequence[Tuple[bytes, int, int]], device: torch.device, group=None) -> List[List[Tuple[bytes, int, int]]]:
+    """All ranks contribute their frames; returns per-rank frame lists (on every rank)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [list(frames)]
+    world = dist.get_world_size(group)
+    cnt = torch.tensor([len(frames)], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(counts, cnt, group=group)
+    counts = [int(c.item()) for c in counts]
+    cap = max(1, max(counts))
+    mine = torch.from_numpy(pack_frames(frames, cap)).to(device)
+    slots = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(slots, mine, group=group)
+    return [unpack_frames(s.cpu().numpy(), c) for s, c in zip(slots, counts)]
+
+
+def shard_streams(n_streams: int, rank: int, world: int) -> List[int]:
+    """Static partition: stream c -> rank c mod world."""
+    return [c for c in range(n_streams) if c % world == rank]

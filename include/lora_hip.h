@@ -84,6 +84,8 @@ typedef struct lora_hip_step {
     int32_t fine;                    /* d_fine_sync after the step                                            */
     float   value;                   /* autocorr / sync corr / SFD corr                                       */
     uint32_t stream;
+    uint32_t cycles;                 /* shader clocks the step took on the device                            */
+    uint32_t reserved;
 } lora_hip_step_t;
 
 /* Device timing of the last lora_hip_decode_device()/lora_hip_flush() pass,

@@ -1,0 +1,60 @@
+"""N>1 path on CPU: world_size-2 gloo run of the frame gather + stream sharding."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gr_lora_amd import gather
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = gather.shard_streams(7, rank, world)
+    frames = [(bytes([rank, s]) * (3 + s), s, 1000 * s + rank) for s in mine]
+    allf = gather.gather_frames(frames, torch.device("cpu"))
+    q.put((rank, allf))
+    dist.destroy_process_group()
+
+
+def test_pack_roundtrip():
+    rng = np.random.default_rng(0)
+    frames = [(bytes(rng.integers(0, 256, int(rng.integers(18, 276)), dtype=np.uint8)), int(rng.integers(0, 64)), int(rng.integers(0, 1 << 40))) for _ in range(20)]
+    slots = gather.pack_frames(frames, 32)
+    assert gather.unpack_frames(slots, 20) == frames
+    with pytest.raises(ValueError):
+        gather.pack_frames(frames, 4)
+
+
+def test_gather_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        allf = res[r]
+        assert len(allf) == 2
+        for src in (0, 1):
+            want = [(bytes([src, s]) * (3 + s), s, 1000 * s + src) for s in gather.shard_streams(7, src, 2)]
+            assert allf[src] == want
+    assert sorted(gather.shard_streams(7, 0, 2) + gather.shard_streams(7, 1, 2)) == list(range(7))
