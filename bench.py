@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--cr", type=int, default=4)
     ap.add_argument("--packets", type=int, default=1024)
     ap.add_argument("--payload", type=int, default=32)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("LORA_BENCH_STREAMS", "1024")))
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("LORA_BENCH_STREAMS", "8")))
     ap.add_argument("--demod", type=int, default=2, help="0 grad, 1 fft, 2 fft_compat")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

@@ -93,7 +93,7 @@ def test_many_streams_in_one_pass(torch_cuda, oracle_mod):
         by_stream.setdefault(i.stream, []).append(g)
     for s in range(24):
         assert by_stream.get(s, []) == wants[s], s
-    assert tm.jobs == 24 and tm.walker_ms > 0.0
+    assert tm.jobs >= 24 and tm.walker_ms > 0.0
 
 
 def test_symbol_bins_exact_and_awgn(torch_cuda, oracle_mod):
@@ -148,3 +148,81 @@ def test_streaming_chunks_equal_batch(torch_cuda, oracle_mod):
     assert [g for g, _ in got] == want
     assert [i.header_pos for _, i in got] == st.header_starts
     h.close()
+
+
+@pytest.mark.parametrize("seg_symbols", [16, 23, 40, 64, 150])
+def test_segment_speculation_equals_serial(torch_cuda, oracle_mod, seg_symbols):
+    """One long multi-packet stream cut into speculative segments must publish exactly
+    what the serial state machine publishes (frames, order, header positions)."""
+    from gr_lora_amd import capi
+    cfg = synth.TxConfig(sf=7, cr=4)
+    rng = np.random.default_rng(4242 + seg_symbols)
+    payloads = [bytes(rng.integers(0, 256, int(rng.integers(1, 48)), dtype=np.uint8)) for _ in range(40)]
+    gaps = [int(g) for g in rng.integers(0, 7 * cfg.sps, len(payloads))]
+    gaps[5] = 0; gaps[6] = 1; gaps[7] = cfg.sps // 2; gaps[8] = 2 * cfg.sps + 3      # back-to-back / ragged
+    st = synth.build_stream(payloads, cfg, gaps=gaps)
+    dev = _to_dev(torch_cuda, st.iq)
+    # same demodulator on both sides: the gradient and FFT demodulators are different
+    # estimators and legitimately disagree on some symbols (see test_gradient_vs_fft_divergence)
+    for demod in (capi.DEMOD_FFT_COMPAT, capi.DEMOD_GRAD):
+        o = oracle_mod.Oracle(sf=7, cr=4, demod=demod)
+        o.run(st.iq)
+        want, wpos = o.frames(), o.frame_positions()
+        assert len(want) >= 30
+        h = capi.Handle(sf=7, cr=4, demod=demod, segment_symbols=seg_symbols)
+        h.decode_device(dev.data_ptr(), st.iq.size, [0], [st.iq.size], 0)
+        got = h.drain()
+        tm = h.timing()
+        assert [g for g, _ in got] == want
+        assert [i.header_pos for _, i in got] == wpos
+        assert tm.jobs >= st.iq.size // (seg_symbols * cfg.sps)
+        h.close()
+
+
+def test_gradient_vs_fft_divergence(torch_cuda, oracle_mod):
+    """A case where the reference's default (gradient) demodulator decodes a clean packet
+    wrong and the FFT demodulator does not: after an s=0 symbol (M2 quirk) fine_sync leaves
+    the window one sample late and the symbol-boundary drop beats the true wrap.  The GPU
+    follows whichever demodulator is selected, bit for bit."""
+    from gr_lora_amd import capi
+    cfg = synth.TxConfig(sf=7, cr=4)
+    rng = np.random.default_rng(4242 + 40)
+    payloads = [bytes(rng.integers(0, 256, int(rng.integers(1, 48)), dtype=np.uint8)) for _ in range(40)]
+    gaps = [int(g) for g in rng.integers(0, 7 * cfg.sps, len(payloads))]
+    gaps[5] = 0; gaps[6] = 1; gaps[7] = cfg.sps // 2; gaps[8] = 2 * cfg.sps + 3
+    st = synth.build_stream(payloads, cfg, gaps=gaps)
+    expect = [synth.expected_frame_tail(p, cfg) for p in payloads]
+    dev = _to_dev(torch_cuda, st.iq)
+    out = {}
+    for demod in (0, 1, 2):
+        h = capi.Handle(sf=7, cr=4, demod=demod)
+        h.decode_device(dev.data_ptr(), st.iq.size, [0], [st.iq.size], 0)
+        out[demod] = [g for g, _ in h.drain()]
+        h.close()
+        o = oracle_mod.Oracle(sf=7, cr=4, demod=demod)
+        o.run(st.iq)
+        assert out[demod] == o.frames()
+    assert [g[15:] for g in out[1]] == expect
+    assert [g[15:] for g in out[2]] == expect
+    assert [i for i, g in enumerate(out[0]) if g[15:] != expect[i]] == [19]
+
+
+def test_segment_speculation_noisy_and_cr_mix(torch_cuda, oracle_mod):
+    """Noise + stale-header-CR carry (ctor cr=4, stream cr=1) across segment boundaries."""
+    from gr_lora_amd import capi
+    cfg = synth.TxConfig(sf=8, cr=1)
+    rng = np.random.default_rng(99)
+    payloads = [bytes(rng.integers(0, 256, int(rng.integers(4, 30)), dtype=np.uint8)) for _ in range(24)]
+    st = synth.build_stream(payloads, cfg, rng=rng, noise_sigma=10 ** (-32 / 20.0))
+    o = oracle_mod.Oracle(sf=8, cr=4, demod=2)
+    o.run(st.iq)
+    want = o.frames()
+    assert len(want) >= 20
+    for seg in (20, 57):
+        h = capi.Handle(sf=8, cr=4, demod=capi.DEMOD_FFT_COMPAT, segment_symbols=seg)
+        dev = _to_dev(torch_cuda, st.iq)
+        h.decode_device(dev.data_ptr(), st.iq.size, [0], [st.iq.size], 0)
+        got = h.drain()
+        assert [g[15:] for g, _ in got] == [w[15:] for w in want]
+        assert [g for g, _ in got] == want
+        h.close()

@@ -147,3 +147,21 @@ def test_implicit_mode_runs(oracle_mod):
     fr = o.frames()
     assert len(fr) == 1
     assert fr[0][18:18 + len(payload)] == payload
+
+
+def test_gradient_fragility_after_quirk_symbol(oracle_mod):
+    """Documented divergence: the default gradient path decodes packet 19 of this clean
+    stream wrong (window 1 sample late after an s=0 symbol), both FFT modes decode it."""
+    cfg = synth.TxConfig(sf=7, cr=4)
+    rng = np.random.default_rng(4242 + 40)
+    payloads = [bytes(rng.integers(0, 256, int(rng.integers(1, 48)), dtype=np.uint8)) for _ in range(40)]
+    gaps = [int(g) for g in rng.integers(0, 7 * cfg.sps, len(payloads))]
+    gaps[5] = 0; gaps[6] = 1; gaps[7] = cfg.sps // 2; gaps[8] = 2 * cfg.sps + 3
+    st = synth.build_stream(payloads, cfg, gaps=gaps)
+    expect = [synth.expected_frame_tail(p, cfg) for p in payloads]
+    bad = {}
+    for mode in (0, 1, 2):
+        fr = _run(oracle_mod, st, cfg, mode).frames()
+        assert len(fr) == 40
+        bad[mode] = [i for i, f in enumerate(fr) if f[15:] != expect[i]]
+    assert bad == {0: [19], 1: [], 2: []}
