@@ -32,6 +32,7 @@ struct DevParams {
     uint32_t sf, nbins, nbins_hdr, sps, decim, log_nbins, delay_after_sync;
     uint32_t implicit, reduced_rate, enable_fine_sync, demod_mode;
     uint32_t ctor_cr, ctor_crc;
+    uint32_t use_fast;          // allow the wave-per-symbol decode rounds (SF7/SF8, D = 8)
     uint32_t fft_groups;        // passes over the symbol in get_shift_fft (1 for SF <= 10 at D = 8)
     uint32_t fft_stride;        // LDS row stride (in cf32) of one polyphase array
     uint32_t lds_work_bytes;    // size of the shared work area
@@ -39,6 +40,7 @@ struct DevParams {
     uint32_t ifreq_in_lds_2;    // 2*sps floats fit in LDS work area
     float    down_ifreq_avg;    // chirp_avg over sps-1 points (decoder_impl.cc:287)
     float    down_ifreq_sd;     // stddev of ideal downchirp ifreq (decoder_impl.cc:289)
+    float    down_ifreq_dsum;   // sum over sps-1 points of (down_ifreq - down_ifreq_avg): float residue
     const float2 *down;         // d_downchirp
     const float  *up_ifreq;     // d_upchirp_ifreq
     const float  *down_ifreq;   // d_downchirp_ifreq

@@ -178,6 +178,7 @@ lora_hip_status build_tables(lora_hip_decoder *h)
     P.enable_fine_sync = c.disable_drift_correction ? 0u : 1u;
     P.demod_mode = (uint32_t)c.demod;
     P.ctor_cr = c.cr & 7u; P.ctor_crc = c.crc ? 1u : 0u;
+    P.use_fast = getenv("LORA_HIP_NO_FAST") ? 0u : 1u;
     // get_shift_fft working set: D/G polyphase rows of N points (+1 pad) must fit the LDS budget
     uint32_t G = 1;
     while ((size_t)(D / G) * (N + 1u) * sizeof(float2) > kWorkBudget && G < D) G <<= 1;
@@ -221,6 +222,9 @@ lora_hip_status build_tables(lora_hip_decoder *h)
         var /= (float)n;
         P.down_ifreq_avg = avg;
         P.down_ifreq_sd = std::sqrt(var);
+        float ds = 0.0f;
+        for (uint32_t i = 0; i < n; i++) ds += down_ifreq[i] - avg;
+        P.down_ifreq_dsum = ds;
     }
     for (uint32_t t = 0; t < N / 2u; t++) {
         const double a = -2.0 * M_PI * (double)t / (double)N;
