@@ -20,7 +20,7 @@ FLAG_TRACE = 1
 EXPORTS = [
     "lora_hip_abi_version", "lora_hip_strerror", "lora_hip_last_error", "lora_hip_create", "lora_hip_destroy",
     "lora_hip_get_geometry", "lora_hip_set_sf", "lora_hip_set_samp_rate", "lora_hip_work", "lora_hip_flush",
-    "lora_hip_decode_device", "lora_hip_frames_available", "lora_hip_poll_frame", "lora_hip_demod_symbols_device",
+    "lora_hip_decode_device", "lora_hip_frames_available", "lora_hip_poll_frame", "lora_hip_drain_frames", "lora_hip_demod_symbols_device",
     "lora_hip_last_timing", "lora_hip_trace", "lora_hip_trace_clear",
 ]
 
@@ -92,6 +92,7 @@ def load():
     L.lora_hip_frames_available.restype = C.c_size_t
     L.lora_hip_frames_available.argtypes = [vp]
     L.lora_hip_poll_frame.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(FrameInfo)]
+    L.lora_hip_drain_frames.argtypes = [vp, vp, C.c_size_t, C.POINTER(FrameInfo), C.c_size_t, C.POINTER(C.c_size_t)]
     L.lora_hip_demod_symbols_device.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int, vp, vp]
     L.lora_hip_last_timing.argtypes = [vp, C.POINTER(Timing)]
     L.lora_hip_trace.restype = C.c_size_t
@@ -168,12 +169,26 @@ class Handle:
         return bytes(buf[: n.value]), info
 
     def drain(self) -> List[Tuple[bytes, FrameInfo]]:
+        """All queued frames, through the bulk call (one ABI crossing per 1024 frames)."""
         out = []
         while True:
-            f = self.poll_frame()
-            if f is None:
+            n_avail = self.frames_available()
+            if n_avail == 0:
                 return out
-            out.append(f)
+            k = min(n_avail, 4096)
+            buf = (C.c_uint8 * (k * 280))()
+            infos = (FrameInfo * k)()
+            n = C.c_size_t(0)
+            self._check(self.L.lora_hip_drain_frames(self.h, buf, k * 280, infos, k, C.byref(n)))
+            raw = bytes(buf)
+            off = 0
+            for i in range(n.value):
+                ln = infos[i].length
+                inf = FrameInfo(infos[i].stream, ln, infos[i].header_pos, infos[i].end_pos)
+                out.append((raw[off:off + ln], inf))
+                off += ln
+            if n.value == 0:
+                return out
 
     def timing(self) -> Timing:
         t = Timing()

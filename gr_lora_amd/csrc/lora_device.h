@@ -113,5 +113,6 @@ int launch_walker(const DevParams &p, const LaunchCfg &c, void *stream);
 int launch_demod_symbols(const DevParams &p, const float2 *iq, const int64_t *d_offsets, uint32_t n,
                          int demod, uint32_t *d_bins, float *scratch, void *stream);
 uint32_t walker_lds_bytes(const DevParams &p);
+uint32_t walker_resident_slots(const DevParams &p);
 
 } // namespace lora_hip

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <deque>
 #include <new>
 #include <string>
@@ -113,6 +114,7 @@ struct lora_hip_decoder {
     uint32_t stream_cr = 0;
     PwrState stream_pwr;
     size_t batch_items = 0, batch_need = 0;
+    uint32_t resident_slots = 0;
 };
 
 namespace {
@@ -407,8 +409,12 @@ lora_hip_status decode_streams(lora_hip_decoder *h, const float2 *d_iq, std::vec
     const bool tracing = (h->cfg.flags & LORA_HIP_FLAG_TRACE) != 0;
     uint64_t total = 0;
     for (const StreamDesc &sd : streams) total += sd.len;
+    // auto: as many segments as workgroups fit on the device at once (one wave of workgroups per launch;
+    // kernel time is ceil(jobs / resident slots) x job latency), never shorter than 64 symbols
+    if (h->resident_slots == 0) h->resident_slots = std::max<uint32_t>(walker_resident_slots(h->P), 64u);
+    const uint64_t want_jobs = std::max<uint64_t>(h->resident_slots - h->resident_slots / 16u, (uint64_t)streams.size());
     uint64_t seg = h->cfg.segment_symbols ? (uint64_t)h->cfg.segment_symbols * sps
-                                          : std::max<uint64_t>(64ull * sps, total / 2048ull);
+                                          : std::max<uint64_t>(64ull * sps, (total + want_jobs - 1) / want_jobs);
     if (seg < 16ull * sps) seg = 16ull * sps;
     const bool segmenting = !tracing && !h->P.implicit;
 
@@ -442,8 +448,11 @@ lora_hip_status decode_streams(lora_hip_decoder *h, const float2 *d_iq, std::vec
     const uint32_t trace_cap = tracing ? (uint32_t)std::min<uint64_t>(2ull * (max_span / sps) + 64ull, 1ull << 22) : 0u;
     RunOut R1;
     h->timing.jobs += (uint32_t)jobs.size();
+    static const bool dbg_t = getenv("LORA_HIP_DEBUG") != nullptr;
+    const auto tp0 = std::chrono::steady_clock::now();
     lora_hip_status s = run_jobs(h, d_iq, jobs, rpj1, trace_cap, st, R1);
     if (s != LORA_HIP_OK) return s;
+    const auto tp1 = std::chrono::steady_clock::now();
 
     // ---- round 2: probes along the speculative chain.  Only segments whose own job
     // reached a header get a probe; it starts from the end state of the previous
@@ -494,6 +503,7 @@ lora_hip_status decode_streams(lora_hip_decoder *h, const float2 *d_iq, std::vec
         if (s != LORA_HIP_OK) return s;
     }
 
+    const auto tp2 = std::chrono::steady_clock::now();
     // ---- stitch, stream by stream, in stream order
     for (size_t i = 0; i < streams.size(); i++) {
         StreamDesc &sd = streams[i];
@@ -595,6 +605,12 @@ lora_hip_status decode_streams(lora_hip_decoder *h, const float2 *d_iq, std::vec
         }
         sd.final_pos = cur.pos;
         sd.cr_out = cur.cr;
+    }
+    if (dbg_t) {
+        const auto tp3 = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[lora_hip] round1 %.3f ms (%zu jobs, rpj %u), round2 %.3f ms (%zu probes), stitch %.3f ms, walker %.3f ms\n",
+                ms(tp0, tp1), jobs.size(), rpj1, ms(tp1, tp2), pjobs.size(), ms(tp2, tp3), h->timing.walker_ms);
     }
     return LORA_HIP_OK;
 }
@@ -766,6 +782,24 @@ lora_hip_status lora_hip_poll_frame(lora_hip_decoder_t *h, uint8_t *buf, size_t 
     std::memcpy(buf, f.blob.data(), f.blob.size());
     if (info) *info = f.info;
     h->frames.pop_front();
+    return LORA_HIP_OK;
+}
+
+lora_hip_status lora_hip_drain_frames(lora_hip_decoder_t *h, uint8_t *buf, size_t cap, lora_hip_frame_info_t *infos,
+                                      size_t max_frames, size_t *n_frames)
+{
+    if (!h || !n_frames || (max_frames && (!buf || !infos))) return LORA_HIP_ERR_ARG;
+    size_t n = 0, used = 0;
+    while (n < max_frames && !h->frames.empty()) {
+        const Frame &f = h->frames.front();
+        if (used + f.blob.size() > cap) break;
+        std::memcpy(buf + used, f.blob.data(), f.blob.size());
+        infos[n] = f.info;
+        used += f.blob.size();
+        n++;
+        h->frames.pop_front();
+    }
+    *n_frames = n;
     return LORA_HIP_OK;
 }
 

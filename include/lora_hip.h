@@ -141,6 +141,11 @@ size_t          lora_hip_frames_available(const lora_hip_decoder_t *h);
 lora_hip_status lora_hip_poll_frame(lora_hip_decoder_t *h, uint8_t *buf, size_t cap, size_t *len,
                                     lora_hip_frame_info_t *info);
 
+/* Pops up to max_frames frames in one call: blobs are packed back to back into buf (infos[i].length bytes
+ * each, in order).  Stops early when the next blob would not fit.  *n_frames receives the count.            */
+lora_hip_status lora_hip_drain_frames(lora_hip_decoder_t *h, uint8_t *buf, size_t cap, lora_hip_frame_info_t *infos,
+                                      size_t max_frames, size_t *n_frames);
+
 /* ---- symbol-level access for the +-1-bin tests (get_shift_fft :430-464, gradient :466-491) -------------- */
 /* offsets (host array, n entries): symbol start item indices into d_iq; bins_out (host, n entries):
  * the raw return value of the selected demodulator (FFT: shift s; GRAD: s-1).                              */
