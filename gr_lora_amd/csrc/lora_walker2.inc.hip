@@ -1,0 +1,526 @@
+// lora_walker2.inc.hip -- the SF7 / SF8 (decimation 8, explicit header, FFT demodulators) walker.
+// Included by lora_kernels.hip.
+//
+// Same state machine as walker_body (decoder_impl::work, lib/decoder_impl.cc:740-903), organised in
+// ROUNDS of 8 wavefronts (512 threads): in DETECT, FIND_SFD and DECODE_* every wavefront evaluates one
+// upcoming symbol window at pos + w*sps (zero drift assumed), then thread 0 replays the reference's
+// per-call logic over the 8 results in order and stops at the first one whose outcome invalidates the
+// later windows (a trigger, a state change, d_fine_sync != 0, end of data).  The accepted sequence is
+// therefore exactly the serial one.  SYNC (one O(sps^2) correlation per packet) is computed by all 8
+// wavefronts together.  The decoder state lives in LDS; per-lane registers only hold symbol data.
+
+constexpr int kW2 = 512;
+constexpr int kW2Waves = kW2 / 64;
+
+struct alignas(16) W2State {
+    int64_t  pos, att_start, att_trig, att_hdr;
+    int32_t  state, done, stop_reason, in_attempt;
+    uint32_t corr_fails, cr, has_crc, payload_length;
+    int32_t  payload_symbols;
+    uint32_t n_words, n_cw, n_sym;
+    uint32_t n_att, npush, n_steps, frame_ok;
+    uint32_t att_cr_prev, att_ambig;
+    float    energy_threshold;
+    float    push_tail[4];
+    uint8_t  phdr[4];
+    // payload finalisation requested by thread 0, executed by the whole workgroup
+    uint32_t fin_pending, fin_n_bytes, fin_plen;
+    int32_t  fin_st, fin_consumed, fin_bin, fin_fine;
+};
+
+struct alignas(16) W2Shared {
+    float    red[kW2Waves * 64 + 64];
+    float    specf[kW2Waves][4];
+    int32_t  speci[kW2Waves][4];
+    Shared   sh;      // words / codewords / decoded bytes (shared with the integer-chain helpers)
+    W2State  st;
+};
+
+struct W2Tabs {
+    const float  *v;     // d_upchirp_ifreq_v (+ guard)
+    const float2 *down;  // d_downchirp
+    const float  *dd;    // d_downchirp_ifreq[k] - chirp_avg
+    const float2 *tws;   // e^{-2 pi i m / sps}
+    const float2 *twN;   // e^{-2 pi i t / N}
+};
+
+__device__ __forceinline__ void w2_block_argmax_first(float &v, int &idx, float *red)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+    __syncthreads();
+    if (lane == 0) { red[wave] = v; ((int *)red)[16 + wave] = idx; }
+    __syncthreads();
+    v = red[0]; idx = ((int *)red)[16];
+#pragma unroll
+    for (int w = 1; w < kW2Waves; w++) {
+        const float ov = red[w];
+        const int oi = ((int *)red)[16 + w];
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+}
+
+// branch-free instantaneous_frequency of one pair from their phases (:236-239)
+__device__ __forceinline__ float unwrap_diff(float pp, float p2)
+{
+    p2 = ((double)(p2 - pp) > M_PI) ? (float)((double)p2 - 2.0 * M_PI) : p2;
+    p2 = ((double)(p2 - pp) < -M_PI) ? (float)((double)p2 + 2.0 * M_PI) : p2;
+    return p2 - pp;
+}
+
+// ---- thread-0 bookkeeping (mirrors end_step / the loop-top checks of walker_body) ---------------------
+__device__ bool w2_pre_step(W2State &S, const Job &job, const LaunchCfg &C, uint32_t sps)
+{
+    if (S.state == kDetect && !S.in_attempt) {
+        if (S.pos >= job.scan_limit) { S.stop_reason = 0; S.done = 1; return false; }
+        if (S.n_att >= C.recs_per_job) { S.stop_reason = 2; S.done = 1; return false; }
+        if (job.max_attempts && S.n_att >= job.max_attempts) { S.stop_reason = 3; S.done = 1; return false; }
+    }
+    if (S.pos + 2 * (int64_t)sps > (int64_t)job.stream_len) { S.stop_reason = 1; S.done = 1; return false; } // :91
+    return true;
+}
+
+__device__ void w2_end_step(W2State &S, const Job &job, const LaunchCfg &C, AttemptRec *recs, StepRec *trace, int32_t st_in,
+                            int32_t consumed, int32_t step_bin, int32_t fine, float step_val, long long t_start)
+{
+    if (trace && S.n_steps < C.trace_cap) {
+        StepRec &s = trace[S.n_steps];
+        s.state = st_in; s.consumed = consumed; s.pos = S.pos; s.bin = step_bin; s.fine = fine; s.value = step_val;
+        s.stream = job.stream_id; s.cycles = (uint32_t)(clock64() - t_start); s.pad = 0;
+    }
+    S.n_steps++;
+    S.pos += consumed;
+    if (S.in_attempt && S.state == kDetect) { // attempt finished: frame published, or sync lost
+        AttemptRec &r = recs[S.n_att];
+        r.status = S.frame_ok ? kAttemptFrame : kAttemptLostSync;
+        if (!S.frame_ok) r.frame_len = 0;
+        r.start_pos = S.att_start; r.trig_pos = S.att_trig; r.hdr_pos = S.att_hdr; r.end_pos = S.pos;
+        r.npush = S.npush;
+        for (int i = 0; i < 4; i++) r.push_tail[i] = S.push_tail[i];
+        r.cr_prev = S.att_cr_prev; r.hdr_ambig = S.att_ambig; r.n_symbols = S.n_sym;
+        S.n_att++;
+        S.in_attempt = 0;
+        S.frame_ok = 0;
+        S.npush = 0;
+        S.att_start = S.pos;
+    } else if (S.in_attempt && job.stop_at_header && S.state == kDecodeHeader) {
+        S.stop_reason = 3;
+        S.done = 1;
+    }
+}
+
+// everything demodulate()/work() do once the bin is known (:506-529, :826-886); thread 0 only.
+// Returns true when the payload is complete: the caller must run the workgroup-wide finalisation.
+__device__ bool w2_post_symbol(const DevParams &P, W2State &S, Shared &sh, uint32_t bin_idx, bool is_first)
+{
+    const bool reduced = is_first || P.reduced_rate; // :495
+    if (reduced) bin_idx = (uint32_t)(lroundf((float)bin_idx / 4.0f) % (long)P.nbins_hdr); // :507-509
+    const uint32_t word = bin_idx ^ (bin_idx >> 1u); // :512
+    const uint32_t need = 4u + (is_first ? 4u : S.cr); // :521
+    bool block_done = false;
+    if (S.n_words < 16u) sh.words[S.n_words] = word;
+    S.n_words++;
+    S.n_sym++;
+    if (S.n_words == need) {
+        const uint32_t ppm = reduced ? P.sf - 2u : P.sf;
+        uint32_t tmp = S.n_cw;
+        deinterleave_block(sh, need, ppm, tmp);
+        S.n_cw = (S.n_cw + ppm <= (uint32_t)kMaxCodewords) ? S.n_cw + ppm : (uint32_t)kMaxCodewords;
+        S.n_words = 0;
+        block_done = true;
+    }
+    if (is_first) {
+        if (block_done) { // decode(true) and header parse (:831-847)
+            uint8_t hA[3], hB[3], h0[3] = {0, 0, 0};
+            decode_header_bytes(sh, S.n_cw, 2, hA);
+            decode_header_bytes(sh, S.n_cw, 1, hB);
+            const uint8_t *use = (S.cr >= 3u) ? hA : (S.cr >= 1u ? hB : h0);
+            S.phdr[0] = use[0]; S.phdr[1] = use[1]; S.phdr[2] = use[2];
+            S.att_ambig = (uint32_t)((hA[0] != hB[0]) || (hA[1] != hB[1]) || (hA[2] != hB[2]));
+            const uint32_t rem = S.n_cw > 5u ? S.n_cw - 5u : 0u; // erase the 5 header codewords (:632)
+            for (uint32_t i = 0; i < rem; i++) sh.cw[i] = sh.cw[i + 5u];
+            S.n_cw = rem;
+            if ((S.phdr[1] >> 5) > 4) S.phdr[1] = (uint8_t)((S.phdr[1] & 0x1f) | (4u << 5)); // :834-835
+            S.cr = S.phdr[1] >> 5;
+            S.has_crc = (S.phdr[1] >> 4) & 1u;
+            S.payload_length = (uint32_t)S.phdr[0] + 2u * S.has_crc; // :838
+            const uint32_t redundancy = P.reduced_rate ? 2u : 0u; // :842-847
+            const int symbols_per_block = (int)S.cr + 4;
+            const float bits_needed = (float)S.payload_length * 8.0f;
+            const float symbols_needed = bits_needed * ((float)symbols_per_block / 4.0f) / (float)(P.sf - redundancy);
+            const int blocks_needed = (int)ceilf(symbols_needed / (float)symbols_per_block);
+            S.payload_symbols = blocks_needed * symbols_per_block;
+            S.state = kDecodePayload;
+        }
+        return false;
+    }
+    if (block_done) S.payload_symbols -= (int32_t)(4u + S.cr); // :866-867
+    if (S.payload_symbols <= 0) { // :870-881
+        uint32_t n_bytes;
+        if (S.cr >= 3u) n_bytes = (uint32_t)ceilf((float)S.n_cw * 4.0f / (4.0f + (float)S.cr)); // :658
+        else n_bytes = (S.n_cw + 1u) / 2u;
+        if (n_bytes > (uint32_t)(kMaxCodewords / 2 + 8)) n_bytes = kMaxCodewords / 2 + 8;
+        S.fin_n_bytes = n_bytes;
+        S.fin_plen = S.payload_length > 257u ? 257u : S.payload_length;
+        return true;
+    }
+    return false;
+}
+
+// ---- wave-level window evaluations ---------------------------------------------------------------------
+// DETECT (:340-366): sums of c1*conj(c2), |c1|^2, |c2|^2 over one symbol pair
+template <int SF>
+__device__ __forceinline__ void w2_detect_window(const float2 *__restrict__ p, float (&out)[4])
+{
+    constexpr int SPS = 8 << SF, J = SPS / 64;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // see fast_demod_symbol
+    const int lane = threadIdx.x & 63;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const float2 c1 = p[j * 64 + lane], c2 = p[SPS + j * 64 + lane];
+        a0 += c1.x * c2.x + c1.y * c2.y;
+        a1 += c1.y * c2.x - c1.x * c2.y;
+        a2 += c1.x * c1.x + c1.y * c1.y;
+        a3 += c2.x * c2.x + c2.y * c2.y;
+    }
+    out[0] = wave_sum_rows(a0); out[1] = wave_sum_rows(a1); out[2] = wave_sum_rows(a2); out[3] = wave_sum_rows(a3);
+}
+
+// FIND_SFD (:385-390, :283-298, :801-803): Pearson correlation of the window's ifreq with the ideal
+// downchirp ifreq, and -- for an upchirp (c < -0.97) -- fine_sync(-1, 4*D) over the 63 lags.
+template <int SF>
+__device__ __forceinline__ void w2_sfd_window(const DevParams &P, const W2Tabs &T, const float2 *__restrict__ p, float &c_out, int32_t &fine_out)
+{
+    constexpr int SPS = 8 << SF, J = SPS / 64;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // see fast_demod_symbol
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    float f[J];
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const int n = j * 64 + lane;
+        f[j] = (n >= 1) ? ifreq_prod(p[n - 1], p[n]) : 0.0f; // ifreq[n-1]; the n-1 loads hit the lines just fetched
+    }
+    // one-pass Pearson over the n = sps-1 points k = 0 .. sps-2
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const int k = j * 64 + lane - 1;
+        const float fk = f[j];
+        const float d = T.dd[k < 0 ? 0 : k];
+        a0 += fk; a1 += fk * fk; a2 += fk * d; // f[j] is 0 for the non-existent k = -1
+    }
+    a0 = wave_sum_rows(a0); a1 = wave_sum_rows(a1); a2 = wave_sum_rows(a2);
+    const float n = (float)(SPS - 1);
+    const float average = a0 / n;
+    const float var = fmaxf(a1 / n - average * average, 0.0f);
+    const float sd = sqrtf(var) * P.down_ifreq_sd;
+    const float c = (a2 - average * P.down_ifreq_dsum) / sd / n;
+    c_out = c;
+    fine_out = 0;
+    if (!(c < -0.97f) || c > 0.96f) return;
+    // fine_sync(-1, 32): c_i = sum_k f[k] * v[sps + i + k], i = -31 .. 31, f[sps-1] = f[sps-2]
+    float mx = 0.0f;
+    int32_t lag = 0;
+    const float *__restrict__ vb = T.v + SPS + lane - 1;
+    const float f_dup = (lane == 63) ? f[J - 1] : 0.0f;
+    for (int i0 = -31; i0 <= 31; i0 += 4) { // 4 lags per pass: independent chains hide the LDS / DPP latency
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const float fj = f[j]; // lane 0, j = 0 has f = 0 (its index sps+i-1 is in range)
+#pragma unroll
+            for (int g = 0; g < 4; g++) acc[g] += fj * vb[i0 + g + j * 64];
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            acc[g] += f_dup * vb[i0 + g + (J - 1) * 64 + 1];
+            acc[g] = wave_sum_rows(acc[g]);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            if (i0 + g <= 31 && acc[g] > mx) { mx = acc[g]; lag = i0 + g; } // strict '>' in increasing lag order (:311)
+        }
+    }
+    fine_out = -lag;
+}
+
+// ---- the kernel -----------------------------------------------------------------------------------------
+template <int SF>
+__device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg &C)
+{
+    constexpr int N = 1 << SF, SPS = 8 * N;
+    constexpr uint32_t sps = SPS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    W2Shared &W = *reinterpret_cast<W2Shared *>(smem);
+    W2State &S = W.st;
+    Shared &sh = W.sh;
+    // LDS carve-up after W2Shared: f2[2 sps] | v[3 sps + 40 (padded to 4)] | dd[sps] | down[sps] | tws[sps] | twN[N/2]
+    float *f2 = reinterpret_cast<float *>(smem + ((sizeof(W2Shared) + 15) & ~(size_t)15));
+    float *vl = f2 + 2 * SPS;
+    constexpr uint32_t NV = (3u * SPS + 40u + 3u) & ~3u;
+    float *ddl = vl + NV;
+    float2 *downl = reinterpret_cast<float2 *>(ddl + SPS);
+    float2 *twsl = downl + SPS;
+    float2 *twnl = twsl + SPS;
+
+    const uint32_t jid = blockIdx.x;
+    if (jid >= C.n_jobs) return;
+    const Job job = C.jobs[jid];
+    const float2 *__restrict__ X = C.iq + job.stream_off;
+    const int64_t n_items = (int64_t)job.stream_len;
+    AttemptRec *recs = C.recs + (size_t)jid * C.recs_per_job;
+    StepRec *trace = C.trace ? C.trace + (size_t)jid * C.trace_cap : nullptr;
+    const bool t0 = threadIdx.x == 0;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+    for (uint32_t i = threadIdx.x; i < 3u * SPS + 40u; i += kW2) vl[i] = P.up_ifreq_v[i];
+    for (uint32_t i = threadIdx.x; i < sps; i += kW2) {
+        ddl[i] = P.down_ifreq[i] - P.down_ifreq_avg;
+        downl[i] = P.down[i];
+        twsl[i] = P.tws[i];
+    }
+    for (uint32_t i = threadIdx.x; i < (uint32_t)N / 2u; i += kW2) twnl[i] = P.twN[i];
+    if (t0) {
+        S = W2State{};
+        S.state = kDetect; S.pos = job.start; S.cr = job.cr_prev; S.has_crc = P.ctor_crc;
+        S.phdr[1] = (uint8_t)((P.ctor_cr << 5) | (P.ctor_crc << 4));
+        S.att_start = job.start; S.att_trig = -1; S.att_hdr = -1; S.att_cr_prev = job.cr_prev;
+    }
+    __syncthreads();
+    W2Tabs T{vl, downl, ddl, twsl, twnl};
+    FastTabs FT{vl, twsl, twnl, downl};
+
+    while (true) {
+        // ---- round head: thread 0 checks the reference's per-call preconditions
+        if (t0 && !S.done) (void)w2_pre_step(S, job, C, sps);
+        __syncthreads();
+        if (S.done) break;
+        const int32_t state = S.state;
+        const int64_t pos = S.pos;
+        const long long t_start = trace ? clock64() : 0;
+        const int64_t wpos = pos + (int64_t)wave * sps;
+        const bool wvalid = wpos + 2 * (int64_t)sps <= n_items;
+
+        if (state == kDetect) {
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+            if (wvalid) w2_detect_window<SF>(X + wpos, a);
+            if (lane == 0) { W.specf[wave][0] = a[0]; W.specf[wave][1] = a[1]; W.specf[wave][2] = a[2]; W.specf[wave][3] = a[3]; W.speci[wave][0] = wvalid ? 1 : 0; }
+            __syncthreads();
+            if (t0) {
+                for (int w = 0; w < kW2Waves; w++) {
+                    if (w > 0 && !w2_pre_step(S, job, C, sps)) break;
+                    if (!W.speci[w][0]) break;
+                    const float d0 = W.specf[w][0], d1 = W.specf[w][1], e1 = W.specf[w][2], e2 = W.specf[w][3];
+                    S.energy_threshold = e2 / 2.0f; // :357
+                    const float pushed = e1 / (float)sps; // :360
+                    if (S.npush >= 4u) { S.push_tail[0] = S.push_tail[1]; S.push_tail[1] = S.push_tail[2]; S.push_tail[2] = S.push_tail[3]; S.push_tail[3] = pushed; }
+                    else S.push_tail[S.npush] = pushed;
+                    S.npush++;
+                    const float sq = sqrtf(e1 * e2);
+                    const float autocorr = hypotf(d0 / sq, d1 / sq); // :363
+                    int32_t consumed = 0;
+                    if (autocorr >= 0.90f) { // :755
+                        S.corr_fails = 0u;
+                        S.state = kSync;
+                        S.in_attempt = 1;
+                        S.att_trig = S.pos; S.att_hdr = -1; S.att_cr_prev = S.cr; S.att_ambig = 0; S.n_sym = 0;
+                    } else {
+                        consumed = (int32_t)sps;
+                    }
+                    w2_end_step(S, job, C, recs, trace, kDetect, consumed, -1, 0, autocorr, t_start);
+                    if (S.state != kDetect || S.done) break;
+                }
+            }
+            __syncthreads();
+            continue;
+        }
+
+        if (state == kSync) { // :770-783, detect_upchirp :392-413 -- all wavefronts together
+            const float2 *__restrict__ x = X + pos;
+            for (uint32_t i = 1u + threadIdx.x; i < 2u * sps; i += kW2) f2[i - 1] = ifreq_prod(x[i - 1], x[i]);
+            __syncthreads();
+            if (t0) f2[2u * sps - 1u] = f2[2u * sps - 2u]; // :243
+            __syncthreads();
+            // C[i] = sum_{k < sps-1} f[i+k] u[k]; a thread owns 4 consecutive shifts and a slice of k
+            constexpr uint32_t tiles = sps / 4u, groups = kW2 / tiles; // SF7: 256 tiles x 2 slices, SF8: 512 x 1
+            const uint32_t tile = threadIdx.x % tiles, grp = threadIdx.x / tiles;
+            constexpr uint32_t kq = sps - 4u;                // taps handled 4 at a time
+            constexpr uint32_t slice = ((kq / groups) + 3u) & ~3u;
+            const uint32_t k_lo = grp * slice, k_hi = (grp + 1u == groups) ? kq : (grp + 1u) * slice;
+            const float *u = vl + sps; // d_upchirp_ifreq == d_upchirp_ifreq_v[sps ..] for k < sps-1
+            const float *fp = f2 + 4u * tile;
+            float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+            {
+                // software-pipelined: the loads of step k+4 are issued before the 16 FMAs of step k
+                float4 lo = *reinterpret_cast<const float4 *>(fp + k_lo);
+                float4 hi = *reinterpret_cast<const float4 *>(fp + k_lo + 4u);
+                float4 uk = *reinterpret_cast<const float4 *>(u + k_lo);
+                for (uint32_t k = k_lo; k < k_hi; k += 4u) {
+                    const uint32_t kn = (k + 4u < k_hi) ? k + 4u : k; // last step re-reads its own (in-range) data
+                    const float4 hi2 = *reinterpret_cast<const float4 *>(fp + kn + 4u);
+                    const float4 uk2 = *reinterpret_cast<const float4 *>(u + kn);
+                    c0 += lo.x * uk.x; c1 += lo.y * uk.x; c2 += lo.z * uk.x; c3 += lo.w * uk.x;
+                    c0 += lo.y * uk.y; c1 += lo.z * uk.y; c2 += lo.w * uk.y; c3 += hi.x * uk.y;
+                    c0 += lo.z * uk.z; c1 += lo.w * uk.z; c2 += hi.x * uk.z; c3 += hi.y * uk.z;
+                    c0 += lo.w * uk.w; c1 += hi.x * uk.w; c2 += hi.y * uk.w; c3 += hi.z * uk.w;
+                    lo = hi; hi = hi2; uk = uk2;
+                }
+                if (grp + 1u == groups) {
+                    for (uint32_t k = kq; k < sps - 1u; k++) { // 3 leftover taps
+                        const float uk = u[k];
+                        c0 += fp[k] * uk; c1 += fp[k + 1u] * uk; c2 += fp[k + 2u] * uk; c3 += fp[k + 3u] * uk;
+                    }
+                }
+            }
+            float bv = 0.0f; // max_correlation = 0 (:400)
+            int bi = 0x7fffffff;
+            if constexpr (groups > 1) { // slices > 0 hand their partial sums to slice 0 (the f2 window is dead by then)
+                __syncthreads();
+                float4 *part = reinterpret_cast<float4 *>(f2);
+                if (grp > 0) part[(grp - 1u) * tiles + tile] = make_float4(c0, c1, c2, c3);
+                __syncthreads();
+                if (grp == 0) {
+                    for (uint32_t g = 1; g < groups; g++) { const float4 o = part[(g - 1u) * tiles + tile]; c0 += o.x; c1 += o.y; c2 += o.z; c3 += o.w; }
+                }
+            }
+            if (grp == 0) {
+                const int i0 = (int)(4u * tile);
+                if (c0 > bv) { bv = c0; bi = i0; }
+                if (c1 > bv) { bv = c1; bi = i0 + 1; }
+                if (c2 > bv) { bv = c2; bi = i0 + 2; }
+                if (c3 > bv) { bv = c3; bi = i0 + 3; }
+            }
+            w2_block_argmax_first(bv, bi, W.red);
+            if (t0) {
+                const int32_t consumed = (bi == 0x7fffffff) ? 0 : bi; // :771
+                S.state = kFindSfd;
+                w2_end_step(S, job, C, recs, trace, kSync, consumed, -1, 0, bv, t_start);
+            }
+            __syncthreads();
+            continue;
+        }
+
+        if (state == kFindSfd) {
+            float c = 0.0f;
+            int32_t fine = 0;
+            if (wvalid) w2_sfd_window<SF>(P, T, X + wpos, c, fine);
+            if (lane == 0) { W.specf[wave][0] = c; W.speci[wave][0] = wvalid ? 1 : 0; W.speci[wave][1] = fine; }
+            __syncthreads();
+            if (t0) {
+                for (int w = 0; w < kW2Waves; w++) {
+                    if (w > 0 && !w2_pre_step(S, job, C, sps)) break;
+                    if (!W.speci[w][0]) break;
+                    const float cw = W.specf[w][0];
+                    int32_t fw = 0;
+                    if (cw > 0.96f) { // :792
+                        S.state = kPause;
+                    } else {
+                        if (cw < -0.97f) fw = W.speci[w][1]; // :801-803
+                        else S.corr_fails++;
+                        if (S.corr_fails > 4u) S.state = kDetect; // :808-809
+                    }
+                    w2_end_step(S, job, C, recs, trace, kFindSfd, (int32_t)sps + fw, -1, fw, cw, t_start);
+                    if (S.state != kFindSfd || S.done || fw != 0) break;
+                }
+            }
+            __syncthreads();
+            continue;
+        }
+
+        if (state == kPause) { // :820-824
+            if (t0) {
+                S.state = kDecodeHeader;
+                const int32_t consumed = (int32_t)(sps + sps / 4u);
+                S.att_hdr = S.pos + consumed;
+                w2_end_step(S, job, C, recs, trace, kPause, consumed, -1, 0, 0.0f, t_start);
+            }
+            __syncthreads();
+            continue;
+        }
+
+        // ---- DECODE_HEADER / DECODE_PAYLOAD round (:826-886)
+        {
+            uint32_t ws = 0;
+            int32_t wfine = 0;
+            if (wvalid) fast_demod_symbol<SF>(P, FT, X + wpos, ws, wfine);
+            if (lane == 0) { W.speci[wave][0] = wvalid ? (int32_t)ws : -1; W.speci[wave][1] = wfine; }
+            __syncthreads();
+            if (t0) {
+                S.fin_pending = 0;
+                for (int w = 0; w < kW2Waves; w++) {
+                    if (w > 0 && !w2_pre_step(S, job, C, sps)) break;
+                    if (!(S.state == kDecodeHeader || S.state == kDecodePayload) || W.speci[w][0] < 0) break;
+                    const bool is_first = S.state == kDecodeHeader;
+                    const int32_t st_w = S.state;
+                    const uint32_t s = (uint32_t)W.speci[w][0];
+                    const int32_t fw = W.speci[w][1];
+                    const uint32_t bin_idx = (s == 0u && P.demod_mode == 2u) ? 0u : (s + (uint32_t)N - 1u) % (uint32_t)N;
+                    if (w2_post_symbol(P, S, sh, bin_idx, is_first)) { // payload complete: finalise with all threads
+                        S.fin_pending = 1; S.fin_st = st_w; S.fin_consumed = (int32_t)sps + fw; S.fin_bin = (int32_t)bin_idx; S.fin_fine = fw;
+                        break;
+                    }
+                    w2_end_step(S, job, C, recs, trace, st_w, (int32_t)sps + fw, (int32_t)bin_idx, fw, 0.0f, t_start);
+                    if (S.done || fw != 0) break; // later windows started at the wrong sample
+                }
+            }
+            __syncthreads();
+            if (S.fin_pending) { // decode(false) + frame bytes (:870-881)
+                const uint32_t n_cw = S.n_cw, cr = S.cr, n_bytes = S.fin_n_bytes, plen = S.fin_plen;
+                decode_payload_bytes(sh, n_cw, cr, n_bytes);
+                AttemptRec &r = recs[S.n_att];
+                for (uint32_t i = threadIdx.x; i < plen; i += kW2) r.frame[3u + i] = (i < n_bytes) ? sh.dec[i] : 0;
+                __syncthreads();
+                if (t0) {
+                    r.frame[0] = S.phdr[0]; r.frame[1] = S.phdr[1]; r.frame[2] = S.phdr[2]; // d_phdr (:600)
+                    r.frame_len = 3u + plen;
+                    S.frame_ok = 1;
+                    S.state = kDetect;
+                    S.n_words = 0; S.n_cw = 0;
+                    S.fin_pending = 0;
+                    w2_end_step(S, job, C, recs, trace, S.fin_st, S.fin_consumed, S.fin_bin, S.fin_fine, 0.0f, t_start);
+                }
+                __syncthreads();
+            }
+        }
+    }
+
+    // an attempt cut short (out of data, or probe stop) is reported but not counted as complete
+    if (t0) {
+        const bool in_attempt = S.in_attempt != 0;
+        if (in_attempt && S.n_att < C.recs_per_job) {
+            AttemptRec &r = recs[S.n_att];
+            r.status = (S.stop_reason == 3) ? kAttemptAtHeader : kAttemptOutOfData;
+            r.start_pos = S.att_start; r.trig_pos = S.att_trig; r.hdr_pos = S.att_hdr; r.end_pos = S.pos;
+            r.npush = S.npush;
+            for (int i = 0; i < 4; i++) r.push_tail[i] = S.push_tail[i];
+            r.cr_prev = S.att_cr_prev; r.hdr_ambig = S.att_ambig; r.n_symbols = S.n_sym; r.frame_len = 0;
+        }
+        JobResult &jr = C.results[jid];
+        jr.final_pos = in_attempt ? S.att_start : S.pos;
+        jr.n_attempts = S.n_att + (in_attempt ? 1u : 0u);
+        jr.final_cr = S.cr;
+        jr.npush = in_attempt ? 0u : S.npush;
+        for (int i = 0; i < 4; i++) jr.push_tail[i] = S.push_tail[i];
+        jr.stop_reason = (uint32_t)S.stop_reason;
+        jr.n_steps = S.n_steps < C.trace_cap ? S.n_steps : C.trace_cap;
+        jr.pad = in_attempt ? 1u : 0u;
+    }
+}
+
+__global__ __launch_bounds__(kW2, 4) void walker2_kernel_sf7(DevParams P, LaunchCfg C) { walker2_body<7>(P, C); }
+__global__ __launch_bounds__(kW2, 2) void walker2_kernel_sf8(DevParams P, LaunchCfg C) { walker2_body<8>(P, C); }
+
+static uint32_t walker2_lds_bytes(uint32_t sf)
+{
+    const uint32_t sps = 8u << sf, n = 1u << sf;
+    const uint32_t nv = (3u * sps + 40u + 3u) & ~3u;
+    return (uint32_t)((sizeof(W2Shared) + 15) & ~(size_t)15) + (2u * sps + nv + sps) * (uint32_t)sizeof(float) +
+           (2u * sps + n / 2u) * (uint32_t)sizeof(float2);
+}

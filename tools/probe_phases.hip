@@ -14,11 +14,13 @@ __global__ __launch_bounds__(256) void probe(DevParams P, const float2 *iq, uint
     const uint32_t nv = (3u * SPS + 4u * 8u + 8u + 3u) & ~3u;
     float2 *tw_s = reinterpret_cast<float2 *>(vl + nv);
     float2 *tw_n = tw_s + SPS;
+    float2 *dn = tw_n + (1 << SF) / 2;
+    for (uint32_t i = threadIdx.x; i < SPS; i += 256) dn[i] = P.down[i];
     for (uint32_t i = threadIdx.x; i < 3u * SPS + 40u; i += 256) vl[i] = P.up_ifreq_v[i];
     for (uint32_t i = threadIdx.x; i < SPS; i += 256) tw_s[i] = P.tws[i];
     for (uint32_t i = threadIdx.x; i < P.nbins / 2u; i += 256) tw_n[i] = P.twN[i];
     __syncthreads();
-    FastTabs T{vl, tw_s, tw_n};
+    FastTabs T{vl, tw_s, tw_n, dn};
     const int wave = threadIdx.x >> 6;
     long long st[9];
     uint32_t s = 0; int32_t f = 0;
@@ -50,7 +52,7 @@ int main(int argc, char **argv)
     for (size_t i = 0; i < iq.size(); i++) { double a = -2 * M_PI * (i % SPS) * (i % SPS) / (16.0 * SPS) + 0.3 * (i % SPS); iq[i] = make_float2(cos(a), sin(a)); }
     hipMemcpy(d_iq, iq.data(), iq.size() * 8, hipMemcpyHostToDevice);
     P.down = d_down; P.tws = d_tws; P.twN = d_twN; P.up_ifreq_v = d_v;
-    const size_t lds = ((3 * SPS + 40 + 3) & ~3) * 4 + (SPS + N / 2) * 8;
+    const size_t lds = ((3 * SPS + 40 + 3) & ~3) * 4 + (2 * SPS + N / 2) * 8;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int it = 0; it < 3; it++) {
         hipEventRecord(e0);

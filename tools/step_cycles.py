@@ -20,5 +20,5 @@ for sf in [int(a) for a in sys.argv[1:]] or [7]:
         for t in tr:
             tot.setdefault(t[0], []).append(t[7])
         print("sf", sf, "demod", demod, "frames", len(h.drain()), "walker_ms %.3f" % h.timing().walker_ms,
-              {names[k]: (len(v), int(np.mean(v)), int(np.sum(v))) for k, v in sorted(tot.items())})
+              {names[k]: (len(v), int(np.min(v)), int(np.mean(v))) for k, v in sorted(tot.items())})
         h.close()
