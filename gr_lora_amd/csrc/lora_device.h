@@ -41,6 +41,9 @@ struct DevParams {
     float    down_ifreq_avg;    // chirp_avg over sps-1 points (decoder_impl.cc:287)
     float    down_ifreq_sd;     // stddev of ideal downchirp ifreq (decoder_impl.cc:289)
     float    down_ifreq_dsum;   // sum over sps-1 points of (down_ifreq - down_ifreq_avg): float residue
+    double   sync_a, sync_b;    // least-squares line a + b*k through d_upchirp_ifreq[0 .. sps-2] (closed-form SYNC)
+    uint32_t sync_closed_form;  // use the O(sps) SYNC (sps >= 4096)
+    uint32_t pad0;
     const float2 *down;         // d_downchirp
     const float  *up_ifreq;     // d_upchirp_ifreq
     const float  *down_ifreq;   // d_downchirp_ifreq

@@ -227,6 +227,12 @@ lora_hip_status build_tables(lora_hip_decoder *h)
         float ds = 0.0f;
         for (uint32_t i = 0; i < n; i++) ds += down_ifreq[i] - avg;
         P.down_ifreq_dsum = ds;
+        // line through the ideal upchirp ifreq (a linear ramp up to float noise) for the closed-form SYNC
+        double sk = 0, su = 0, skk = 0, sku = 0;
+        for (uint32_t k = 0; k < n; k++) { sk += k; su += up_ifreq[k]; skk += (double)k * k; sku += (double)k * up_ifreq[k]; }
+        P.sync_b = (n * sku - sk * su) / (n * skk - sk * sk);
+        P.sync_a = (su - P.sync_b * sk) / n;
+        P.sync_closed_form = (sps >= 4096u && !getenv("LORA_HIP_SYNC_DIRECT")) ? 1u : 0u;
     }
     for (uint32_t t = 0; t < N / 2u; t++) {
         const double a = -2.0 * M_PI * (double)t / (double)N;
