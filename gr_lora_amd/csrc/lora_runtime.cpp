@@ -180,7 +180,8 @@ lora_hip_status build_tables(lora_hip_decoder *h)
     P.enable_fine_sync = c.disable_drift_correction ? 0u : 1u;
     P.demod_mode = (uint32_t)c.demod;
     P.ctor_cr = c.cr & 7u; P.ctor_crc = c.crc ? 1u : 0u;
-    P.use_fast = getenv("LORA_HIP_NO_FAST") ? 0u : 1u;
+    // 0: generic kernels only, 1: walker_body with wave-per-symbol decode rounds, 2 (default): walker2
+    P.use_fast = getenv("LORA_HIP_NO_FAST") ? 0u : (getenv("LORA_HIP_FAST_MODE") ? (uint32_t)atoi(getenv("LORA_HIP_FAST_MODE")) : 2u);
     // get_shift_fft working set: D/G polyphase rows of N points (+1 pad) must fit the LDS budget
     uint32_t G = 1;
     while ((size_t)(D / G) * (N + 1u) * sizeof(float2) > kWorkBudget && G < D) G <<= 1;

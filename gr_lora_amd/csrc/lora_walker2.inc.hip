@@ -178,7 +178,6 @@ template <int SF>
 __device__ __forceinline__ void w2_detect_window(const float2 *__restrict__ p, float (&out)[4])
 {
     constexpr int SPS = 8 << SF, J = SPS / 64;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // see fast_demod_symbol
     const int lane = threadIdx.x & 63;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
@@ -198,7 +197,6 @@ template <int SF>
 __device__ __forceinline__ void w2_sfd_window(const DevParams &P, const W2Tabs &T, const float2 *__restrict__ p, float &c_out, int32_t &fine_out)
 {
     constexpr int SPS = 8 << SF, J = SPS / 64;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // see fast_demod_symbol
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));
     float f[J];
@@ -435,6 +433,11 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         }
 
         if (state == kPause) { // :820-824
+            // every wavefront must have read S.state / S.pos (round head) before thread 0 rewrites them: without
+            // this barrier a slow wavefront could read the new state, take the DECODE branch (another barrier
+            // count) and stay one round out of phase -- seen as rare wrong payload bytes when two workgroups
+            // shared a CU (tests/test_gpu_determinism.py).  The other branches have a barrier at this point.
+            __syncthreads();
             if (t0) {
                 S.state = kDecodeHeader;
                 const int32_t consumed = (int32_t)(sps + sps / 4u);
