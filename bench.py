@@ -156,6 +156,17 @@ def main():
         value = total_items * args.steps / elapsed / 1e6
         kernel_ms = walker_ms / max(1, args.steps)  # walker kernel time per pass (HIP events, launch stream)
         achieved = 8.0 * n_items / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        # HBM bytes per pass from the committed rocprofv3 PMC run of this same workload (separate FETCH_SIZE /
+        # WRITE_SIZE passes, gfx950 FETCH x2 correction as MI355X_MICROARCH.md prescribes); null otherwise
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_b_pmc_traffic.json")))
+            if pmc.get("workload_items") == n_items and args.demod != 0:
+                traffic = int(pmc["hbm_bytes_per_pass_corrected"])
+        except (OSError, ValueError, KeyError):
+            pass
+        fast = args.sf in (7, 8) and args.demod != 0 and not os.environ.get("LORA_HIP_NO_FAST")
+        kname = ("walker2_kernel_sf%d" % args.sf) if fast else "walker_kernel"
         res = {
             "metric": "IQ Msamples/s demodulated", "value": round(value, 3), "unit": "Msamples/s",
             "symbols_per_s": round(value * 1e6 / cfg.sps, 1),
@@ -166,8 +177,9 @@ def main():
                        "items_per_gpu": n_items, "demod": ["grad", "fft", "fft_compat"][args.demod],
                        "bit_exact_vs_expected": verified, "parallelism": "streams sharded, dp%d" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": "walker_kernel", "kernel_ms_per_pass": round(kernel_ms, 4),
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per pass (PMC, profiles/r01_b_pmc_traffic.json)",
+                         "kernel": kname, "kernel_ms_per_pass": round(kernel_ms, 4),
                          "launches_per_pass": launches / max(1, args.steps),
                          "algorithmic_bytes_per_pass": 8 * n_items},
         }
