@@ -42,6 +42,7 @@ struct W2Tabs {
     const float  *dd;    // d_downchirp_ifreq[k] - chirp_avg
     const float2 *tws;   // e^{-2 pi i m / sps}
     const float2 *twN;   // e^{-2 pi i t / N}
+    float        *scratch; // 72 floats per wavefront
 };
 
 __device__ __forceinline__ void w2_block_argmax_first(float &v, int &idx, float *red)
@@ -223,29 +224,57 @@ __device__ __forceinline__ void w2_sfd_window(const DevParams &P, const W2Tabs &
     c_out = c;
     fine_out = 0;
     if (!(c < -0.97f) || c > 0.96f) return;
-    // fine_sync(-1, 32): c_i = sum_k f[k] * v[sps + i + k], i = -31 .. 31, f[sps-1] = f[sps-2]
-    float mx = 0.0f;
-    int32_t lag = 0;
-    const float *__restrict__ vb = T.v + SPS + lane - 1;
-    const float f_dup = (lane == 63) ? f[J - 1] : 0.0f;
-    for (int i0 = -31; i0 <= 31; i0 += 4) { // 4 lags per pass: independent chains hide the LDS / DPP latency
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // fine_sync(-1, 32) (:300-321): c_i = sum_{k<sps} fe[k] * v[sps + i + k], i = -31 .. 31, with fe[sps-1] = fe[sps-2].
+    // v is the ifreq of concatenated upchirps: v[m] = a + b*(m mod sps) except the one wrap sample per period
+    // (m mod sps == sps-1), up to float noise ~1e-5 of the sums.  With t = (i+k) mod sps that gives, exactly in
+    // the line model,
+    //   i >= 0: c_i = a G0 + b (i G0 + G1) - b sps T_i    + Wd fe[sps-1-i],   T_i = sum of the last i samples
+    //   i <  0: c_i = a G0 + b (i G0 + G1) + b sps H_{-i} + Wd fe[-i-1],      H_j = sum of the first j samples
+    // G0 = sum fe[k], G1 = sum k fe[k], Wd = v[2 sps - 1] - (a + b (sps-1)).  O(sps) instead of 63 x sps.
+    double g0 = 0.0, g1 = 0.0;
 #pragma unroll
-        for (int j = 0; j < J; j++) {
-            const float fj = f[j]; // lane 0, j = 0 has f = 0 (its index sps+i-1 is in range)
-#pragma unroll
-            for (int g = 0; g < 4; g++) acc[g] += fj * vb[i0 + g + j * 64];
-        }
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            acc[g] += f_dup * vb[i0 + g + (J - 1) * 64 + 1];
-            acc[g] = wave_sum_rows(acc[g]);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            if (i0 + g <= 31 && acc[g] > mx) { mx = acc[g]; lag = i0 + g; } // strict '>' in increasing lag order (:311)
-        }
+    for (int j = 0; j < J; j++) {
+        const int k = j * 64 + lane - 1; // lane 0, j = 0 holds f = 0 (k = -1)
+        g0 += (double)f[j];
+        g1 += (double)k * (double)f[j];
     }
+    if (lane == 63) { g0 += (double)f[J - 1]; g1 += (double)(SPS - 1) * (double)f[J - 1]; } // duplicated last tap (:243)
+    {
+        // wave-wide sums of the two doubles (as hi/lo float pairs would lose bits; use shuffles on 64-bit values)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { g0 += __shfl_xor(g0, o, 64); g1 += __shfl_xor(g1, o, 64); }
+    }
+    // the first 32 and last 33 samples go to this wavefront's scratch: head[k] = fe[k], tail[q] = fe[sps-1-q]
+    float *scr = T.scratch + (threadIdx.x >> 6) * 72;
+    if (lane >= 1 && lane <= 32) scr[lane - 1] = f[0];                 // fe[0..31]
+    if (lane >= 31) scr[32 + 1 + (63 - lane)] = f[J - 1];              // fe[sps-2-(63-lane)] -> tail[1 + (63-lane)]
+    if (lane == 63) scr[32] = f[J - 1];                                // tail[0] = fe[sps-1] = fe[sps-2]
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int i = lane - 31; // this lane's lag
+    float c_i = -3.0e38f;
+    if (lane <= 62) {
+        const double a = P.sync_a, b = P.sync_b;
+        const double wd = (double)T.v[2 * SPS - 1] - (a + b * (double)(SPS - 1));
+        double edge = 0.0;
+        float wrap_f;
+        if (i >= 0) {
+            for (int q = 0; q < i; q++) edge -= (double)scr[32 + q];   // T_i
+            wrap_f = scr[32 + i];                                       // fe[sps-1-i]
+        } else {
+            for (int q = 0; q < -i; q++) edge += (double)scr[q];       // H_{-i}
+            wrap_f = scr[-i - 1];                                       // fe[-i-1]
+        }
+        c_i = (float)(a * g0 + b * ((double)i * g0 + g1) + b * (double)SPS * edge + wd * (double)wrap_f);
+    }
+    int li = lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { // first maximum in lag order (strict '>' scan from 0, :311)
+        const float ov = __shfl_xor(c_i, o, 64);
+        const int oi = __shfl_xor(li, o, 64);
+        if (ov > c_i || (ov == c_i && oi < li)) { c_i = ov; li = oi; }
+    }
+    const int32_t lag = (c_i > 0.0f) ? li - 31 : 0;
     fine_out = -lag;
 }
 
@@ -292,7 +321,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         S.att_start = job.start; S.att_trig = -1; S.att_hdr = -1; S.att_cr_prev = job.cr_prev;
     }
     __syncthreads();
-    W2Tabs T{vl, downl, ddl, twsl, twnl};
+    W2Tabs T{vl, downl, ddl, twsl, twnl, W.red};
     FastTabs FT{vl, twsl, twnl, downl};
 
     while (true) {
