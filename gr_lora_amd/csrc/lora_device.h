@@ -87,6 +87,8 @@ struct JobResult {
     uint32_t stop_reason;  // 0 scan_limit reached, 1 out of data, 2 attempt capacity, 3 max_attempts / probe stop
     uint32_t n_steps;      // trace entries written
     uint32_t pad;
+    uint32_t cyc[6];       // shader clocks / 64 spent per state (DETECT, SYNC, FIND_SFD, PAUSE, HEADER, PAYLOAD); walker2 only
+    uint32_t rounds[6];    // rounds per state
 };
 
 struct StepRec {           // mirrors lora_hip_step_t

@@ -320,6 +320,12 @@ lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vec
     HIP_TRY(h, hipEventRecord(h->ev1, st));
     HIP_TRY(h, hipMemcpyAsync(out.res.data(), h->d_results.p, nj * sizeof(JobResult), hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipStreamSynchronize(st));
+    if (getenv("LORA_HIP_DEBUG") && h->P.use_fast >= 2u) {
+        double cyc[6] = {0}, rnd[6] = {0};
+        for (uint32_t j = 0; j < nj; j++) for (int i = 0; i < 6; i++) { cyc[i] += 64.0 * out.res[j].cyc[i]; rnd[i] += out.res[j].rounds[i]; }
+        fprintf(stderr, "[lora_hip] per-job avg kcycles (rounds): DETECT %.0f (%.1f) SYNC %.0f (%.1f) SFD %.0f (%.1f) PAUSE %.0f (%.1f) HDR %.0f (%.1f) PAYLOAD %.0f (%.1f)\n",
+                cyc[0] / nj / 1e3, rnd[0] / nj, cyc[1] / nj / 1e3, rnd[1] / nj, cyc[2] / nj / 1e3, rnd[2] / nj, cyc[3] / nj / 1e3, rnd[3] / nj, cyc[4] / nj / 1e3, rnd[4] / nj, cyc[5] / nj / 1e3, rnd[5] / nj);
+    }
     // copy back only the attempt records that were written
     uint32_t max_att = 0;
     for (uint32_t j = 0; j < nj; j++) max_att = std::max(max_att, out.res[j].n_attempts);

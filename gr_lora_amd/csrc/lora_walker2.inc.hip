@@ -28,12 +28,19 @@ struct alignas(16) W2State {
     int32_t  fin_st, fin_consumed, fin_bin, fin_fine;
 };
 
+struct alignas(16) W2Stats { // per-state time accounting (reported under LORA_HIP_DEBUG), kept out of the hot state
+    long long prev_t;
+    int32_t   prev_state;
+    uint32_t  cyc[6], rounds[6];
+};
+
 struct alignas(16) W2Shared {
     float    red[kW2Waves * 64 + 64];
     float    specf[kW2Waves][4];
     int32_t  speci[kW2Waves][4];
     Shared   sh;      // words / codewords / decoded bytes (shared with the integer-chain helpers)
     W2State  st;
+    W2Stats  stats;
 };
 
 struct W2Tabs {
@@ -319,6 +326,8 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         S.state = kDetect; S.pos = job.start; S.cr = job.cr_prev; S.has_crc = P.ctor_crc;
         S.phdr[1] = (uint8_t)((P.ctor_cr << 5) | (P.ctor_crc << 4));
         S.att_start = job.start; S.att_trig = -1; S.att_hdr = -1; S.att_cr_prev = job.cr_prev;
+        W.stats = W2Stats{};
+        W.stats.prev_state = -1;
     }
     __syncthreads();
     W2Tabs T{vl, downl, ddl, twsl, twnl, W.red};
@@ -331,7 +340,12 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         if (S.done) break;
         const int32_t state = S.state;
         const int64_t pos = S.pos;
-        const long long t_start = trace ? clock64() : 0;
+        const long long t_start = clock64();
+        if (t0) {
+            W2Stats &Q = W.stats;
+            if (Q.prev_state >= 0) { Q.cyc[Q.prev_state] += (uint32_t)((t_start - Q.prev_t) >> 6); Q.rounds[Q.prev_state]++; }
+            Q.prev_state = state < 6 ? state : 5; Q.prev_t = t_start;
+        }
         const int64_t wpos = pos + (int64_t)wave * sps;
         const bool wvalid = wpos + 2 * (int64_t)sps <= n_items;
 
@@ -543,6 +557,9 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         jr.stop_reason = (uint32_t)S.stop_reason;
         jr.n_steps = S.n_steps < C.trace_cap ? S.n_steps : C.trace_cap;
         jr.pad = in_attempt ? 1u : 0u;
+        W2Stats &Q = W.stats;
+        if (Q.prev_state >= 0) { Q.cyc[Q.prev_state] += (uint32_t)((clock64() - Q.prev_t) >> 6); Q.rounds[Q.prev_state]++; }
+        for (int i = 0; i < 6; i++) { jr.cyc[i] = Q.cyc[i]; jr.rounds[i] = Q.rounds[i]; }
     }
 }
 
