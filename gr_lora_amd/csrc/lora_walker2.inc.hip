@@ -2,15 +2,30 @@
 // Included by lora_kernels.hip.
 //
 // Same state machine as walker_body (decoder_impl::work, lib/decoder_impl.cc:740-903), organised in
-// ROUNDS of 8 wavefronts (512 threads): in DETECT, FIND_SFD and DECODE_* every wavefront evaluates one
-// upcoming symbol window at pos + w*sps (zero drift assumed), then thread 0 replays the reference's
-// per-call logic over the 8 results in order and stops at the first one whose outcome invalidates the
-// later windows (a trigger, a state change, d_fine_sync != 0, end of data).  The accepted sequence is
-// therefore exactly the serial one.  SYNC (one O(sps^2) correlation per packet) is computed by all 8
-// wavefronts together.  The decoder state lives in LDS; per-lane registers only hold symbol data.
+// ROUNDS: 512 threads = 7 worker wavefronts + 1 control wavefront.  In DETECT, FIND_SFD and DECODE_*
+// every worker evaluates one upcoming symbol window at pos + w*sps (zero drift assumed); the control
+// thread then replays the reference's per-call logic over the 7 results in order and stops at the first
+// one whose outcome invalidates the later windows (a trigger, a state change, d_fine_sync != 0, end of
+// data).  The accepted sequence is therefore exactly the serial one.  DECODE rounds are PIPELINED: while
+// the control thread resolves round r, the workers already demodulate round r+1 at the predicted position
+// (same state, 7 symbols further); a misprediction only discards that round.  SYNC (one correlation per
+// packet) is computed by all 8 wavefronts together.  The decoder state lives in LDS and is touched by the
+// control thread only; the per-round PLAN is double-buffered so that no wavefront can read a plan that is
+// being rewritten.
 
 constexpr int kW2 = 512;
-constexpr int kW2Waves = kW2 / 64;
+constexpr int kW2Waves = kW2 / 64;   // wavefronts per workgroup
+constexpr int kW2Workers = kW2Waves - 1; // the last wavefront is the control wavefront
+
+enum W2Mode : int32_t { kPlanExit = 0, kPlanDetect, kPlanSync, kPlanSfd, kPlanPause, kPlanDecode, kPlanFinalize };
+
+struct alignas(16) W2Plan {
+    int64_t pos;          // where the workers evaluate their windows
+    int32_t mode;         // W2Mode
+    int32_t buf;          // spec buffer the workers fill (kPlanDecode)
+    int32_t resolve_prev; // kPlanDecode: spec[buf ^ 1] holds the previous round, to be resolved now
+    int32_t pad;
+};
 
 struct alignas(16) W2State {
     int64_t  pos, att_start, att_trig, att_hdr;
@@ -37,7 +52,8 @@ struct alignas(16) W2Stats { // per-state time accounting (reported under LORA_H
 struct alignas(16) W2Shared {
     float    red[kW2Waves * 64 + 64];
     float    specf[kW2Waves][4];
-    int32_t  speci[kW2Waves][4];
+    int32_t  speci[2][kW2Waves][4];   // [buffer][worker]: decode rounds are double-buffered
+    W2Plan   plan[2];
     Shared   sh;      // words / codewords / decoded bytes (shared with the integer-chain helpers)
     W2State  st;
     W2Stats  stats;
@@ -311,8 +327,9 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     const int64_t n_items = (int64_t)job.stream_len;
     AttemptRec *recs = C.recs + (size_t)jid * C.recs_per_job;
     StepRec *trace = C.trace ? C.trace + (size_t)jid * C.trace_cap : nullptr;
-    const bool t0 = threadIdx.x == 0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool is_ctl = wave == kW2Workers;                 // control wavefront
+    const bool t0 = threadIdx.x == kW2Workers * 64;         // the control thread: sole owner of the decoder state S
 
     for (uint32_t i = threadIdx.x; i < 3u * SPS + 40u; i += kW2) vl[i] = P.up_ifreq_v[i];
     for (uint32_t i = threadIdx.x; i < sps; i += kW2) {
@@ -321,6 +338,22 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         twsl[i] = P.tws[i];
     }
     for (uint32_t i = threadIdx.x; i < (uint32_t)N / 2u; i += kW2) twnl[i] = P.twN[i];
+
+    // plan for the next round from the TRUE state (control thread only)
+    auto plan_from_state = [&](W2Plan &pl) {
+        pl.buf = 0; pl.resolve_prev = 0; pl.pad = 0; pl.pos = S.pos;
+        if (!S.done) (void)w2_pre_step(S, job, C, sps);
+        if (S.done) { pl.mode = kPlanExit; return; }
+        if (S.fin_pending) { pl.mode = kPlanFinalize; return; }
+        switch (S.state) {
+        case kDetect: pl.mode = kPlanDetect; break;
+        case kSync: pl.mode = kPlanSync; break;
+        case kFindSfd: pl.mode = kPlanSfd; break;
+        case kPause: pl.mode = kPlanPause; break;
+        default: pl.mode = kPlanDecode; break;
+        }
+    };
+
     if (t0) {
         S = W2State{};
         S.state = kDetect; S.pos = job.start; S.cr = job.cr_prev; S.has_crc = P.ctor_crc;
@@ -328,36 +361,36 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         S.att_start = job.start; S.att_trig = -1; S.att_hdr = -1; S.att_cr_prev = job.cr_prev;
         W.stats = W2Stats{};
         W.stats.prev_state = -1;
+        plan_from_state(W.plan[0]);
     }
-    __syncthreads();
     W2Tabs T{vl, downl, ddl, twsl, twnl, W.red};
     FastTabs FT{vl, twsl, twnl, downl};
 
-    while (true) {
-        // ---- round head: thread 0 checks the reference's per-call preconditions
-        if (t0 && !S.done) (void)w2_pre_step(S, job, C, sps);
-        __syncthreads();
-        if (S.done) break;
-        const int32_t state = S.state;
-        const int64_t pos = S.pos;
+    for (uint32_t it = 0;; it++) {
+        __syncthreads(); // plan[it & 1] and everything the control thread wrote are visible; plan[(it+1) & 1] is free
+        const W2Plan plan = W.plan[it & 1u];
+        W2Plan &next = W.plan[(it + 1u) & 1u];
+        if (plan.mode == kPlanExit) break;
+        const int64_t pos = plan.pos;
         const long long t_start = clock64();
         if (t0) {
             W2Stats &Q = W.stats;
+            const int sidx = plan.mode == kPlanDetect ? 0 : plan.mode == kPlanSync ? 1 : plan.mode == kPlanSfd ? 2 : plan.mode == kPlanPause ? 3 : 5;
             if (Q.prev_state >= 0) { Q.cyc[Q.prev_state] += (uint32_t)((t_start - Q.prev_t) >> 6); Q.rounds[Q.prev_state]++; }
-            Q.prev_state = state < 6 ? state : 5; Q.prev_t = t_start;
+            Q.prev_state = sidx; Q.prev_t = t_start;
         }
         const int64_t wpos = pos + (int64_t)wave * sps;
-        const bool wvalid = wpos + 2 * (int64_t)sps <= n_items;
+        const bool wvalid = !is_ctl && wpos + 2 * (int64_t)sps <= n_items;
 
-        if (state == kDetect) {
+        if (plan.mode == kPlanDetect) {
             float a[4] = {0.f, 0.f, 0.f, 0.f};
             if (wvalid) w2_detect_window<SF>(X + wpos, a);
-            if (lane == 0) { W.specf[wave][0] = a[0]; W.specf[wave][1] = a[1]; W.specf[wave][2] = a[2]; W.specf[wave][3] = a[3]; W.speci[wave][0] = wvalid ? 1 : 0; }
+            if (lane == 0 && !is_ctl) { W.specf[wave][0] = a[0]; W.specf[wave][1] = a[1]; W.specf[wave][2] = a[2]; W.specf[wave][3] = a[3]; W.speci[0][wave][0] = wvalid ? 1 : 0; }
             __syncthreads();
             if (t0) {
-                for (int w = 0; w < kW2Waves; w++) {
+                for (int w = 0; w < kW2Workers; w++) {
                     if (w > 0 && !w2_pre_step(S, job, C, sps)) break;
-                    if (!W.speci[w][0]) break;
+                    if (!W.speci[0][w][0]) break;
                     const float d0 = W.specf[w][0], d1 = W.specf[w][1], e1 = W.specf[w][2], e2 = W.specf[w][3];
                     S.energy_threshold = e2 / 2.0f; // :357
                     const float pushed = e1 / (float)sps; // :360
@@ -378,12 +411,12 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                     w2_end_step(S, job, C, recs, trace, kDetect, consumed, -1, 0, autocorr, t_start);
                     if (S.state != kDetect || S.done) break;
                 }
+                plan_from_state(next);
             }
-            __syncthreads();
             continue;
         }
 
-        if (state == kSync) { // :770-783, detect_upchirp :392-413 -- all wavefronts together
+        if (plan.mode == kPlanSync) { // :770-783, detect_upchirp :392-413 -- all wavefronts together
             const float2 *__restrict__ x = X + pos;
             for (uint32_t i = 1u + threadIdx.x; i < 2u * sps; i += kW2) f2[i - 1] = ifreq_prod(x[i - 1], x[i]);
             __syncthreads();
@@ -415,8 +448,8 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 }
                 if (grp + 1u == groups) {
                     for (uint32_t k = kq; k < sps - 1u; k++) { // 3 leftover taps
-                        const float uk = u[k];
-                        c0 += fp[k] * uk; c1 += fp[k + 1u] * uk; c2 += fp[k + 2u] * uk; c3 += fp[k + 3u] * uk;
+                        const float uk1 = u[k];
+                        c0 += fp[k] * uk1; c1 += fp[k + 1u] * uk1; c2 += fp[k + 2u] * uk1; c3 += fp[k + 3u] * uk1;
                     }
                 }
             }
@@ -443,71 +476,88 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 const int32_t consumed = (bi == 0x7fffffff) ? 0 : bi; // :771
                 S.state = kFindSfd;
                 w2_end_step(S, job, C, recs, trace, kSync, consumed, -1, 0, bv, t_start);
+                plan_from_state(next);
             }
-            __syncthreads();
             continue;
         }
 
-        if (state == kFindSfd) {
+        if (plan.mode == kPlanSfd) {
             float c = 0.0f;
             int32_t fine = 0;
             if (wvalid) w2_sfd_window<SF>(P, T, X + wpos, c, fine);
-            if (lane == 0) { W.specf[wave][0] = c; W.speci[wave][0] = wvalid ? 1 : 0; W.speci[wave][1] = fine; }
+            if (lane == 0 && !is_ctl) { W.specf[wave][0] = c; W.speci[0][wave][0] = wvalid ? 1 : 0; W.speci[0][wave][1] = fine; }
             __syncthreads();
             if (t0) {
-                for (int w = 0; w < kW2Waves; w++) {
+                for (int w = 0; w < kW2Workers; w++) {
                     if (w > 0 && !w2_pre_step(S, job, C, sps)) break;
-                    if (!W.speci[w][0]) break;
+                    if (!W.speci[0][w][0]) break;
                     const float cw = W.specf[w][0];
                     int32_t fw = 0;
                     if (cw > 0.96f) { // :792
                         S.state = kPause;
                     } else {
-                        if (cw < -0.97f) fw = W.speci[w][1]; // :801-803
+                        if (cw < -0.97f) fw = W.speci[0][w][1]; // :801-803
                         else S.corr_fails++;
                         if (S.corr_fails > 4u) S.state = kDetect; // :808-809
                     }
                     w2_end_step(S, job, C, recs, trace, kFindSfd, (int32_t)sps + fw, -1, fw, cw, t_start);
                     if (S.state != kFindSfd || S.done || fw != 0) break;
                 }
+                plan_from_state(next);
             }
-            __syncthreads();
             continue;
         }
 
-        if (state == kPause) { // :820-824
-            // every wavefront must have read S.state / S.pos (round head) before thread 0 rewrites them: without
-            // this barrier a slow wavefront could read the new state, take the DECODE branch (another barrier
-            // count) and stay one round out of phase -- seen as rare wrong payload bytes when two workgroups
-            // shared a CU (tests/test_gpu_determinism.py).  The other branches have a barrier at this point.
-            __syncthreads();
+        if (plan.mode == kPlanPause) { // :820-824
             if (t0) {
                 S.state = kDecodeHeader;
                 const int32_t consumed = (int32_t)(sps + sps / 4u);
                 S.att_hdr = S.pos + consumed;
                 w2_end_step(S, job, C, recs, trace, kPause, consumed, -1, 0, 0.0f, t_start);
+                plan_from_state(next);
             }
-            __syncthreads();
             continue;
         }
 
-        // ---- DECODE_HEADER / DECODE_PAYLOAD round (:826-886)
-        {
+        if (plan.mode == kPlanFinalize) { // decode(false) + frame bytes (:870-881), all threads
+            const uint32_t n_cw = S.n_cw, cr = S.cr, n_bytes = S.fin_n_bytes, plen = S.fin_plen;
+            decode_payload_bytes(sh, n_cw, cr, n_bytes);
+            AttemptRec &r = recs[S.n_att];
+            for (uint32_t i = threadIdx.x; i < plen; i += kW2) r.frame[3u + i] = (i < n_bytes) ? sh.dec[i] : 0;
+            __syncthreads();
+            if (t0) {
+                r.frame[0] = S.phdr[0]; r.frame[1] = S.phdr[1]; r.frame[2] = S.phdr[2]; // d_phdr (:600)
+                r.frame_len = 3u + plen;
+                S.frame_ok = 1;
+                S.state = kDetect;
+                S.n_words = 0; S.n_cw = 0;
+                S.fin_pending = 0;
+                w2_end_step(S, job, C, recs, trace, S.fin_st, S.fin_consumed, S.fin_bin, S.fin_fine, 0.0f, t_start);
+                plan_from_state(next);
+            }
+            continue;
+        }
+
+        // ---- kPlanDecode: DECODE_HEADER / DECODE_PAYLOAD rounds (:826-886), pipelined.  Workers demodulate the
+        // 7 symbols at plan.pos into spec[plan.buf]; concurrently the control thread resolves the previous round
+        // (spec[plan.buf ^ 1]) and decides whether this round's position was predicted correctly.
+        if (!is_ctl) {
             uint32_t ws = 0;
             int32_t wfine = 0;
             if (wvalid) fast_demod_symbol<SF>(P, FT, X + wpos, ws, wfine);
-            if (lane == 0) { W.speci[wave][0] = wvalid ? (int32_t)ws : -1; W.speci[wave][1] = wfine; }
-            __syncthreads();
-            if (t0) {
-                S.fin_pending = 0;
-                for (int w = 0; w < kW2Waves; w++) {
+            if (lane == 0) { W.speci[plan.buf][wave][0] = wvalid ? (int32_t)ws : -1; W.speci[plan.buf][wave][1] = wfine; }
+        } else if (t0) {
+            bool predicted = true;
+            if (plan.resolve_prev) {
+                const int rb = plan.buf ^ 1;
+                for (int w = 0; w < kW2Workers; w++) {
                     if (w > 0 && !w2_pre_step(S, job, C, sps)) break;
-                    if (!(S.state == kDecodeHeader || S.state == kDecodePayload) || W.speci[w][0] < 0) break;
+                    if (!(S.state == kDecodeHeader || S.state == kDecodePayload) || W.speci[rb][w][0] < 0) break;
                     const bool is_first = S.state == kDecodeHeader;
                     const int32_t st_w = S.state;
-                    const uint32_t s = (uint32_t)W.speci[w][0];
-                    const int32_t fw = W.speci[w][1];
-                    const uint32_t bin_idx = (s == 0u && P.demod_mode == 2u) ? 0u : (s + (uint32_t)N - 1u) % (uint32_t)N;
+                    const uint32_t sres = (uint32_t)W.speci[rb][w][0];
+                    const int32_t fw = W.speci[rb][w][1];
+                    const uint32_t bin_idx = (sres == 0u && P.demod_mode == 2u) ? 0u : (sres + (uint32_t)N - 1u) % (uint32_t)N;
                     if (w2_post_symbol(P, S, sh, bin_idx, is_first)) { // payload complete: finalise with all threads
                         S.fin_pending = 1; S.fin_st = st_w; S.fin_consumed = (int32_t)sps + fw; S.fin_bin = (int32_t)bin_idx; S.fin_fine = fw;
                         break;
@@ -515,29 +565,20 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                     w2_end_step(S, job, C, recs, trace, st_w, (int32_t)sps + fw, (int32_t)bin_idx, fw, 0.0f, t_start);
                     if (S.done || fw != 0) break; // later windows started at the wrong sample
                 }
+                // is the round the workers are computing right now the true continuation?
+                predicted = !S.done && !S.fin_pending && (S.state == kDecodeHeader || S.state == kDecodePayload) && S.pos == plan.pos &&
+                            w2_pre_step(S, job, C, sps);
             }
-            __syncthreads();
-            if (S.fin_pending) { // decode(false) + frame bytes (:870-881)
-                const uint32_t n_cw = S.n_cw, cr = S.cr, n_bytes = S.fin_n_bytes, plen = S.fin_plen;
-                decode_payload_bytes(sh, n_cw, cr, n_bytes);
-                AttemptRec &r = recs[S.n_att];
-                for (uint32_t i = threadIdx.x; i < plen; i += kW2) r.frame[3u + i] = (i < n_bytes) ? sh.dec[i] : 0;
-                __syncthreads();
-                if (t0) {
-                    r.frame[0] = S.phdr[0]; r.frame[1] = S.phdr[1]; r.frame[2] = S.phdr[2]; // d_phdr (:600)
-                    r.frame_len = 3u + plen;
-                    S.frame_ok = 1;
-                    S.state = kDetect;
-                    S.n_words = 0; S.n_cw = 0;
-                    S.fin_pending = 0;
-                    w2_end_step(S, job, C, recs, trace, S.fin_st, S.fin_consumed, S.fin_bin, S.fin_fine, 0.0f, t_start);
-                }
-                __syncthreads();
+            if (predicted) {
+                next.mode = kPlanDecode; next.pos = plan.pos + (int64_t)kW2Workers * sps; next.buf = plan.buf ^ 1; next.resolve_prev = 1; next.pad = 0;
+            } else {
+                plan_from_state(next); // this round's results are discarded
             }
         }
     }
 
     // an attempt cut short (out of data, or probe stop) is reported but not counted as complete
+    __syncthreads();
     if (t0) {
         const bool in_attempt = S.in_attempt != 0;
         if (in_attempt && S.n_att < C.recs_per_job) {
