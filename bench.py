@@ -110,15 +110,16 @@ def main():
 
     def step():
         h.decode_device(d_iq.data_ptr(), n_items, offs, lens, stream)
-        fr = h.drain()
-        allf = gather.gather_frames([(b, i.stream, i.header_pos) for b, i in fr], dev)
-        return fr, allf
+        buf, infos = h.drain_raw()
+        slots, counts = gather.gather_raw(buf, infos, dev)   # RCCL all_gather of the frames when N > 1
+        return slots, counts
 
-    # correctness of what is being timed (outside the timed region)
-    fr, _ = step()
+    # correctness of what is being timed (outside the timed region): frames as gathered, this rank's share
+    slots, counts = step()
+    mine = gather.unpack_frames(slots[rank if len(counts) > 1 else 0], counts[rank if len(counts) > 1 else 0])
     got = {}
-    for b, i in fr:
-        got.setdefault(i.stream, []).append(b[15:])
+    for b, sid, _hp in mine:
+        got.setdefault(sid, []).append(b[15:])
     verified = all(got.get(s, []) == expect[s] for s in range(len(offs)))
 
     for _ in range(args.warmup):

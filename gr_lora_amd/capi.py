@@ -190,6 +190,30 @@ class Handle:
             if n.value == 0:
                 return out
 
+    INFO_DTYPE = np.dtype([("stream", "<u4"), ("length", "<u4"), ("header_pos", "<i8"), ("end_pos", "<i8")])
+
+    def drain_raw(self):
+        """All queued frames without per-frame Python objects: (blob bytes back to back as uint8[], infos as a
+        structured array with fields stream / length / header_pos / end_pos)."""
+        bufs, infos = [], []
+        while True:
+            n_avail = self.frames_available()
+            if n_avail == 0:
+                break
+            k = min(n_avail, 8192)
+            buf = np.empty(k * 280, dtype=np.uint8)
+            inf = np.empty(k, dtype=self.INFO_DTYPE)
+            n = C.c_size_t(0)
+            self._check(self.L.lora_hip_drain_frames(self.h, buf.ctypes.data, buf.size, C.cast(inf.ctypes.data, C.POINTER(FrameInfo)), k, C.byref(n)))
+            if n.value == 0:
+                break
+            inf = inf[: n.value]
+            bufs.append(buf[: int(inf["length"].sum())])
+            infos.append(inf)
+        if not bufs:
+            return np.empty(0, dtype=np.uint8), np.empty(0, dtype=self.INFO_DTYPE)
+        return np.concatenate(bufs), np.concatenate(infos)
+
     def timing(self) -> Timing:
         t = Timing()
         self._check(self.L.lora_hip_last_timing(self.h, C.byref(t)))

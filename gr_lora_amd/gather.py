@@ -59,6 +59,43 @@ def gather_frames(frames: Sequence[Tuple[bytes, int, int]], device: torch.device
     return [unpack_frames(s.cpu().numpy(), c) for s, c in zip(slots, counts)]
 
 
+def pack_raw(buf: np.ndarray, infos: np.ndarray, capacity: int) -> np.ndarray:
+    """Vectorised pack_frames for Handle.drain_raw() output."""
+    n = infos.size
+    if n > capacity:
+        raise ValueError("frame slot capacity exceeded")
+    out = np.zeros((capacity, SLOT_BYTES), dtype=np.uint8)
+    if n == 0:
+        return out
+    lengths = infos["length"].astype(np.int64)
+    if lengths.max() > SLOT_BLOB:
+        raise ValueError("frame blob too long")
+    out[:n, 0:4] = np.ascontiguousarray(infos["stream"]).view(np.uint8).reshape(n, 4)
+    out[:n, 4:8] = np.ascontiguousarray(infos["length"]).view(np.uint8).reshape(n, 4)
+    out[:n, 8:16] = np.ascontiguousarray(infos["header_pos"]).view(np.uint8).reshape(n, 8)
+    starts = np.cumsum(lengths) - lengths
+    row = np.repeat(np.arange(n), lengths)
+    col = np.arange(int(lengths.sum())) - np.repeat(starts, lengths)
+    out[row, 16 + col] = buf[: int(lengths.sum())]
+    return out
+
+
+def gather_raw(buf: np.ndarray, infos: np.ndarray, device: torch.device, group=None):
+    """All ranks contribute their frames (raw form); returns (slots uint8 [world, cap, SLOT_BYTES], counts)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return pack_raw(buf, infos, max(1, infos.size))[None], [int(infos.size)]
+    world = dist.get_world_size(group)
+    cnt = torch.tensor([infos.size], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(counts, cnt, group=group)
+    counts = [int(c.item()) for c in counts]
+    cap = max(1, max(counts))
+    mine = torch.from_numpy(pack_raw(buf, infos, cap)).to(device)
+    slots = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(slots, mine, group=group)
+    return torch.stack(slots).cpu().numpy(), counts
+
+
 def shard_streams(n_streams: int, rank: int, world: int) -> List[int]:
     """Static partition: stream c -> rank c mod world."""
     return [c for c in range(n_streams) if c % world == rank]

@@ -58,3 +58,15 @@ def test_gather_world2_gloo():
             want = [(bytes([src, s]) * (3 + s), s, 1000 * s + src) for s in gather.shard_streams(7, src, 2)]
             assert allf[src] == want
     assert sorted(gather.shard_streams(7, 0, 2) + gather.shard_streams(7, 1, 2)) == list(range(7))
+
+
+def test_pack_raw_equals_pack_frames():
+    rng = np.random.default_rng(4)
+    frames = [(bytes(rng.integers(0, 256, int(rng.integers(18, 276)), dtype=np.uint8)), int(rng.integers(0, 64)), int(rng.integers(0, 1 << 40))) for _ in range(37)]
+    infos = np.zeros(len(frames), dtype=[("stream", "<u4"), ("length", "<u4"), ("header_pos", "<i8"), ("end_pos", "<i8")])
+    for i, (b, s, hp) in enumerate(frames):
+        infos[i] = (s, len(b), hp, 0)
+    buf = np.frombuffer(b"".join(b for b, _, _ in frames), dtype=np.uint8)
+    assert (gather.pack_raw(buf, infos, 40) == gather.pack_frames(frames, 40)).all()
+    slots, counts = gather.gather_raw(buf, infos, torch.device("cpu"))
+    assert counts == [37] and gather.unpack_frames(slots[0], 37) == frames
