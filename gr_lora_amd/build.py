@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "liblora_hip.so")
 SOURCES = ["lora_kernels.hip", "lora_runtime.cpp"]
-DEPS = SOURCES + ["lora_device.h", "lora_walker2.inc.hip", "whitening_data.inc", os.path.join("..", "..", "include", "lora_hip.h")]
+DEPS = SOURCES + ["lora_device.h", "lora_stitch.hpp", "lora_walker2.inc.hip", "whitening_data.inc", os.path.join("..", "..", "include", "lora_hip.h")]
 
 
 def hipcc_path() -> str:

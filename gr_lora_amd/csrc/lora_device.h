@@ -11,6 +11,10 @@
 #pragma once
 #include <stdint.h>
 
+#if !defined(__HIPCC__) && !defined(HIP_INCLUDE_HIP_HIP_RUNTIME_H)
+struct float2 { float x, y; }; // host-only builds (tests/host_sim) do not pull in HIP
+#endif
+
 namespace lora_hip {
 
 constexpr int kWG = 256;              // threads per workgroup (4 wavefronts of 64)

@@ -1,0 +1,342 @@
+// lora_stitch.hpp -- the speculation scheduler: segments, probes and the stitch, independent of HIP.
+//
+// decode_streams<Env>() is instantiated twice: by lora_runtime.cpp over the real device (jobs run by the
+// walker kernels) and by tests/host_sim/stitch_sim.cpp over a CPU environment whose jobs are run by the
+// oracle's state machine -- so the scheduling logic is exercised by the CPU test-suite as well.
+//
+// Env must provide:  uint32_t sps(), ctor_cr(), segment_symbols(), resident_slots();  bool tracing(), implicit();
+//   int  run_jobs(const std::vector<Job> &, uint32_t recs_per_job, uint32_t trace_cap, RunOut &);   (0 = ok)
+//   void publish(const AttemptRec &, StreamDesc &);   void append_trace(const RunOut &, uint32_t job, uint32_t cap, int64_t base);
+//   void count_jobs(uint32_t), count_probes(uint32_t), count_slow_path();   double walker_ms();
+#pragma once
+#include <algorithm>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "lora_device.h"
+
+namespace lora_hip {
+
+// d_pwr_queue (boost::circular_buffer<float>(4)) + d_snr, kept on the host: the
+// device reports the values each DETECT step pushed (:360), the host replays them.
+struct PwrState {
+    float q[4];
+    int n = 0;
+    float snr = 0.0f; // uninitialised upstream (decoder_impl.h:101); pinned to 0
+    void push(float v)
+    {
+        if (n < 4) q[n++] = v;
+        else { q[0] = q[1]; q[1] = q[2]; q[2] = q[3]; q[3] = v; }
+    }
+    void apply(uint32_t npush, const float tail[4])
+    {
+        const uint32_t k = npush < 4u ? npush : 4u;
+        for (uint32_t i = 0; i < k; i++) push(tail[i]);
+    }
+    void determine_snr() // :377-383
+    {
+        if (n >= 2) snr = q[n - 1] / q[0];
+    }
+};
+
+struct StreamDesc {
+    uint64_t off, len;
+    uint32_t id;
+    uint32_t cr_in;       // d_phdr.cr carried in
+    PwrState pwr;         // power queue / snr carried in
+    int64_t  abs_base;    // added to reported positions
+    // results
+    int64_t  final_pos = 0;
+    uint32_t cr_out = 0;
+    bool incomplete = false;
+};
+
+struct RunOut {
+    std::vector<JobResult> res;
+    std::vector<AttemptRec> recs;
+    uint32_t rpj = 0;
+    const AttemptRec &rec(size_t job, uint32_t a) const { return recs[job * rpj + a]; }
+    // attempts that ran to completion (the last one is pending when JobResult.pad is set)
+    uint32_t n_done(size_t job) const
+    {
+        const JobResult &r = res[job];
+        const uint32_t n = r.pad ? r.n_attempts - 1u : r.n_attempts;
+        return n < rpj ? n : rpj;
+    }
+};
+
+// A completed attempt of the TRUE trajectory: replay its DETECT pushes, take the
+// SNR at the trigger (:756), publish the frame if there is one.
+template <class Env>
+void adopt(Env &env, const AttemptRec &r, StreamDesc &sd)
+{
+    sd.pwr.apply(r.npush, r.push_tail);
+    sd.pwr.determine_snr();
+    if (r.status == kAttemptFrame) env.publish(r, sd);
+}
+
+struct Cursor { int64_t pos; uint32_t cr; }; // DETECT state between attempts: position + carried d_phdr.cr
+
+inline uint32_t recs_for(uint64_t span_items, uint32_t sps)
+{ // a completed packet spans >= 13 symbols, a lost-sync attempt >= 5 (+ its DETECT steps)
+    return (uint32_t)std::min<uint64_t>(span_items / (5ull * sps) + 6ull, 4096ull);
+}
+
+// The truth by construction: one job from `cur` up to `limit`, everything adopted.
+template <class Env>
+int run_serial(Env &env, StreamDesc &sd, Cursor &cur, int64_t limit, bool tracing)
+{
+    while (true) {
+        std::vector<Job> jobs(1);
+        Job &j = jobs[0];
+        j.stream_off = sd.off; j.stream_len = sd.len; j.start = cur.pos; j.scan_limit = limit; j.stream_id = sd.id;
+        j.cr_prev = cur.cr; j.max_attempts = 0; j.stop_at_header = 0;
+        const uint64_t span = (uint64_t)std::max<int64_t>(limit - cur.pos, 0);
+        const uint32_t rpj = recs_for(span, env.sps());
+        const uint32_t trace_cap = tracing ? (uint32_t)std::min<uint64_t>(2ull * (span / env.sps()) + 64ull, 1ull << 22) : 0u;
+        RunOut out;
+        int s = env.run_jobs(jobs, rpj, trace_cap, out);
+        if (s != 0) return s;
+        const JobResult &jr = out.res[0];
+        for (uint32_t a = 0; a < out.n_done(0); a++) adopt(env, out.rec(0, a), sd);
+        if (tracing) env.append_trace(out, 0, trace_cap, sd.abs_base);
+        cur.cr = jr.final_cr;
+        cur.pos = jr.final_pos; // start of the pending attempt when one was cut short
+        if (jr.pad) { sd.incomplete = true; return 0; }
+        sd.pwr.apply(jr.npush, jr.push_tail);
+        if (jr.stop_reason != 2u) return 0;
+    }
+}
+
+inline int cr_class(uint32_t cr) { return cr >= 3u ? 2 : (cr >= 1u ? 1 : 0); }
+
+// Decodes a set of independent streams.
+//
+// Every stream is cut into fixed segments.  Round 1 runs one walker job per
+// segment, each starting in DETECT at its segment boundary (a guess: the true
+// decoder arrives there with some other window phase and possibly mid-packet).
+// Round 2 runs, for every segment, a probe that starts from the END state of the
+// preceding segment's job and walks DETECT/SYNC/FIND_SFD up to the first header.
+// The host then stitches: if the probe enters DECODE_HEADER at the same sample
+// as one of the segment job's attempts, the two trajectories are identical from
+// there on (the decoder state at header entry is position + d_phdr.cr), and the
+// job's remaining attempts are the true ones.  Anything else is re-run serially
+// from the true state.  The result is exactly the serial state machine's.
+template <class Env>
+int decode_streams(Env &env, std::vector<StreamDesc> &streams)
+{
+    const uint32_t sps = env.sps();
+    const bool tracing = env.tracing();
+    uint64_t total = 0;
+    for (const StreamDesc &sd : streams) total += sd.len;
+    // auto: as many segments as workgroups fit on the device at once (one wave of workgroups per launch;
+    // kernel time is ceil(jobs / resident slots) x job latency), never shorter than 64 symbols
+    const uint32_t slots = env.resident_slots();
+    const uint64_t want_jobs = std::max<uint64_t>(slots - slots / 16u, (uint64_t)streams.size());
+    uint64_t seg = env.segment_symbols() ? (uint64_t)env.segment_symbols() * sps
+                                          : std::max<uint64_t>(64ull * sps, (total + want_jobs - 1) / want_jobs);
+    if (seg < 16ull * sps) seg = 16ull * sps;
+    const bool segmenting = !tracing && !env.implicit();
+
+    struct Seg { uint32_t stream; int64_t b0, b1; };
+    std::vector<Seg> segs;
+    std::vector<size_t> first_seg(streams.size() + 1, 0);
+    for (size_t i = 0; i < streams.size(); i++) {
+        first_seg[i] = segs.size();
+        StreamDesc &sd = streams[i];
+        sd.cr_out = sd.cr_in; sd.final_pos = 0; sd.incomplete = false;
+        uint64_t n = 1;
+        if (segmenting && sd.len > seg + seg / 2) n = (sd.len + seg - 1) / seg;
+        for (uint64_t k = 0; k < n; k++)
+            segs.push_back(Seg{(uint32_t)i, (int64_t)(k * seg), (k + 1 == n) ? (int64_t)sd.len : (int64_t)((k + 1) * seg)});
+    }
+    first_seg[streams.size()] = segs.size();
+    if (segs.empty()) return 0;
+
+    // ---- round 1: every segment speculatively
+    std::vector<Job> jobs(segs.size());
+    uint64_t max_span = 0;
+    for (size_t k = 0; k < segs.size(); k++) {
+        const StreamDesc &sd = streams[segs[k].stream];
+        Job &j = jobs[k];
+        j.stream_off = sd.off; j.stream_len = sd.len; j.start = segs[k].b0; j.scan_limit = segs[k].b1;
+        j.stream_id = sd.id; j.cr_prev = (k == first_seg[segs[k].stream]) ? sd.cr_in : env.ctor_cr();
+        j.max_attempts = 0; j.stop_at_header = 0;
+        max_span = std::max<uint64_t>(max_span, (uint64_t)(segs[k].b1 - segs[k].b0));
+    }
+    const uint32_t rpj1 = recs_for(max_span, sps);
+    const uint32_t trace_cap = tracing ? (uint32_t)std::min<uint64_t>(2ull * (max_span / sps) + 64ull, 1ull << 22) : 0u;
+    RunOut R1;
+    env.count_jobs((uint32_t)jobs.size());
+    static const bool dbg_t = getenv("LORA_HIP_DEBUG") != nullptr;
+    const auto tp0 = std::chrono::steady_clock::now();
+    int s = env.run_jobs(jobs, rpj1, trace_cap, R1);
+    if (s != 0) return s;
+    const auto tp1 = std::chrono::steady_clock::now();
+
+    // ---- round 2: probes along the speculative chain.  Only segments whose own job
+    // reached a header get a probe; it starts from the end state of the previous
+    // header-bearing job and scans through any header-less segments in between.
+    auto has_header = [&](size_t k) {
+        const uint32_t nall = std::min(R1.res[k].n_attempts, rpj1);
+        for (uint32_t a = 0; a < nall; a++) {
+            const AttemptRec &r = R1.rec(k, a);
+            if (r.hdr_pos >= 0 && (r.status == kAttemptFrame || r.status == kAttemptOutOfData)) return true;
+        }
+        return false;
+    };
+    auto job_ok = [&](size_t k) { return !R1.res[k].pad && R1.res[k].stop_reason != 2u; };
+    struct Probe { uint32_t stream; size_t target; Cursor start; int job; };
+    std::vector<Probe> probes;
+    std::vector<size_t> first_probe(streams.size() + 1, 0);
+    std::vector<Job> pjobs;
+    for (size_t i = 0; i < streams.size(); i++) {
+        first_probe[i] = probes.size();
+        const size_t f = first_seg[i], e = first_seg[i + 1];
+        if (e - f < 2) continue;
+        const StreamDesc &sd = streams[i];
+        bool chain = job_ok(f), pending = false;
+        Cursor cur{R1.res[f].final_pos, R1.res[f].final_cr};
+        auto add_probe = [&](size_t target, int64_t limit) {
+            Job j{};
+            j.stream_off = sd.off; j.stream_len = sd.len; j.start = cur.pos; j.scan_limit = limit;
+            j.stream_id = sd.id; j.cr_prev = cur.cr; j.max_attempts = 0; j.stop_at_header = 1;
+            probes.push_back(Probe{(uint32_t)i, target, cur, (int)pjobs.size()});
+            pjobs.push_back(j);
+        };
+        for (size_t k = f + 1; k < e && chain; k++) {
+            if (cur.pos >= segs[k].b1) continue; // a packet ran across this whole segment
+            if (!has_header(k)) { pending = true; continue; }
+            add_probe(k, std::min<int64_t>((int64_t)sd.len, segs[k].b1 + 16ll * sps));
+            chain = job_ok(k);
+            cur = Cursor{R1.res[k].final_pos, R1.res[k].final_cr};
+            pending = false;
+        }
+        if (chain && pending) add_probe(e - 1, (int64_t)sd.len); // header-less tail still has to be walked
+    }
+    first_probe[streams.size()] = probes.size();
+    RunOut R2;
+    const uint32_t rpj2 = 8;
+    if (!pjobs.empty()) {
+        env.count_probes((uint32_t)pjobs.size());
+        s = env.run_jobs(pjobs, rpj2, 0, R2);
+        if (s != 0) return s;
+    }
+
+    const auto tp2 = std::chrono::steady_clock::now();
+    // ---- stitch, stream by stream, in stream order
+    for (size_t i = 0; i < streams.size(); i++) {
+        StreamDesc &sd = streams[i];
+        const size_t f = first_seg[i];
+        // the first segment starts from the true state: adopt it wholesale
+        for (uint32_t a = 0; a < R1.n_done(f); a++) adopt(env, R1.rec(f, a), sd);
+        if (tracing) env.append_trace(R1, (uint32_t)f, trace_cap, sd.abs_base);
+        Cursor cur{R1.res[f].final_pos, R1.res[f].final_cr};
+        int64_t covered = segs[f].b1; // the true trajectory is known up to here
+        if (R1.res[f].pad) sd.incomplete = true;
+        else sd.pwr.apply(R1.res[f].npush, R1.res[f].push_tail);
+        static const bool dbg = getenv("LORA_HIP_DEBUG") != nullptr;
+        auto serial_to = [&](int64_t limit, const char *why) -> int {
+            if (dbg) fprintf(stderr, "[lora_hip] serial fallback stream %u pos %lld -> %lld: %s\n", sd.id, (long long)cur.pos, (long long)limit, why);
+            env.count_slow_path();
+            int r = run_serial(env, sd, cur, limit, false);
+            covered = std::max(covered, limit);
+            return r;
+        };
+        if (!sd.incomplete && R1.res[f].stop_reason == 2u) {
+            s = serial_to(segs[f].b1, "first segment out of records");
+            if (s != 0) return s;
+        }
+        for (size_t q = first_probe[i]; q < first_probe[i + 1] && !sd.incomplete; q++) {
+            const Probe &pb = probes[q];
+            const int64_t b1 = segs[pb.target].b1;
+            if (cur.pos >= b1) continue;
+            if (pb.start.pos != cur.pos || pb.start.cr != cur.cr) { // speculation chain broken: redo serially
+                s = serial_to(b1, "probe start differs from the true state");
+                if (s != 0) return s;
+                continue;
+            }
+            const size_t pj = (size_t)pb.job;
+            const JobResult &pr = R2.res[pj];
+            // lost-sync attempts the true trajectory went through before the header
+            for (uint32_t a = 0; a < R2.n_done(pj); a++) adopt(env, R2.rec(pj, a), sd);
+            if (!pr.pad) { // no header before the probe's limit
+                cur = Cursor{pr.final_pos, pr.final_cr};
+                sd.pwr.apply(pr.npush, pr.push_tail);
+                covered = std::max(covered, std::min<int64_t>(pjobs[pj].scan_limit, b1));
+                if (pr.stop_reason == 2u || (cur.pos < b1 && cur.pos + 2 * (int64_t)sps <= (int64_t)sd.len)) {
+                    s = serial_to(b1, "probe ended without a header");
+                    if (s != 0) return s;
+                }
+                continue;
+            }
+            const AttemptRec &L = R2.rec(pj, std::min(pr.n_attempts, rpj2) - 1u);
+            if (L.status != kAttemptAtHeader) { // ran out of data before reaching a header
+                cur.pos = L.start_pos;
+                sd.incomplete = true;
+                break;
+            }
+            // which segment job entered a header at the same sample?
+            int match = -1;
+            size_t mk = 0;
+            for (size_t k = f + 1; k <= pb.target && match < 0; k++) {
+                if (segs[k].b1 <= cur.pos) continue;
+                const uint32_t nall = std::min(R1.res[k].n_attempts, rpj1);
+                for (uint32_t a = 0; a < nall; a++) {
+                    const AttemptRec &r = R1.rec(k, a);
+                    if (r.hdr_pos != L.hdr_pos || (r.status != kAttemptFrame && r.status != kAttemptOutOfData)) continue;
+                    if (r.hdr_ambig && cr_class(r.cr_prev) != cr_class(L.cr_prev)) continue;
+                    match = (int)a; mk = k;
+                    break;
+                }
+            }
+            if (match < 0) {
+                cur = Cursor{L.start_pos, L.cr_prev};
+                s = serial_to(b1, "no segment job entered the same header");
+                if (s != 0) return s;
+                continue;
+            }
+            const AttemptRec &m = R1.rec(mk, (uint32_t)match);
+            if (m.status == kAttemptOutOfData) {
+                cur = Cursor{L.start_pos, L.cr_prev};
+                sd.incomplete = true;
+                break;
+            }
+            // merged: the true DETECT scan is the probe's, everything after the header is the job's
+            sd.pwr.apply(L.npush, L.push_tail);
+            sd.pwr.determine_snr();
+            env.publish(m, sd);
+            for (uint32_t a = (uint32_t)match + 1u; a < R1.n_done(mk); a++) adopt(env, R1.rec(mk, a), sd);
+            const JobResult &jr = R1.res[mk];
+            cur = Cursor{jr.final_pos, jr.final_cr};
+            if (jr.pad) { sd.incomplete = true; break; }
+            sd.pwr.apply(jr.npush, jr.push_tail);
+            covered = std::max(covered, segs[mk].b1);
+            if (jr.stop_reason == 2u) {
+                s = serial_to(segs[mk].b1, "segment job out of records");
+                if (s != 0) return s;
+            }
+        }
+        // whatever the probes did not cover is walked serially (exactness before speed)
+        if (!sd.incomplete && cur.pos < (int64_t)sd.len && covered < (int64_t)sd.len &&
+            cur.pos + 2 * (int64_t)sps <= (int64_t)sd.len) {
+            s = serial_to((int64_t)sd.len, "uncovered tail");
+            if (s != 0) return s;
+        }
+        sd.final_pos = cur.pos;
+        sd.cr_out = cur.cr;
+    }
+    if (dbg_t) {
+        const auto tp3 = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[lora_hip] round1 %.3f ms (%zu jobs, rpj %u), round2 %.3f ms (%zu probes), stitch %.3f ms, walker %.3f ms\n",
+                ms(tp0, tp1), jobs.size(), rpj1, ms(tp1, tp2), pjobs.size(), ms(tp2, tp3), env.walker_ms());
+    }
+    return 0;
+}
+
+
+} // namespace lora_hip

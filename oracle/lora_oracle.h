@@ -91,6 +91,29 @@ void     lora_oracle_instantaneous_frequency(const float *iq, float *out, uint32
 void     lora_oracle_demod_at(lora_oracle_t *o, const float *iq, const int64_t *offsets, size_t n,
                               int mode, uint32_t *bins_out);
 
+/* ---- job-level entry, used by tests/host_sim to exercise the product's speculation scheduler on the CPU ----
+ * Runs the state machine like one walker job: start in DETECT at `start` with d_phdr.cr = cr_prev, begin no new
+ * DETECT step at pos >= scan_limit, stop after max_attempts (0 = no limit) or, with stop_at_header, on entering
+ * DECODE_HEADER.  Attempts are reported in the same terms as the device's AttemptRec / JobResult.                */
+typedef struct {
+    int64_t  start_pos, trig_pos, hdr_pos, end_pos;
+    uint32_t status;        /* 1 frame, 2 lost sync, 3 out of data, 4 stopped at header */
+    uint32_t npush;
+    float    push_tail[4];
+    uint32_t cr_prev, hdr_ambig, frame_len, n_symbols;
+    uint8_t  frame[264];
+} oracle_attempt_t;
+typedef struct {
+    int64_t  final_pos;
+    uint32_t n_attempts, final_cr, npush;
+    float    push_tail[4];
+    uint32_t stop_reason;   /* 0 scan limit, 1 out of data, 2 record capacity, 3 max_attempts / probe stop */
+    uint32_t pad;           /* 1: the last reported attempt is incomplete */
+} oracle_job_result_t;
+void lora_oracle_run_job(lora_oracle_t *o, const float *iq, size_t n_items, int64_t start, int64_t scan_limit,
+                         uint32_t cr_prev, uint32_t max_attempts, int stop_at_header, uint32_t recs_cap,
+                         oracle_attempt_t *recs, oracle_job_result_t *res);
+
 /* integer chain helpers (bit-exact) */
 uint32_t lora_oracle_rotl(uint32_t bits, uint32_t count, uint32_t size);   /* utilities.h:96-103 */
 uint8_t  lora_oracle_hamming_encode(uint8_t nibble);                      /* utilities.h:257-264 */

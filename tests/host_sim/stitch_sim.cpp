@@ -1,0 +1,93 @@
+// stitch_sim.cpp -- TEST-ONLY environment for the product's speculation scheduler (gr_lora_amd/csrc/lora_stitch.hpp):
+// jobs are executed by the CPU oracle's state machine instead of the walker kernels, so that segmenting,
+// probing and stitching are exercised by the CPU test-suite.  Built by tests/test_stitch_sim.py with g++.
+#include <cstring>
+#include <vector>
+
+#include "../../gr_lora_amd/csrc/lora_stitch.hpp"
+#include "../../oracle/lora_oracle.h"
+
+using namespace lora_hip;
+
+namespace {
+struct SimFrame { std::vector<uint8_t> blob; int64_t hdr_pos; };
+
+struct SimEnv {
+    lora_oracle_t *o;
+    const float *iq;
+    size_t n_items;
+    uint32_t sps_, ctor_cr_, seg_symbols, slots;
+    std::vector<SimFrame> frames;
+    uint32_t n_jobs = 0, n_probes = 0, n_slow = 0;
+
+    uint32_t sps() const { return sps_; }
+    uint32_t ctor_cr() const { return ctor_cr_; }
+    uint32_t segment_symbols() const { return seg_symbols; }
+    uint32_t resident_slots() const { return slots; }
+    bool tracing() const { return false; }
+    bool implicit() const { return false; }
+    int run_jobs(const std::vector<Job> &jobs, uint32_t rpj, uint32_t, RunOut &out)
+    {
+        out.rpj = rpj;
+        out.res.assign(jobs.size(), JobResult{});
+        out.recs.assign(jobs.size() * (size_t)rpj, AttemptRec{});
+        std::vector<oracle_attempt_t> tmp(rpj + 1);
+        for (size_t j = 0; j < jobs.size(); j++) {
+            const Job &jb = jobs[j];
+            oracle_job_result_t r{};
+            lora_oracle_run_job(o, iq + 2 * jb.stream_off, (size_t)jb.stream_len, jb.start, jb.scan_limit, jb.cr_prev,
+                                jb.max_attempts, (int)jb.stop_at_header, rpj, tmp.data(), &r);
+            JobResult &jr = out.res[j];
+            jr.final_pos = r.final_pos; jr.n_attempts = r.n_attempts; jr.final_cr = r.final_cr; jr.npush = r.npush;
+            std::memcpy(jr.push_tail, r.push_tail, sizeof jr.push_tail);
+            jr.stop_reason = r.stop_reason; jr.pad = r.pad;
+            for (uint32_t a = 0; a < r.n_attempts && a < rpj; a++) {
+                AttemptRec &d = out.recs[j * (size_t)rpj + a];
+                const oracle_attempt_t &s = tmp[a];
+                d.start_pos = s.start_pos; d.trig_pos = s.trig_pos; d.hdr_pos = s.hdr_pos; d.end_pos = s.end_pos;
+                d.status = s.status; d.npush = s.npush; std::memcpy(d.push_tail, s.push_tail, sizeof d.push_tail);
+                d.cr_prev = s.cr_prev; d.hdr_ambig = s.hdr_ambig; d.frame_len = s.frame_len; d.n_symbols = s.n_symbols;
+                std::memcpy(d.frame, s.frame, s.frame_len);
+            }
+        }
+        return 0;
+    }
+    void publish(const AttemptRec &r, StreamDesc &sd)
+    { // same blob as lora_runtime.cpp::publish
+        SimFrame f;
+        f.blob.assign(15 + r.frame_len, 0);
+        f.blob[13] = lora_oracle_snr_byte(sd.pwr.snr);
+        std::memcpy(f.blob.data() + 15, r.frame, r.frame_len);
+        f.hdr_pos = sd.abs_base + r.hdr_pos;
+        frames.push_back(std::move(f));
+    }
+    void append_trace(const RunOut &, uint32_t, uint32_t, int64_t) {}
+    void count_jobs(uint32_t n) { n_jobs += n; }
+    void count_probes(uint32_t n) { n_probes += n; }
+    void count_slow_path() { n_slow++; }
+    double walker_ms() const { return 0.0; }
+};
+} // namespace
+
+extern "C" int stitch_sim_decode(const float *iq, size_t n_items, int sf, int ctor_cr, int crc, int reduced_rate, int demod,
+                                 uint32_t segment_symbols, uint32_t resident_slots, uint8_t *out, size_t cap, int *lens,
+                                 long long *hdr_pos, int max_frames, uint32_t *stats)
+{
+    lora_oracle_t *o = lora_oracle_create(1e6f, 125000, (uint8_t)sf, 0, (uint8_t)ctor_cr, crc, reduced_rate, 0, demod);
+    if (!o) return -1;
+    SimEnv env{o, iq, n_items, lora_oracle_sps(o), (uint32_t)ctor_cr, segment_symbols, resident_slots};
+    std::vector<StreamDesc> sds(1);
+    sds[0].off = 0; sds[0].len = n_items; sds[0].id = 0; sds[0].cr_in = (uint32_t)ctor_cr; sds[0].abs_base = 0;
+    const int rc = decode_streams(env, sds);
+    lora_oracle_destroy(o);
+    if (rc != 0) return -2;
+    size_t used = 0;
+    int n = 0;
+    for (const SimFrame &f : env.frames) {
+        if (n >= max_frames || used + f.blob.size() > cap) return -3;
+        std::memcpy(out + used, f.blob.data(), f.blob.size());
+        lens[n] = (int)f.blob.size(); hdr_pos[n] = f.hdr_pos; used += f.blob.size(); n++;
+    }
+    stats[0] = env.n_jobs; stats[1] = env.n_probes; stats[2] = env.n_slow; stats[3] = sds[0].incomplete ? 1u : 0u;
+    return n;
+}

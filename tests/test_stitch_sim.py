@@ -1,0 +1,104 @@
+"""CPU tests of the product's speculation scheduler (gr_lora_amd/csrc/lora_stitch.hpp): the same
+decode_streams<> template the device runtime uses, instantiated over an environment whose jobs are run by the
+oracle's state machine (tests/host_sim/stitch_sim.cpp).  Segmenting + probing + stitching must reproduce the
+serial decoder exactly: frames, order, header positions."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from gr_lora_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIM_DIR = os.path.join(ROOT, "tests", "host_sim")
+SIM_LIB = os.path.join(SIM_DIR, "libstitch_sim.so")
+
+
+@pytest.fixture(scope="module")
+def sim(oracle_mod):
+    src = os.path.join(SIM_DIR, "stitch_sim.cpp")
+    deps = [src, os.path.join(ROOT, "gr_lora_amd", "csrc", "lora_stitch.hpp"), os.path.join(ROOT, "gr_lora_amd", "csrc", "lora_device.h"),
+            os.path.join(ROOT, "oracle", "liblora_oracle.so")]
+    if not os.path.exists(SIM_LIB) or any(os.path.getmtime(d) > os.path.getmtime(SIM_LIB) for d in deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-o", SIM_LIB, src, "-L", os.path.join(ROOT, "oracle"),
+                               "-llora_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
+    L = C.CDLL(SIM_LIB)
+    L.stitch_sim_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
+                                    C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+
+    def run(iq, sf, ctor_cr=4, demod=2, reduced=False, seg=0, slots=512):
+        a = np.ascontiguousarray(iq, dtype=np.complex64)
+        out = np.zeros(1 << 20, dtype=np.uint8)
+        lens = np.zeros(4096, dtype=np.int32)
+        hp = np.zeros(4096, dtype=np.int64)
+        st = np.zeros(4, dtype=np.uint32)
+        n = L.stitch_sim_decode(a.ctypes.data, a.size, sf, ctor_cr, 1, int(reduced), demod, seg, slots, out.ctypes.data, out.size,
+                                lens.ctypes.data, hp.ctypes.data, 4096, st.ctypes.data)
+        assert n >= 0, n
+        frames, off = [], 0
+        for i in range(n):
+            frames.append(bytes(out[off:off + lens[i]]))
+            off += int(lens[i])
+        return frames, hp[:n].tolist(), dict(jobs=int(st[0]), probes=int(st[1]), slow=int(st[2]), incomplete=int(st[3]))
+    return run
+
+
+def _serial(O, iq, sf, ctor_cr=4, demod=2, reduced=False):
+    o = O.Oracle(sf=sf, cr=ctor_cr, demod=demod, reduced_rate=reduced)
+    o.run(iq)
+    return o.frames(), o.frame_positions()
+
+
+@pytest.mark.parametrize("seg", [16, 23, 40, 64, 150, 0])
+def test_segmented_equals_serial(sim, oracle_mod, seg):
+    cfg = synth.TxConfig(sf=7, cr=4)
+    rng = np.random.default_rng(900 + seg)
+    payloads = [bytes(rng.integers(0, 256, int(rng.integers(1, 48)), dtype=np.uint8)) for _ in range(30)]
+    gaps = [int(g) for g in rng.integers(0, 7 * cfg.sps, len(payloads))]
+    gaps[5] = 0; gaps[6] = 1; gaps[7] = cfg.sps // 2; gaps[8] = 2 * cfg.sps + 3
+    st = synth.build_stream(payloads, cfg, gaps=gaps)
+    want, wpos = _serial(oracle_mod, st.iq, 7)
+    got, gpos, stats = sim(st.iq, 7, seg=seg, slots=40)
+    assert got == want and gpos == wpos
+    assert stats["jobs"] >= (st.iq.size // (seg * cfg.sps) if seg else 2)
+    assert stats["probes"] > 0
+
+
+def test_fast_path_dominates_on_regular_traffic(sim, oracle_mod):
+    """On ordinary traffic nearly every segment merges through its probe; serial fall-backs stay rare."""
+    cfg = synth.TxConfig(sf=7, cr=4)
+    rng = np.random.default_rng(4)
+    payloads = [bytes(rng.integers(0, 256, 32, dtype=np.uint8)) for _ in range(60)]
+    st = synth.build_stream(payloads, cfg, rng=rng)
+    want, wpos = _serial(oracle_mod, st.iq, 7)
+    got, gpos, stats = sim(st.iq, 7, seg=64)
+    assert got == want and gpos == wpos
+    assert stats["slow"] <= 2 and stats["jobs"] > 60
+
+
+@pytest.mark.parametrize("sf,cr,noise_db", [(8, 1, -32), (7, 2, -30), (9, 3, None)])
+def test_noise_and_stale_cr_carry(sim, oracle_mod, sf, cr, noise_db):
+    cfg = synth.TxConfig(sf=sf, cr=cr)
+    rng = np.random.default_rng(77 + sf)
+    payloads = [bytes(rng.integers(0, 256, int(rng.integers(4, 30)), dtype=np.uint8)) for _ in range(12)]
+    st = synth.build_stream(payloads, cfg, rng=rng, noise_sigma=(10 ** (noise_db / 20.0) if noise_db else 0.0))
+    want, wpos = _serial(oracle_mod, st.iq, sf)
+    for seg in (20, 57):
+        got, gpos, _ = sim(st.iq, sf, seg=seg)
+        assert got == want and gpos == wpos
+
+
+def test_gradient_mode_and_truncated_stream(sim, oracle_mod):
+    """demod = GRAD through the scheduler, and a stream that ends in the middle of a packet."""
+    cfg = synth.TxConfig(sf=7, cr=4)
+    rng = np.random.default_rng(12)
+    payloads = [bytes(rng.integers(0, 256, 20, dtype=np.uint8)) for _ in range(10)]
+    st = synth.build_stream(payloads, cfg, rng=rng)
+    cut = st.iq[: st.header_starts[-1] + 30 * cfg.sps]
+    for demod in (0, 2):
+        want, wpos = _serial(oracle_mod, cut, 7, demod=demod)
+        got, gpos, stats = sim(cut, 7, demod=demod, seg=33)
+        assert got == want and gpos == wpos and len(got) == 9
+        assert stats["incomplete"] == 1
