@@ -20,7 +20,7 @@ FLAG_TRACE = 1
 EXPORTS = [
     "lora_hip_abi_version", "lora_hip_strerror", "lora_hip_last_error", "lora_hip_create", "lora_hip_destroy",
     "lora_hip_get_geometry", "lora_hip_set_sf", "lora_hip_set_samp_rate", "lora_hip_work", "lora_hip_flush",
-    "lora_hip_decode_device", "lora_hip_frames_available", "lora_hip_poll_frame", "lora_hip_drain_frames", "lora_hip_demod_symbols_device",
+    "lora_hip_decode_device", "lora_hip_frames_available", "lora_hip_poll_frame", "lora_hip_drain_frames", "lora_hip_demod_symbols_device", "lora_hip_demod_symbols_ex_device",
     "lora_hip_last_timing", "lora_hip_trace", "lora_hip_trace_clear",
 ]
 
@@ -94,6 +94,7 @@ def load():
     L.lora_hip_poll_frame.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(FrameInfo)]
     L.lora_hip_drain_frames.argtypes = [vp, vp, C.c_size_t, C.POINTER(FrameInfo), C.c_size_t, C.POINTER(C.c_size_t)]
     L.lora_hip_demod_symbols_device.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int, vp, vp]
+    L.lora_hip_demod_symbols_ex_device.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int, vp, vp, vp]
     L.lora_hip_last_timing.argtypes = [vp, C.POINTER(Timing)]
     L.lora_hip_trace.restype = C.c_size_t
     L.lora_hip_trace.argtypes = [vp, C.POINTER(C.POINTER(Step))]
@@ -155,6 +156,15 @@ class Handle:
         out = np.zeros(off.size, dtype=np.uint32)
         self._check(self.L.lora_hip_demod_symbols_device(self.h, dev_ptr, total_items, off.ctypes.data, off.size, demod, out.ctypes.data, stream))
         return out
+
+    def demod_symbols_ex_device(self, dev_ptr: int, total_items: int, offsets: Sequence[int], demod: int, stream: int = 0):
+        """(shifts, fine): get_shift_fft's value and d_fine_sync after the per-symbol fine_sync, per window."""
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        out = np.zeros(off.size, dtype=np.uint32)
+        fine = np.zeros(off.size, dtype=np.int32)
+        self._check(self.L.lora_hip_demod_symbols_ex_device(self.h, dev_ptr, total_items, off.ctypes.data, off.size, demod, out.ctypes.data,
+                                                            fine.ctypes.data, stream))
+        return out, fine
 
     def frames_available(self) -> int:
         return self.L.lora_hip_frames_available(self.h)

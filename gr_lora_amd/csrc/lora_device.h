@@ -54,6 +54,7 @@ struct DevParams {
     const float  *up_ifreq_v;   // d_upchirp_ifreq_v (+ guard tail)
     const float2 *twN;          // e^{-2 pi i t / N},   t < N/2
     const float2 *tws;          // e^{-2 pi i m / sps}, m < sps
+    const float  *wave_tabs;    // packed table block of the wave demodulator (lora_wave_demod.inc.hip), SF7/SF8 at D = 8
 };
 
 struct Job {
@@ -120,7 +121,9 @@ struct LaunchCfg {
 
 int launch_walker(const DevParams &p, const LaunchCfg &c, void *stream);
 int launch_demod_symbols(const DevParams &p, const float2 *iq, const int64_t *d_offsets, uint32_t n,
-                         int demod, uint32_t *d_bins, float *scratch, void *stream);
+                         int demod, uint32_t *d_bins, int32_t *d_fine, float *scratch, void *stream);
+uint32_t wave_tables_floats(uint32_t sf);                                  // 0 when the wave demodulator does not cover sf
+void build_wave_tables(uint32_t sf, const float2 *down, float *out);
 uint32_t walker_lds_bytes(const DevParams &p);
 uint32_t walker_resident_slots(const DevParams &p);
 

@@ -68,6 +68,7 @@ struct lora_hip_decoder {
     int device = 0;
     // device tables
     float2 *d_down = nullptr, *d_twN = nullptr, *d_tws = nullptr;
+    float *d_wave_tabs = nullptr;
     float *d_up_ifreq = nullptr, *d_down_ifreq = nullptr, *d_up_ifreq_v = nullptr;
     // per-pass buffers
     DevBuf<Job> d_jobs;
@@ -230,6 +231,13 @@ lora_hip_status build_tables(lora_hip_decoder *h)
     if ((s = upload(h, &h->d_down_ifreq, down_ifreq)) != LORA_HIP_OK) return s;
     if ((s = upload(h, &h->d_up_ifreq_v, up3)) != LORA_HIP_OK) return s;
     P.down = h->d_down; P.twN = h->d_twN; P.tws = h->d_tws;
+    P.wave_tabs = nullptr;
+    if (D == 8u && wave_tables_floats(c.sf) != 0u) { // packed twiddle block of the wave demodulator
+        std::vector<float> wt(wave_tables_floats(c.sf));
+        build_wave_tables(c.sf, down.data(), wt.data());
+        if ((s = upload(h, &h->d_wave_tabs, wt)) != LORA_HIP_OK) return s;
+        P.wave_tabs = h->d_wave_tabs;
+    }
     P.up_ifreq = h->d_up_ifreq; P.down_ifreq = h->d_down_ifreq; P.up_ifreq_v = h->d_up_ifreq_v;
     return LORA_HIP_OK;
 }
@@ -278,6 +286,12 @@ lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vec
         for (uint32_t j = 0; j < nj; j++) for (int i = 0; i < 6; i++) { cyc[i] += 64.0 * out.res[j].cyc[i]; rnd[i] += out.res[j].rounds[i]; }
         fprintf(stderr, "[lora_hip] per-job avg kcycles (rounds): DETECT %.0f (%.1f) SYNC %.0f (%.1f) SFD %.0f (%.1f) PAUSE %.0f (%.1f) HDR %.0f (%.1f) PAYLOAD %.0f (%.1f)\n",
                 cyc[0] / nj / 1e3, rnd[0] / nj, cyc[1] / nj / 1e3, rnd[1] / nj, cyc[2] / nj / 1e3, rnd[2] / nj, cyc[3] / nj / 1e3, rnd[3] / nj, cyc[4] / nj / 1e3, rnd[4] / nj, cyc[5] / nj / 1e3, rnd[5] / nj);
+        std::vector<double> tot(nj);
+        for (uint32_t j = 0; j < nj; j++) { double t = 0; for (int i = 0; i < 6; i++) t += 64.0 * out.res[j].cyc[i]; tot[j] = t; }
+        std::sort(tot.begin(), tot.end());
+        double mean = 0; for (double t : tot) mean += t; mean /= nj;
+        fprintf(stderr, "[lora_hip] job kcycles over %u jobs: min %.0f p50 %.0f p90 %.0f max %.0f mean %.0f\n", nj, tot[0] / 1e3, tot[nj / 2] / 1e3,
+                tot[(size_t)(nj * 0.9)] / 1e3, tot[nj - 1] / 1e3, mean / 1e3);
     }
     // copy back only the attempt records that were written
     uint32_t max_att = 0;
@@ -408,6 +422,7 @@ void lora_hip_destroy(lora_hip_decoder_t *h)
     if (h->d_down) (void)hipFree(h->d_down);
     if (h->d_twN) (void)hipFree(h->d_twN);
     if (h->d_tws) (void)hipFree(h->d_tws);
+    if (h->d_wave_tabs) (void)hipFree(h->d_wave_tabs);
     if (h->d_up_ifreq) (void)hipFree(h->d_up_ifreq);
     if (h->d_down_ifreq) (void)hipFree(h->d_down_ifreq);
     if (h->d_up_ifreq_v) (void)hipFree(h->d_up_ifreq_v);
@@ -536,9 +551,9 @@ lora_hip_status lora_hip_drain_frames(lora_hip_decoder_t *h, uint8_t *buf, size_
     return LORA_HIP_OK;
 }
 
-lora_hip_status lora_hip_demod_symbols_device(lora_hip_decoder_t *h, const void *d_iq, size_t total_items,
-                                              const int64_t *offsets, size_t n, int demod, uint32_t *bins_out,
-                                              void *hip_stream)
+lora_hip_status lora_hip_demod_symbols_ex_device(lora_hip_decoder_t *h, const void *d_iq, size_t total_items,
+                                                 const int64_t *offsets, size_t n, int demod, uint32_t *bins_out,
+                                                 int32_t *fine_out, void *hip_stream)
 {
     if (!h || !d_iq || (n && (!offsets || !bins_out)) || demod < 0 || demod > 2) return LORA_HIP_ERR_ARG;
     if (n == 0) return LORA_HIP_OK;
@@ -547,16 +562,28 @@ lora_hip_status lora_hip_demod_symbols_device(lora_hip_decoder_t *h, const void 
     hipStream_t st = (hipStream_t)hip_stream;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, h->d_offsets.reserve(n));
-    HIP_TRY(h, h->d_bins.reserve(n));
+    HIP_TRY(h, h->d_bins.reserve(2u * n)); // bins | fine
     const uint32_t grid = (uint32_t)std::min<size_t>(n, 2048);
     if (!h->P.ifreq_in_lds_1) HIP_TRY(h, h->d_scratch.reserve((size_t)grid * 2u * h->P.sps));
     HIP_TRY(h, hipMemcpyAsync(h->d_offsets.p, offsets, n * sizeof(int64_t), hipMemcpyHostToDevice, st));
-    if (launch_demod_symbols(h->P, (const float2 *)d_iq, h->d_offsets.p, (uint32_t)n, demod, h->d_bins.p,
+    int32_t *d_fine = fine_out ? reinterpret_cast<int32_t *>(h->d_bins.p + n) : nullptr;
+    DevParams P = h->P;
+    if (demod != 0) P.demod_mode = (uint32_t)demod; // FFT vs FFT_COMPAT decides the bin fine_sync is run with
+    if (launch_demod_symbols(P, (const float2 *)d_iq, h->d_offsets.p, (uint32_t)n, demod, h->d_bins.p, d_fine,
                              h->P.ifreq_in_lds_1 ? nullptr : h->d_scratch.p, st) != 0)
-        return fail(h, LORA_HIP_ERR_HIP, "demod launch failed: %s", hipGetErrorString(hipGetLastError()));
+        return fail(h, fine_out ? LORA_HIP_ERR_BAD_CONFIG : LORA_HIP_ERR_HIP, "demod launch failed (fine_sync output needs SF7/SF8 at decimation 8 and an FFT demodulator): %s",
+                    hipGetErrorString(hipGetLastError()));
     HIP_TRY(h, hipMemcpyAsync(bins_out, h->d_bins.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    if (fine_out) HIP_TRY(h, hipMemcpyAsync(fine_out, d_fine, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipStreamSynchronize(st));
     return LORA_HIP_OK;
+}
+
+lora_hip_status lora_hip_demod_symbols_device(lora_hip_decoder_t *h, const void *d_iq, size_t total_items,
+                                              const int64_t *offsets, size_t n, int demod, uint32_t *bins_out,
+                                              void *hip_stream)
+{
+    return lora_hip_demod_symbols_ex_device(h, d_iq, total_items, offsets, n, demod, bins_out, nullptr, hip_stream);
 }
 
 lora_hip_status lora_hip_last_timing(const lora_hip_decoder_t *h, lora_hip_timing_t *t)

@@ -61,10 +61,7 @@ struct alignas(16) W2Shared {
 
 struct W2Tabs {
     const float  *v;     // d_upchirp_ifreq_v (+ guard)
-    const float2 *down;  // d_downchirp
     const float  *dd;    // d_downchirp_ifreq[k] - chirp_avg
-    const float2 *tws;   // e^{-2 pi i m / sps}
-    const float2 *twN;   // e^{-2 pi i t / N}
     float        *scratch; // 72 floats per wavefront
 };
 
@@ -311,14 +308,12 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     W2Shared &W = *reinterpret_cast<W2Shared *>(smem);
     W2State &S = W.st;
     Shared &sh = W.sh;
-    // LDS carve-up after W2Shared: f2[2 sps] | v[3 sps + 40 (padded to 4)] | dd[sps] | down[sps] | tws[sps] | twN[N/2]
+    // LDS carve-up after W2Shared: f2[2 sps] | v[3 sps + 40 (padded to 4)] | dd[sps] | twiddle block of the wave demodulator
     float *f2 = reinterpret_cast<float *>(smem + ((sizeof(W2Shared) + 15) & ~(size_t)15));
     float *vl = f2 + 2 * SPS;
     constexpr uint32_t NV = (3u * SPS + 40u + 3u) & ~3u;
     float *ddl = vl + NV;
-    float2 *downl = reinterpret_cast<float2 *>(ddl + SPS);
-    float2 *twsl = downl + SPS;
-    float2 *twnl = twsl + SPS;
+    v4f *tab4 = reinterpret_cast<v4f *>(ddl + SPS);
 
     const uint32_t jid = blockIdx.x;
     if (jid >= C.n_jobs) return;
@@ -331,13 +326,8 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     const bool is_ctl = wave == kW2Workers;                 // control wavefront
     const bool t0 = threadIdx.x == kW2Workers * 64;         // the control thread: sole owner of the decoder state S
 
-    for (uint32_t i = threadIdx.x; i < 3u * SPS + 40u; i += kW2) vl[i] = P.up_ifreq_v[i];
-    for (uint32_t i = threadIdx.x; i < sps; i += kW2) {
-        ddl[i] = P.down_ifreq[i] - P.down_ifreq_avg;
-        downl[i] = P.down[i];
-        twsl[i] = P.tws[i];
-    }
-    for (uint32_t i = threadIdx.x; i < (uint32_t)N / 2u; i += kW2) twnl[i] = P.twN[i];
+    const WaveTabs FT = wave_tabs_to_lds<SF>(P, tab4, vl, kW2);
+    for (uint32_t i = threadIdx.x; i < sps; i += kW2) ddl[i] = P.down_ifreq[i] - P.down_ifreq_avg;
 
     // plan for the next round from the TRUE state (control thread only)
     auto plan_from_state = [&](W2Plan &pl) {
@@ -363,8 +353,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         W.stats.prev_state = -1;
         plan_from_state(W.plan[0]);
     }
-    W2Tabs T{vl, downl, ddl, twsl, twnl, W.red};
-    FastTabs FT{vl, twsl, twnl, downl};
+    W2Tabs T{vl, ddl, W.red};
 
     for (uint32_t it = 0;; it++) {
         __syncthreads(); // plan[it & 1] and everything the control thread wrote are visible; plan[(it+1) & 1] is free
@@ -544,7 +533,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         if (!is_ctl) {
             uint32_t ws = 0;
             int32_t wfine = 0;
-            if (wvalid) fast_demod_symbol<SF>(P, FT, X + wpos, ws, wfine);
+            if (wvalid) wave_demod_symbol<SF, SF == 7>(P, FT, X + wpos, ws, wfine);
             if (lane == 0) { W.speci[plan.buf][wave][0] = wvalid ? (int32_t)ws : -1; W.speci[plan.buf][wave][1] = wfine; }
         } else if (t0) {
             bool predicted = true;
@@ -611,6 +600,7 @@ static uint32_t walker2_lds_bytes(uint32_t sf)
 {
     const uint32_t sps = 8u << sf, n = 1u << sf;
     const uint32_t nv = (3u * sps + 40u + 3u) & ~3u;
+    (void)n;
     return (uint32_t)((sizeof(W2Shared) + 15) & ~(size_t)15) + (2u * sps + nv + sps) * (uint32_t)sizeof(float) +
-           (2u * sps + n / 2u) * (uint32_t)sizeof(float2);
+           wave_tables_floats(sf) * (uint32_t)sizeof(float);
 }

@@ -1,0 +1,390 @@
+// lora_wave_demod.inc.hip -- one wavefront demodulates one symbol (decimation 8: SF7 / SF8 at 1 Msps / 125 kHz).
+// Included by lora_kernels.hip.
+//
+// get_shift_fft (lib/decoder_impl.cc:430-464) + the per-symbol fine_sync (:300-338, :514-518) for the
+// decode rounds of walker2 and for lora_hip_demod_symbols_device.  Written for the VALU, which is what
+// bounds the walker: complex arithmetic in packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, two
+// flops per lane per instruction), lane exchanges as single DPP moves (bound_ctrl: no `old` operand to
+// materialise) or v_permlane{16,32}_swap, every twiddle a 16-byte LDS entry (w.x, w.y, -w.y, w.x) so that a
+// complex multiply is two packed instructions: a*w = a.xx*(w.x,w.y) + a.yy*(-w.y,w.x).
+//
+// Work split.  sps = 8 N samples, lane = 8 r + p, p = lane & 7.  The 8 lanes of a group hold polyphase
+// branch r (samples n = 8 q + r); inside the group the LOGICAL index is lq = p ^ (p >= 4 ? 3 : 0), which
+// makes the first cross-lane butterfly (lq ^ 4) a row_half_mirror DPP and leaves the other two on quad_perm.
+// Lane (r, lq) owns q = 8 j + lq, j < J = N / 8, i.e. n = 64 j + 8 lq + r.
+//   1. dechirp, J-point DIF in registers (output k1 = bitrev(m))
+//   2. twiddle W_N^{lq k1}, 8-point DIF across the group (output k2 = bitrev3(lq)): Y_r[k1 + J k2]
+//   3. polyphase combine with W_sps^{k r} (k = signed bin; the reference's fold tmp[N/2] += F[N/2], :450, is
+//      part of the table) and a reduce-scatter over r: lane bits 5, 4 (permlane swaps), 3 (DPP)
+//   4. |X|^2 arg-max, first maximum in bin order (:454-463)
+//   5. fine_sync over lags -1, 0, +1 against the ifreq template; the window's instantaneous frequency is
+//      computed from the registers that were loaded for the dechirp (EARLY_F) or from a second, cache-hot
+//      read after the FFT (SF8, where 32 more live registers would spill).
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int kDppQuadXor1 = 0xB1, kDppQuadXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140, kDppRor8 = 0x128,
+              kDppBcast15 = 0x142, kDppBcast31 = 0x143;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v)
+{ // every lane reads a valid lane: bound_ctrl = true lets the compiler fold the move into the consumer
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ v2f dpp2(v2f v)
+{
+    const float x = v.x, y = v.y; // (bit_cast on a vector element reads element 0 with this compiler: go through scalars)
+    v2f r;
+    r.x = dpp_f<CTRL>(x);
+    r.y = dpp_f<CTRL>(y);
+    return r;
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_rows_f(float old, float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, false));
+}
+
+// sums / maxima over the wavefront, result uniform (SGPR): 4 DPP steps inside the 16-lane rows, 2 row broadcasts
+__device__ __forceinline__ float wave_sum_u(float v)
+{
+    v += dpp_f<kDppQuadXor1>(v); v += dpp_f<kDppQuadXor2>(v); v += dpp_f<kDppHalfMirror>(v); v += dpp_f<kDppMirror>(v);
+    v += dpp_rows_f<kDppBcast15, 0xa>(0.0f, v);
+    v += dpp_rows_f<kDppBcast31, 0xc>(0.0f, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_max_nonneg_u(float v)
+{
+    v = fmaxf(v, dpp_f<kDppQuadXor1>(v)); v = fmaxf(v, dpp_f<kDppQuadXor2>(v));
+    v = fmaxf(v, dpp_f<kDppHalfMirror>(v)); v = fmaxf(v, dpp_f<kDppMirror>(v));
+    v = fmaxf(v, dpp_rows_f<kDppBcast15, 0xa>(0.0f, v));
+    v = fmaxf(v, dpp_rows_f<kDppBcast31, 0xc>(0.0f, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ int wave_min_u(int v)
+{
+#define LORA_MIN_STEP(CTRL) v = min(v, __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true))
+    LORA_MIN_STEP(kDppQuadXor1); LORA_MIN_STEP(kDppQuadXor2); LORA_MIN_STEP(kDppHalfMirror); LORA_MIN_STEP(kDppMirror);
+#undef LORA_MIN_STEP
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, kDppBcast15, 0xa, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, kDppBcast31, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// a * w with the twiddle given as (w, wr = (-w.y, w.x)): two packed instructions
+__device__ __forceinline__ v2f cmulw(v2f a, v2f w, v2f wr) { return __builtin_elementwise_fma(a.xx, w, a.yy * wr); }
+__device__ __forceinline__ v2f cmulw(v2f a, v4f t) { return cmulw(a, t.xy, t.zw); }
+
+// in-register radix-2 DIF, natural input order, bit-reversed output
+template <int J>
+__device__ __forceinline__ void fft_inlane_dif_pk(v2f (&a)[J])
+{
+#pragma unroll
+    for (int h = J / 2; h >= 1; h >>= 1) {
+#pragma unroll
+        for (int b = 0; b < J / 2; b++) {
+            const int off = b % h, blk = b / h;
+            const int i0 = blk * 2 * h + off, i1 = i0 + h;
+            const int tw = off * (J / 2 / h); // W_J^tw
+            const v2f u = a[i0], v = a[i1];
+            a[i0] = u + v;
+            const v2f d = u - v;
+            if (tw == 0) a[i1] = d;
+            else if (tw == J / 4) a[i1] = d.yx * (v2f){1.0f, -1.0f}; // * (-i)
+            else {
+                const float c = kW64c[tw * (64 / J)], s = kW64s[tw * (64 / J)];
+                a[i1] = cmulw(d, (v2f){c, s}, (v2f){-s, c});
+            }
+        }
+    }
+}
+
+// one DIF butterfly stage across lanes: a' = (sg * a + partner) * w   (upper lane: sg = +1, w = 1; lower: sg = -1)
+template <int CTRL, int J>
+__device__ __forceinline__ void xstage_pk(v2f (&a)[J], v2f sg, v4f w)
+{
+#pragma unroll
+    for (int m = 0; m < J; m++) {
+        const v2f p = dpp2<CTRL>(a[m]);
+        a[m] = cmulw(__builtin_elementwise_fma(sg, a[m], p), w);
+    }
+}
+template <int CTRL, int J>
+__device__ __forceinline__ void xstage_last_pk(v2f (&a)[J], v2f sg)
+{
+#pragma unroll
+    for (int m = 0; m < J; m++) a[m] = __builtin_elementwise_fma(sg, a[m], dpp2<CTRL>(a[m]));
+}
+
+// LDS-resident tables of the wave demodulator (built by build_wave_tables below, copied in by the kernels)
+struct WaveTabs {
+    const v4f   *down4; // [sps]      d_downchirp[n] as (d, i d)
+    const v4f   *twn4;  // [J][8]     W_N^{lq * bitrev(m)}
+    const v4f   *tws4;  // [J][64]    polyphase twiddle of register m on each lane (incl. the N/2 fold)
+    const v4f   *xst4;  // [2][64]    lane twiddles of the first two cross-lane stages
+    const float *v;     // d_upchirp_ifreq_v (+ guard)
+};
+
+template <int SF> struct WaveGeom {
+    static constexpr int N = 1 << SF, J = N / 8, SPS = 8 * N, LOGJ = ilog2(J);
+    static constexpr uint32_t n_down4 = SPS, n_twn4 = J * 8, n_tws4 = J * 64, n_xst4 = 2 * 64;
+    static constexpr uint32_t n_v4f = n_down4 + n_twn4 + n_tws4 + n_xst4; // v4f entries of the packed table block
+};
+
+__device__ __host__ constexpr int wave_lq_of(int lane) { return (lane & 7) ^ ((lane & 4) ? 3 : 0); }
+
+// atan2 of two points at once where it pays (the polynomial); see lean_atan2 for the accuracy statement
+__device__ __forceinline__ v2f lean_atan2_pk(v2f y, v2f x)
+{
+    const float ax0 = fabsf(x.x), ay0 = fabsf(y.x), ax1 = fabsf(x.y), ay1 = fabsf(y.y);
+    const float mx0 = fmaxf(fmaxf(ax0, ay0), 1.0e-37f), mx1 = fmaxf(fmaxf(ax1, ay1), 1.0e-37f); // atan2(0, 0) = 0
+    v2f a;
+    a.x = fminf(ax0, ay0) * __builtin_amdgcn_rcpf(mx0);
+    a.y = fminf(ax1, ay1) * __builtin_amdgcn_rcpf(mx1);
+    const v2f s = a * a;
+    v2f p = (v2f){-0.0040545230731368065f, -0.0040545230731368065f};
+    p = __builtin_elementwise_fma(p, s, (v2f){0.02186279185116291f, 0.02186279185116291f});
+    p = __builtin_elementwise_fma(p, s, (v2f){-0.0559120774269104f, -0.0559120774269104f});
+    p = __builtin_elementwise_fma(p, s, (v2f){0.09642177820205688f, 0.09642177820205688f});
+    p = __builtin_elementwise_fma(p, s, (v2f){-0.13908621668815613f, -0.13908621668815613f});
+    p = __builtin_elementwise_fma(p, s, (v2f){0.19946564733982086f, 0.19946564733982086f});
+    p = __builtin_elementwise_fma(p, s, (v2f){-0.33329859375953674f, -0.33329859375953674f});
+    p = __builtin_elementwise_fma(p, s, (v2f){0.9999993443489075f, 0.9999993443489075f});
+    const v2f r = a * p;
+    float r0 = r.x, r1 = r.y;
+    r0 = (ay0 > ax0) ? 1.57079632679489662f - r0 : r0;
+    r1 = (ay1 > ax1) ? 1.57079632679489662f - r1 : r1;
+    r0 = (x.x < 0.0f) ? 3.14159265358979324f - r0 : r0;
+    r1 = (x.y < 0.0f) ? 3.14159265358979324f - r1 : r1;
+    return (v2f){copysignf(r0, y.x), copysignf(r1, y.y)};
+}
+
+// instantaneous frequency (:231-240) of two adjacent-sample pairs: arg(cur * conj(prev))
+__device__ __forceinline__ v2f ifreq_prod_pk(v2f p0, v2f c0, v2f p1, v2f c1)
+{
+    const v2f im = (v2f){c0.y * p0.x - c0.x * p0.y, c1.y * p1.x - c1.x * p1.y};
+    const v2f re = (v2f){c0.x * p0.x + c0.y * p0.y, c1.x * p1.x + c1.y * p1.y};
+    return lean_atan2_pk(im, re);
+}
+
+// Demodulates the symbol window x[0 .. sps): s_out = get_shift_fft's return value, fine_out = d_fine_sync after
+// fine_sync(bin_idx, 2) (0 when drift correction is disabled).  Must be called by a whole wavefront.
+template <int SF, bool EARLY_F>
+__device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const WaveTabs &T, const float2 *__restrict__ x, uint32_t &s_out, int32_t &fine_out)
+{
+    using G = WaveGeom<SF>;
+    constexpr int N = G::N, J = G::J, SPS = G::SPS, LOGJ = G::LOGJ;
+    int lane = threadIdx.x & 63;
+    // opaque to the optimiser: keeps the per-lane table addresses from being hoisted out of the caller's
+    // state-machine loop (that costs ~100 VGPRs of loop-invariant addresses)
+    asm volatile("" : "+v"(lane));
+    const int lq = wave_lq_of(lane), r = lane >> 3;
+    const int nl = 8 * lq + r;
+    const bool want_fine = P.enable_fine_sync != 0u;
+    const v2f *__restrict__ xv = reinterpret_cast<const v2f *>(x);
+
+    v2f a[J];
+    float f[J]; // ifreq[n - 1] of this lane's samples
+#pragma unroll
+    for (int j = 0; j < J; j++) a[j] = xv[j * 64 + nl];
+    if (EARLY_F && want_fine) {
+#pragma unroll
+        for (int j = 0; j < J; j += 2) {
+            const int n0 = j * 64 + nl, n1 = n0 + 64;
+            const v2f fp = ifreq_prod_pk(xv[n0 >= 1 ? n0 - 1 : 0], a[j], xv[n1 - 1], a[j + 1]);
+            f[j] = (n0 >= 1) ? fp.x : 0.0f;
+            f[j + 1] = fp.y;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < J; j++) a[j] = cmulw(a[j], T.down4[j * 64 + nl]); // dechirp (:437)
+    fft_inlane_dif_pk<J>(a);
+#pragma unroll
+    for (int m = 1; m < J; m++) a[m] = cmulw(a[m], T.twn4[m * 8 + lq]); // W_N^{lq k1}
+    { // 8-point DIF across the group
+        const v2f sg1 = (lq & 4) ? (v2f){-1.f, -1.f} : (v2f){1.f, 1.f};
+        const v2f sg2 = (lq & 2) ? (v2f){-1.f, -1.f} : (v2f){1.f, 1.f};
+        const v2f sg3 = (lq & 1) ? (v2f){-1.f, -1.f} : (v2f){1.f, 1.f};
+        xstage_pk<kDppHalfMirror, J>(a, sg1, T.xst4[lane]);
+        xstage_pk<kDppQuadXor2, J>(a, sg2, T.xst4[64 + lane]);
+        xstage_last_pk<kDppQuadXor1, J>(a, sg3);
+    }
+#pragma unroll
+    for (int m = 0; m < J; m++) a[m] = cmulw(a[m], T.tws4[m * 64 + lane]); // W_sps^{k r} (+ fold)
+    // reduce-scatter over r: lanes with the bit clear keep the first half of the registers
+    v2f b4[J / 2], b2[J / 4], b1[J / 8];
+#pragma unroll
+    for (int i = 0; i < J / 2; i++) { // lane bit 5: v_permlane32_swap leaves own+partner halves side by side
+        const float lx = a[i].x, ly = a[i].y, hx = a[i + J / 2].x, hy = a[i + J / 2].y;
+        const auto sx = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(int, lx), __builtin_bit_cast(int, hx), false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(int, ly), __builtin_bit_cast(int, hy), false, false);
+        const int x0 = sx[0], x1 = sx[1], y0 = sy[0], y1 = sy[1]; // scalars first: bit_cast on a vector element is miscompiled
+        b4[i] = (v2f){__builtin_bit_cast(float, x0), __builtin_bit_cast(float, y0)} + (v2f){__builtin_bit_cast(float, x1), __builtin_bit_cast(float, y1)};
+    }
+#pragma unroll
+    for (int i = 0; i < J / 4; i++) { // lane bit 4
+        const float lx = b4[i].x, ly = b4[i].y, hx = b4[i + J / 4].x, hy = b4[i + J / 4].y;
+        const auto sx = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(int, lx), __builtin_bit_cast(int, hx), false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(int, ly), __builtin_bit_cast(int, hy), false, false);
+        const int x0 = sx[0], x1 = sx[1], y0 = sy[0], y1 = sy[1]; // scalars first: bit_cast on a vector element is miscompiled
+        b2[i] = (v2f){__builtin_bit_cast(float, x0), __builtin_bit_cast(float, y0)} + (v2f){__builtin_bit_cast(float, x1), __builtin_bit_cast(float, y1)};
+    }
+    {
+        const bool hi = (lane & 8) != 0; // lane bit 3: row_ror:8
+#pragma unroll
+        for (int i = 0; i < J / 8; i++) {
+            const v2f t0 = b2[i] + dpp2<kDppRor8>(b2[i]);
+            const v2f t1 = b2[i + J / 8] + dpp2<kDppRor8>(b2[i + J / 8]);
+            b1[i] = hi ? t1 : t0;
+        }
+    }
+    // late ifreq: second read of the window, pinned behind the reduce-scatter so that the loads are not
+    // hoisted above the FFT (where they would hold 4 J more registers)
+    if (!EARLY_F && want_fine) {
+        int zero = 0;
+        asm volatile("; fine-sync reload after the reduce-scatter" : "+v"(zero) : "v"(b1[0].x));
+        const int nl2 = nl + zero;
+#pragma unroll
+        for (int j = 0; j < J; j += 2) {
+            const int n0 = j * 64 + nl2, n1 = n0 + 64;
+            const v2f fp = ifreq_prod_pk(xv[n0 >= 1 ? n0 - 1 : 0], xv[n0], xv[n1 - 1], xv[n1]);
+            f[j] = (n0 >= 1) ? fp.x : 0.0f;
+            f[j + 1] = fp.y;
+        }
+    }
+    // arg-max on |X|^2 (monotone in the reference's std::abs, :454), first maximum in bin order wins (:463)
+    const int mbase = ((lane & 32) ? J / 2 : 0) + ((lane & 16) ? J / 4 : 0) + ((lane & 8) ? J / 8 : 0);
+    const int k2 = ((lq & 1) << 2) | (lq & 2) | ((lq >> 2) & 1);
+    float bv = -1.0f;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < J / 8; i++) {
+        const int m = mbase + i;
+        const int k1 = (int)(__brev((uint32_t)m) >> (32 - LOGJ));
+        const int jb = k1 + J * k2;
+        const float mag = b1[i].x * b1[i].x + b1[i].y * b1[i].y;
+        if (mag > bv || (mag == bv && jb < bi)) { bv = mag; bi = jb; }
+    }
+    const float best = wave_max_nonneg_u(bv);
+    const uint32_t s = (uint32_t)wave_min_u(bv == best ? bi : 0x7fffffff);
+    s_out = s;
+    fine_out = 0;
+    if (!want_fine) return;
+    // fine_sync (:300-338) with search = max(D/4, 2) = 2 -> lags -1, 0, +1
+    const uint32_t bin_idx = (s == 0u && P.demod_mode == 2u) ? 0u : (s + (uint32_t)N - 1u) % (uint32_t)N;
+    const float *__restrict__ v = T.v + ((int)(bin_idx + 1u) * 8 + SPS);
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const int n = j * 64 + nl;
+        const int k = (n >= 1) ? n - 1 : 1; // f[j] is 0 for the non-existent k = -1
+        const float fj = f[j];
+        c0 += fj * v[k - 1]; c1 += fj * v[k]; c2 += fj * v[k + 1];
+        if (j == J - 1) { // ifreq[sps-1] = ifreq[sps-2] (:243): the lane that owns n = sps-1 adds the duplicated tap
+            const float fl = (nl == 63) ? fj : 0.0f;
+            c0 += fl * v[k]; c1 += fl * v[k + 1]; c2 += fl * v[k + 2];
+        }
+    }
+    c0 = wave_sum_u(c0); c1 = wave_sum_u(c1); c2 = wave_sum_u(c2);
+    float mx = 0.0f;
+    int32_t lag = 0;
+    if (c0 > mx) { mx = c0; lag = -1; }
+    if (c1 > mx) { mx = c1; lag = 0; }
+    if (c2 > mx) { mx = c2; lag = 1; }
+    fine_out = -lag;
+}
+
+// copies the packed table block (down4 | twn4 | tws4 | xst4) and the ifreq template into LDS; all threads of the block
+template <int SF>
+__device__ __forceinline__ WaveTabs wave_tabs_to_lds(const DevParams &P, v4f *lds4, float *lds_v, uint32_t nthreads)
+{
+    using G = WaveGeom<SF>;
+    const v4f *__restrict__ src = reinterpret_cast<const v4f *>(P.wave_tabs);
+    for (uint32_t i = threadIdx.x; i < G::n_v4f; i += nthreads) lds4[i] = src[i];
+    for (uint32_t i = threadIdx.x; i < 3u * G::SPS + 40u; i += nthreads) lds_v[i] = P.up_ifreq_v[i];
+    WaveTabs T;
+    T.down4 = lds4; T.twn4 = lds4 + G::n_down4; T.tws4 = T.twn4 + G::n_twn4; T.xst4 = T.tws4 + G::n_tws4; T.v = lds_v;
+    return T;
+}
+
+// host side: the table block in the layout above, from the handle's downchirp
+static void build_wave_tables_host(uint32_t sf, const float2 *down, float *out /* 4 * n_v4f floats */)
+{
+    const int N = 1 << sf, J = N / 8, SPS = 8 * N;
+    int logj = 0;
+    while ((1 << logj) < J) logj++;
+    auto put = [&](size_t idx, double re, double im) {
+        const float c = (float)re, s = (float)im;
+        out[4 * idx + 0] = c; out[4 * idx + 1] = s; out[4 * idx + 2] = -s; out[4 * idx + 3] = c;
+    };
+    size_t o = 0;
+    for (int n = 0; n < SPS; n++) { out[4 * o + 0] = down[n].x; out[4 * o + 1] = down[n].y; out[4 * o + 2] = -down[n].y; out[4 * o + 3] = down[n].x; o++; }
+    for (int m = 0; m < J; m++)
+        for (int lq = 0; lq < 8; lq++) {
+            const int k1 = brev_bits(m, logj);
+            const int t = (lq * k1) % N;
+            const double a = -2.0 * M_PI * (double)t / (double)N;
+            put(o++, std::cos(a), std::sin(a));
+        }
+    for (int m = 0; m < J; m++)
+        for (int lane = 0; lane < 64; lane++) {
+            const int lq = wave_lq_of(lane), r = lane >> 3;
+            const int k2 = ((lq & 1) << 2) | (lq & 2) | ((lq >> 2) & 1);
+            const int k1 = brev_bits(m, logj);
+            const int jb = k1 + J * k2;
+            const int k = (jb < N / 2) ? jb : jb - N;
+            const int e = ((k * r) % SPS + SPS) % SPS;
+            const double ang = -2.0 * M_PI * (double)e / (double)SPS;
+            double re = std::cos(ang), im = std::sin(ang);
+            if (jb == N / 2) { // tmp[N/2] += F[N/2] (:450)
+                const int e2 = ((N / 2) * r) % SPS;
+                const double a2 = -2.0 * M_PI * (double)e2 / (double)SPS;
+                re += std::cos(a2); im += std::sin(a2);
+            }
+            put(o++, re, im);
+        }
+    const double rs = 0.70710678118654752440;
+    for (int lane = 0; lane < 64; lane++) { // stage 1: lower lanes (lq >= 4) multiply by W_8^{lq & 3}
+        const int lq = wave_lq_of(lane), t1 = lq & 3;
+        if (!(lq & 4) || t1 == 0) put(o++, 1.0, 0.0);
+        else if (t1 == 1) put(o++, rs, -rs);
+        else if (t1 == 2) put(o++, 0.0, -1.0);
+        else put(o++, -rs, -rs);
+    }
+    for (int lane = 0; lane < 64; lane++) { // stage 2: lower lanes (lq & 2) multiply by W_4^{lq & 1}
+        const int lq = wave_lq_of(lane);
+        if ((lq & 2) && (lq & 1)) put(o++, 0.0, -1.0);
+        else put(o++, 1.0, 0.0);
+    }
+}
+
+uint32_t wave_tables_floats(uint32_t sf) { return sf == 7u ? 4u * WaveGeom<7>::n_v4f : (sf == 8u ? 4u * WaveGeom<8>::n_v4f : 0u); }
+void build_wave_tables(uint32_t sf, const float2 *down, float *out) { build_wave_tables_host(sf, down, out); }
+
+// ---- symbol-level kernel: one wavefront per symbol, for lora_hip_demod_symbols_device ------------------
+template <int SF>
+__global__ __launch_bounds__(256) void demod_symbols_wave_kernel(DevParams P, const float2 *iq, const int64_t *offsets, uint32_t n,
+                                                                 uint32_t *bins, int32_t *fine)
+{
+    using G = WaveGeom<SF>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    v4f *lds4 = reinterpret_cast<v4f *>(smem);
+    float *lds_v = reinterpret_cast<float *>(lds4 + G::n_v4f);
+    const WaveTabs T = wave_tabs_to_lds<SF>(P, lds4, lds_v, 256u);
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6;
+    for (uint32_t s = blockIdx.x * 4u + wave; s < n; s += gridDim.x * 4u) {
+        uint32_t b;
+        int32_t fs;
+        wave_demod_symbol<SF, SF == 7>(P, T, iq + offsets[s], b, fs);
+        if ((threadIdx.x & 63u) == 0u) { bins[s] = b; if (fine) fine[s] = fs; }
+    }
+}
+
+static uint32_t wave_tabs_lds_bytes(uint32_t sf)
+{
+    const uint32_t sps = 8u << sf;
+    return wave_tables_floats(sf) * (uint32_t)sizeof(float) + ((3u * sps + 40u + 3u) & ~3u) * (uint32_t)sizeof(float);
+}

@@ -153,6 +153,13 @@ lora_hip_status lora_hip_demod_symbols_device(lora_hip_decoder_t *h, const void 
                                               const int64_t *offsets, size_t n, int demod,
                                               uint32_t *bins_out, void *hip_stream);
 
+/* Same, and additionally fine_out[i] = d_fine_sync after fine_sync(bin_idx, max(D/4, 2)) on that window
+ * (decoder_impl.cc:300-338, called from demodulate() :514-518).  fine_out may be NULL; non-NULL needs the
+ * wave-per-symbol demodulator (SF7 / SF8 at decimation 8, demod FFT or FFT_COMPAT), else BAD_CONFIG.        */
+lora_hip_status lora_hip_demod_symbols_ex_device(lora_hip_decoder_t *h, const void *d_iq, size_t total_items,
+                                                 const int64_t *offsets, size_t n, int demod,
+                                                 uint32_t *bins_out, int32_t *fine_out, void *hip_stream);
+
 /* ---- introspection --------------------------------------------------------------------------------------- */
 lora_hip_status lora_hip_last_timing(const lora_hip_decoder_t *h, lora_hip_timing_t *t);
 size_t          lora_hip_trace(const lora_hip_decoder_t *h, const lora_hip_step_t **steps);

@@ -129,6 +129,53 @@ def test_symbol_bins_exact_and_awgn(torch_cuda, oracle_mod):
         h.close()
 
 
+@pytest.mark.parametrize("sf", [7, 8])
+def test_wave_demod_shift_and_fine_sync_vs_oracle(torch_cuda, oracle_mod, sf):
+    """The wave-per-symbol demodulator (the walker's decode rounds) on its own: shift and d_fine_sync per
+    window against get_shift_fft / fine_sync of the oracle -- clean symbols, windows cut a few samples
+    early/late (fine_sync = -+1), and AWGN (shift within +-1 bin; where the shift agrees, fine_sync too)."""
+    from gr_lora_amd import capi
+    cfg = synth.TxConfig(sf=sf)
+    rng = np.random.default_rng(100 + sf)
+    up = synth.base_upchirp(cfg)
+    n_sym = 96
+    shifts = rng.integers(0, cfg.nbins, n_sym)
+    shifts[:4] = [0, 1, cfg.nbins - 1, cfg.nbins // 2]
+    ar = np.arange(cfg.sps)
+    # every symbol twice in a row so that a window cut early/late still sees the same chirp around its edges
+    iq = np.concatenate([np.tile(up[(ar + s * cfg.decim) % cfg.sps], 3) for s in shifts]).astype(np.complex64)
+    slip = rng.integers(-3, 4, n_sym)
+    slip[:8] = [0, 0, 0, 0, 1, -1, 2, -2]
+    offs = np.arange(n_sym) * 3 * cfg.sps + cfg.sps + slip
+    o = oracle_mod.Oracle(sf=sf)
+    for mode in (1, 2):
+        h = capi.Handle(sf=sf, demod=mode)
+        for sigma in (0.0, synth.awgn_sigma_for_snr(-3.0, cfg)):
+            x = iq
+            if sigma:
+                x = (iq + (rng.standard_normal(iq.size) + 1j * rng.standard_normal(iq.size)).astype(np.complex64) * np.float32(sigma / np.sqrt(2))).astype(np.complex64)
+            dev = _to_dev(torch_cuda, x)
+            g, gf = h.demod_symbols_ex_device(dev.data_ptr(), x.size, offs, mode)
+            w = o.demod_at(x, offs, 1).astype(np.int64)
+            d = np.abs(g.astype(np.int64) - w)
+            d = np.minimum(d, cfg.nbins - d)
+            if sigma == 0.0:
+                assert g.tolist() == w.tolist()
+            else:
+                assert d.max() <= 1 and (d == 0).mean() > 0.9
+            n_nonzero = 0
+            for i in range(n_sym):
+                if d[i] != 0:
+                    continue
+                sres = int(w[i])
+                bin_idx = 0 if (sres == 0 and mode == 2) else (sres + cfg.nbins - 1) % cfg.nbins
+                wf = o.fine_sync(x[offs[i]:offs[i] + cfg.sps], bin_idx, 2)
+                assert int(gf[i]) == wf, (sf, mode, sigma, i, sres, int(gf[i]), wf)
+                n_nonzero += wf != 0
+            assert n_nonzero > 10 # the slipped windows exercise lags -1 and +1
+        h.close()
+
+
 def test_streaming_chunks_equal_batch(torch_cuda, oracle_mod):
     """lora_hip_work() with arbitrary chunking publishes the same frames (decoder_impl::work contract)."""
     from gr_lora_amd import capi
