@@ -8,18 +8,27 @@
 // materialise) or v_permlane{16,32}_swap, every twiddle a 16-byte LDS entry (w.x, w.y, -w.y, w.x) so that a
 // complex multiply is two packed instructions: a*w = a.xx*(w.x,w.y) + a.yy*(-w.y,w.x).
 //
-// Work split.  sps = 8 N samples, lane = 8 r + p, p = lane & 7.  The 8 lanes of a group hold polyphase
-// branch r (samples n = 8 q + r); inside the group the LOGICAL index is lq = p ^ (p >= 4 ? 3 : 0), which
-// makes the first cross-lane butterfly (lq ^ 4) a row_half_mirror DPP and leaves the other two on quad_perm.
-// Lane (r, lq) owns q = 8 j + lq, j < J = N / 8, i.e. n = 64 j + 8 lq + r.
+// Work split.  sps = 8 N samples, lane = 8 lq + r.  A lane owns the samples n = 64 j + lane, j < J = N / 8:
+// every load instruction covers 512 contiguous bytes (the earlier layout with the 8 lanes of a polyphase
+// branch adjacent cost one L1 access per LANE and made the texture path, not the VALU, the bound).  In terms
+// of the polyphase split n = 8 q + r, q = 8 j + lq: lane bits 0-2 are the branch r, bits 3-5 are lq.
 //   1. dechirp, J-point DIF in registers (output k1 = bitrev(m))
-//   2. twiddle W_N^{lq k1}, 8-point DIF across the group (output k2 = bitrev3(lq)): Y_r[k1 + J k2]
+//   2. twiddle W_N^{lq k1}, 8-point DIF over lq = lane bits 5, 4, 3.  Bits 5 and 4 use v_permlane{32,16}_swap
+//      as a TRANSPOSE: swapping registers (i, i + J/2) leaves each lane with both inputs of one butterfly
+//      (in_low, in_high), so sum and twiddled difference are computed in the lane, without sign selects;
+//      afterwards the lane bit says which element the lane holds and the register slot carries the lq bit.
+//      Bit 3 is a DPP row_ror:8 butterfly.  Result: Y_r[k1 + J k2] for the (register, lane) layout that
+//      wave_layout_bin() below describes; the host builds the polyphase table from the same function.
 //   3. polyphase combine with W_sps^{k r} (k = signed bin; the reference's fold tmp[N/2] += F[N/2], :450, is
-//      part of the table) and a reduce-scatter over r: lane bits 5, 4 (permlane swaps), 3 (DPP)
+//      part of the table) and a reduce-scatter over r = lane bits 2 (row_shl/shr:4 with bank masks), 1, 0
 //   4. |X|^2 arg-max, first maximum in bin order (:454-463)
 //   5. fine_sync over lags -1, 0, +1 against the ifreq template; the window's instantaneous frequency is
 //      computed from the registers that were loaded for the dechirp (EARLY_F) or from a second, cache-hot
 //      read after the FFT (SF8, where 32 more live registers would spill).
+//
+// Instruction costs this is written against (tools/ubench_valu.hip, cycles per wave64 instruction per SIMD):
+// v_fma/mul/add_f32 2.4-3.0, v_pk_{fma,mul,add}_f32 4.3, DPP moves and v_*_dpp 4.3, v_cndmask/v_cmp/v_max 4.3,
+// v_rcp_f32 and v_permlane*_swap 8.2.
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -45,6 +54,12 @@ template <int CTRL, int ROWMASK>
 __device__ __forceinline__ float dpp_rows_f(float old, float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, false));
+}
+
+template <int CTRL, int BANKMASK>
+__device__ __forceinline__ float dpp_rows_bank_f(float old, float v)
+{ // lanes of the enabled banks read `v` through the DPP pattern, the others keep `old`
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, 0xf, BANKMASK, false));
 }
 
 // sums / maxima over the wavefront, result uniform (SGPR): 4 DPP steps inside the 16-lane rows, 2 row broadcasts
@@ -76,6 +91,11 @@ __device__ __forceinline__ int wave_min_u(int v)
 // a * w with the twiddle given as (w, wr = (-w.y, w.x)): two packed instructions
 __device__ __forceinline__ v2f cmulw(v2f a, v2f w, v2f wr) { return __builtin_elementwise_fma(a.xx, w, a.yy * wr); }
 __device__ __forceinline__ v2f cmulw(v2f a, v4f t) { return cmulw(a, t.xy, t.zw); }
+#ifdef LORA_WD_NO_LDS // experiment (tools/probe_phases.hip): twiddles from registers instead of LDS
+#define LORA_WD_TAB(expr, lane) ((v4f){1.0f, 0.001f * (float)(lane), -0.001f * (float)(lane), 1.0f})
+#else
+#define LORA_WD_TAB(expr, lane) (expr)
+#endif
 
 // in-register radix-2 DIF, natural input order, bit-reversed output
 template <int J>
@@ -133,7 +153,17 @@ template <int SF> struct WaveGeom {
     static constexpr uint32_t n_v4f = n_down4 + n_twn4 + n_tws4 + n_xst4; // v4f entries of the packed table block
 };
 
-__device__ __host__ constexpr int wave_lq_of(int lane) { return (lane & 7) ^ ((lane & 4) ? 3 : 0); }
+// Bin held by register g of `lane` after the cross-lane FFT (and, with g the surviving register, after the
+// reduce-scatter): stage 1 paired registers (i, i + J/2) -> slot s, stage 2 (i, i + J/4) -> slot t.
+__device__ __host__ constexpr int wave_layout_bin(int J, int logj, int g, int lane)
+{
+    const int b5 = (lane >> 5) & 1, b4 = (lane >> 4) & 1, b3 = (lane >> 3) & 1;
+    const int s = g / (J / 2), t = (g / (J / 4)) & 1, i = g % (J / 4);
+    const int e = i + (J / 4) * b4 + (J / 2) * b5; // in-lane FFT output register the value descends from
+    const int k1 = brev_bits(e, logj);
+    const int k2 = 4 * b3 + 2 * t + s;             // bitrev3 of the position (s, t, b3) in the 8-point DIF
+    return k1 + J * k2;
+}
 
 // atan2 of two points at once where it pays (the polynomial); see lean_atan2 for the accuracy statement
 __device__ __forceinline__ v2f lean_atan2_pk(v2f y, v2f x)
@@ -172,23 +202,31 @@ __device__ __forceinline__ v2f ifreq_prod_pk(v2f p0, v2f c0, v2f p1, v2f c1)
 // Demodulates the symbol window x[0 .. sps): s_out = get_shift_fft's return value, fine_out = d_fine_sync after
 // fine_sync(bin_idx, 2) (0 when drift correction is disabled).  Must be called by a whole wavefront.
 template <int SF, bool EARLY_F>
-__device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const WaveTabs &T, const float2 *__restrict__ x, uint32_t &s_out, int32_t &fine_out)
+__device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const WaveTabs &T, const float2 *__restrict__ x, uint32_t &s_out, int32_t &fine_out,
+                                                  long long *stamps = nullptr /* tools/probe_phases.hip */)
 {
+#define LORA_WSTAMP(i) do { if (stamps) stamps[i] = clock64(); } while (0)
+    LORA_WSTAMP(0);
     using G = WaveGeom<SF>;
     constexpr int N = G::N, J = G::J, SPS = G::SPS, LOGJ = G::LOGJ;
     int lane = threadIdx.x & 63;
     // opaque to the optimiser: keeps the per-lane table addresses from being hoisted out of the caller's
     // state-machine loop (that costs ~100 VGPRs of loop-invariant addresses)
     asm volatile("" : "+v"(lane));
-    const int lq = wave_lq_of(lane), r = lane >> 3;
-    const int nl = 8 * lq + r;
+    const int lq = lane >> 3;
+    const int nl = lane;
     const bool want_fine = P.enable_fine_sync != 0u;
     const v2f *__restrict__ xv = reinterpret_cast<const v2f *>(x);
 
     v2f a[J];
     float f[J]; // ifreq[n - 1] of this lane's samples
+#ifdef LORA_WD_NO_GLOBAL // experiment: synthetic samples instead of the HBM read
+#pragma unroll
+    for (int j = 0; j < J; j++) a[j] = (v2f){(float)(lane + j), (float)(lane ^ j)};
+#else
 #pragma unroll
     for (int j = 0; j < J; j++) a[j] = xv[j * 64 + nl];
+#endif
     if (EARLY_F && want_fine) {
 #pragma unroll
         for (int j = 0; j < J; j += 2) {
@@ -198,45 +236,72 @@ __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const Wave
             f[j + 1] = fp.y;
         }
     }
+    LORA_WSTAMP(1);
 #pragma unroll
-    for (int j = 0; j < J; j++) a[j] = cmulw(a[j], T.down4[j * 64 + nl]); // dechirp (:437)
+    for (int j = 0; j < J; j++) a[j] = cmulw(a[j], LORA_WD_TAB(T.down4[j * 64 + nl], lane)); // dechirp (:437)
     fft_inlane_dif_pk<J>(a);
+    LORA_WSTAMP(2);
 #pragma unroll
-    for (int m = 1; m < J; m++) a[m] = cmulw(a[m], T.twn4[m * 8 + lq]); // W_N^{lq k1}
-    { // 8-point DIF across the group
-        const v2f sg1 = (lq & 4) ? (v2f){-1.f, -1.f} : (v2f){1.f, 1.f};
-        const v2f sg2 = (lq & 2) ? (v2f){-1.f, -1.f} : (v2f){1.f, 1.f};
-        const v2f sg3 = (lq & 1) ? (v2f){-1.f, -1.f} : (v2f){1.f, 1.f};
-        xstage_pk<kDppHalfMirror, J>(a, sg1, T.xst4[lane]);
-        xstage_pk<kDppQuadXor2, J>(a, sg2, T.xst4[64 + lane]);
-        xstage_last_pk<kDppQuadXor1, J>(a, sg3);
+    for (int m = 1; m < J; m++) a[m] = cmulw(a[m], LORA_WD_TAB(T.twn4[m * 8 + lq], lane)); // W_N^{lq k1}
+    LORA_WSTAMP(3);
+    { // 8-point DIF over lq
+        const v4f w1 = T.xst4[lane], w2 = T.xst4[64 + lane]; // W_8^{lq & 3}, W_4^{lq & 1}: the same on both lanes of a pair
+#pragma unroll
+        for (int i = 0; i < J / 2; i++) { // lq bit 2 = lane bit 5
+            const float dx = a[i].x, dy = a[i].y, sx = a[i + J / 2].x, sy = a[i + J / 2].y;
+            const auto px = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(int, dx), __builtin_bit_cast(int, sx), false, false);
+            const auto py = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(int, dy), __builtin_bit_cast(int, sy), false, false);
+            const int x0 = px[0], x1 = px[1], y0 = py[0], y1 = py[1]; // scalars first: bit_cast on a vector element is miscompiled
+            const v2f lo = (v2f){__builtin_bit_cast(float, x0), __builtin_bit_cast(float, y0)};
+            const v2f hi = (v2f){__builtin_bit_cast(float, x1), __builtin_bit_cast(float, y1)};
+            a[i] = lo + hi;
+            a[i + J / 2] = cmulw(lo - hi, w1);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int i = 0; i < J / 4; i++) { // lq bit 1 = lane bit 4
+                const int g = i + h * (J / 2);
+                const float dx = a[g].x, dy = a[g].y, sx = a[g + J / 4].x, sy = a[g + J / 4].y;
+                const auto px = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(int, dx), __builtin_bit_cast(int, sx), false, false);
+                const auto py = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(int, dy), __builtin_bit_cast(int, sy), false, false);
+                const int x0 = px[0], x1 = px[1], y0 = py[0], y1 = py[1];
+                const v2f lo = (v2f){__builtin_bit_cast(float, x0), __builtin_bit_cast(float, y0)};
+                const v2f hi = (v2f){__builtin_bit_cast(float, x1), __builtin_bit_cast(float, y1)};
+                a[g] = lo + hi;
+                a[g + J / 4] = cmulw(lo - hi, w2);
+            }
+        const v2f sg3 = (lane & 8) ? (v2f){-1.f, -1.f} : (v2f){1.f, 1.f}; // lq bit 0 = lane bit 3
+        xstage_last_pk<kDppRor8, J>(a, sg3);
     }
+    LORA_WSTAMP(4);
 #pragma unroll
-    for (int m = 0; m < J; m++) a[m] = cmulw(a[m], T.tws4[m * 64 + lane]); // W_sps^{k r} (+ fold)
-    // reduce-scatter over r: lanes with the bit clear keep the first half of the registers
+    for (int m = 0; m < J; m++) a[m] = cmulw(a[m], LORA_WD_TAB(T.tws4[m * 64 + lane], lane)); // W_sps^{k r} (+ fold)
+    // reduce-scatter over r = lane bits 2, 1, 0: lanes with the bit clear keep the first half of the registers
     v2f b4[J / 2], b2[J / 4], b1[J / 8];
 #pragma unroll
-    for (int i = 0; i < J / 2; i++) { // lane bit 5: v_permlane32_swap leaves own+partner halves side by side
+    for (int i = 0; i < J / 2; i++) { // lane bit 2: row_shr:4 into banks 1,3 / row_shl:4 into banks 0,2
         const float lx = a[i].x, ly = a[i].y, hx = a[i + J / 2].x, hy = a[i + J / 2].y;
-        const auto sx = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(int, lx), __builtin_bit_cast(int, hx), false, false);
-        const auto sy = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(int, ly), __builtin_bit_cast(int, hy), false, false);
-        const int x0 = sx[0], x1 = sx[1], y0 = sy[0], y1 = sy[1]; // scalars first: bit_cast on a vector element is miscompiled
-        b4[i] = (v2f){__builtin_bit_cast(float, x0), __builtin_bit_cast(float, y0)} + (v2f){__builtin_bit_cast(float, x1), __builtin_bit_cast(float, y1)};
-    }
-#pragma unroll
-    for (int i = 0; i < J / 4; i++) { // lane bit 4
-        const float lx = b4[i].x, ly = b4[i].y, hx = b4[i + J / 4].x, hy = b4[i + J / 4].y;
-        const auto sx = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(int, lx), __builtin_bit_cast(int, hx), false, false);
-        const auto sy = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(int, ly), __builtin_bit_cast(int, hy), false, false);
-        const int x0 = sx[0], x1 = sx[1], y0 = sy[0], y1 = sy[1]; // scalars first: bit_cast on a vector element is miscompiled
-        b2[i] = (v2f){__builtin_bit_cast(float, x0), __builtin_bit_cast(float, y0)} + (v2f){__builtin_bit_cast(float, x1), __builtin_bit_cast(float, y1)};
+        v2f X, Y;
+        X.x = dpp_rows_bank_f<0x114, 0xA>(lx, hx); X.y = dpp_rows_bank_f<0x114, 0xA>(ly, hy); // upper lanes: partner's second half
+        Y.x = dpp_rows_bank_f<0x104, 0x5>(hx, lx); Y.y = dpp_rows_bank_f<0x104, 0x5>(hy, ly); // lower lanes: partner's first half
+        b4[i] = X + Y;
     }
     {
-        const bool hi = (lane & 8) != 0; // lane bit 3: row_ror:8
+        const bool hi = (lane & 2) != 0;
+#pragma unroll
+        for (int i = 0; i < J / 4; i++) {
+            const v2f t0 = b4[i] + dpp2<kDppQuadXor2>(b4[i]);
+            const v2f t1 = b4[i + J / 4] + dpp2<kDppQuadXor2>(b4[i + J / 4]);
+            b2[i] = hi ? t1 : t0;
+        }
+    }
+    {
+        const bool hi = (lane & 1) != 0;
 #pragma unroll
         for (int i = 0; i < J / 8; i++) {
-            const v2f t0 = b2[i] + dpp2<kDppRor8>(b2[i]);
-            const v2f t1 = b2[i + J / 8] + dpp2<kDppRor8>(b2[i + J / 8]);
+            const v2f t0 = b2[i] + dpp2<kDppQuadXor1>(b2[i]);
+            const v2f t1 = b2[i + J / 8] + dpp2<kDppQuadXor1>(b2[i + J / 8]);
             b1[i] = hi ? t1 : t0;
         }
     }
@@ -254,16 +319,14 @@ __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const Wave
             f[j + 1] = fp.y;
         }
     }
+    LORA_WSTAMP(5);
     // arg-max on |X|^2 (monotone in the reference's std::abs, :454), first maximum in bin order wins (:463)
-    const int mbase = ((lane & 32) ? J / 2 : 0) + ((lane & 16) ? J / 4 : 0) + ((lane & 8) ? J / 8 : 0);
-    const int k2 = ((lq & 1) << 2) | (lq & 2) | ((lq >> 2) & 1);
+    const int gbase = ((lane & 4) ? J / 2 : 0) + ((lane & 2) ? J / 4 : 0) + ((lane & 1) ? J / 8 : 0); // surviving registers
     float bv = -1.0f;
     int bi = 0x7fffffff;
 #pragma unroll
     for (int i = 0; i < J / 8; i++) {
-        const int m = mbase + i;
-        const int k1 = (int)(__brev((uint32_t)m) >> (32 - LOGJ));
-        const int jb = k1 + J * k2;
+        const int jb = wave_layout_bin(J, LOGJ, gbase + i, lane);
         const float mag = b1[i].x * b1[i].x + b1[i].y * b1[i].y;
         if (mag > bv || (mag == bv && jb < bi)) { bv = mag; bi = jb; }
     }
@@ -271,6 +334,7 @@ __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const Wave
     const uint32_t s = (uint32_t)wave_min_u(bv == best ? bi : 0x7fffffff);
     s_out = s;
     fine_out = 0;
+    LORA_WSTAMP(6);
     if (!want_fine) return;
     // fine_sync (:300-338) with search = max(D/4, 2) = 2 -> lags -1, 0, +1
     const uint32_t bin_idx = (s == 0u && P.demod_mode == 2u) ? 0u : (s + (uint32_t)N - 1u) % (uint32_t)N;
@@ -294,6 +358,8 @@ __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const Wave
     if (c1 > mx) { mx = c1; lag = 0; }
     if (c2 > mx) { mx = c2; lag = 1; }
     fine_out = -lag;
+    LORA_WSTAMP(7);
+#undef LORA_WSTAMP
 }
 
 // copies the packed table block (down4 | twn4 | tws4 | xst4) and the ifreq template into LDS; all threads of the block
@@ -328,12 +394,10 @@ static void build_wave_tables_host(uint32_t sf, const float2 *down, float *out /
             const double a = -2.0 * M_PI * (double)t / (double)N;
             put(o++, std::cos(a), std::sin(a));
         }
-    for (int m = 0; m < J; m++)
+    for (int g = 0; g < J; g++)
         for (int lane = 0; lane < 64; lane++) {
-            const int lq = wave_lq_of(lane), r = lane >> 3;
-            const int k2 = ((lq & 1) << 2) | (lq & 2) | ((lq >> 2) & 1);
-            const int k1 = brev_bits(m, logj);
-            const int jb = k1 + J * k2;
+            const int r = lane & 7;
+            const int jb = wave_layout_bin(J, logj, g, lane);
             const int k = (jb < N / 2) ? jb : jb - N;
             const int e = ((k * r) % SPS + SPS) % SPS;
             const double ang = -2.0 * M_PI * (double)e / (double)SPS;
@@ -346,16 +410,15 @@ static void build_wave_tables_host(uint32_t sf, const float2 *down, float *out /
             put(o++, re, im);
         }
     const double rs = 0.70710678118654752440;
-    for (int lane = 0; lane < 64; lane++) { // stage 1: lower lanes (lq >= 4) multiply by W_8^{lq & 3}
-        const int lq = wave_lq_of(lane), t1 = lq & 3;
-        if (!(lq & 4) || t1 == 0) put(o++, 1.0, 0.0);
+    for (int lane = 0; lane < 64; lane++) { // stage 1 (lq bit 2): the difference is multiplied by W_8^{lq & 3}
+        const int t1 = (lane >> 3) & 3;
+        if (t1 == 0) put(o++, 1.0, 0.0);
         else if (t1 == 1) put(o++, rs, -rs);
         else if (t1 == 2) put(o++, 0.0, -1.0);
         else put(o++, -rs, -rs);
     }
-    for (int lane = 0; lane < 64; lane++) { // stage 2: lower lanes (lq & 2) multiply by W_4^{lq & 1}
-        const int lq = wave_lq_of(lane);
-        if ((lq & 2) && (lq & 1)) put(o++, 0.0, -1.0);
+    for (int lane = 0; lane < 64; lane++) { // stage 2 (lq bit 1): the difference is multiplied by W_4^{lq & 1}
+        if ((lane >> 3) & 1) put(o++, 0.0, -1.0);
         else put(o++, 1.0, 0.0);
     }
 }
