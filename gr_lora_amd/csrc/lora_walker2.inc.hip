@@ -2,20 +2,21 @@
 // Included by lora_kernels.hip.
 //
 // Same state machine as walker_body (decoder_impl::work, lib/decoder_impl.cc:740-903), organised in
-// ROUNDS: 512 threads = 7 worker wavefronts + 1 control wavefront.  In DETECT, FIND_SFD and DECODE_*
+// ROUNDS: WAVES wavefronts = WAVES-1 workers + 1 control wavefront (SF7: one 1024-thread workgroup per CU,
+// 15 workers; SF8: 512 threads, 7 workers).  In DETECT, FIND_SFD and DECODE_*
 // every worker evaluates one upcoming symbol window at pos + w*sps (zero drift assumed); the control
-// thread then replays the reference's per-call logic over the 7 results in order and stops at the first
+// thread then replays the reference's per-call logic over the results in order and stops at the first
 // one whose outcome invalidates the later windows (a trigger, a state change, d_fine_sync != 0, end of
 // data).  The accepted sequence is therefore exactly the serial one.  DECODE rounds are PIPELINED: while
 // the control thread resolves round r, the workers already demodulate round r+1 at the predicted position
-// (same state, 7 symbols further); a misprediction only discards that round.  SYNC (one correlation per
-// packet) is computed by all 8 wavefronts together.  The decoder state lives in LDS and is touched by the
+// (same state, one round further; once the header is decoded the control thread knows how many payload
+// symbols remain and plans exactly that many windows); a misprediction only discards that round.  SYNC (one
+// correlation per packet) is computed by all wavefronts together.  The decoder state lives in LDS and is touched by the
 // control thread only; the per-round PLAN is double-buffered so that no wavefront can read a plan that is
 // being rewritten.
 
-constexpr int kW2 = 512;
-constexpr int kW2Waves = kW2 / 64;   // wavefronts per workgroup
-constexpr int kW2Workers = kW2Waves - 1; // the last wavefront is the control wavefront
+constexpr int kW2MaxWaves = 8; // wavefronts per workgroup the shared structures are sized for (16-wave workgroups, one
+                               // per CU, were measured slower: all 15 workers hit their load and VALU phases together)
 
 enum W2Mode : int32_t { kPlanExit = 0, kPlanDetect, kPlanSync, kPlanSfd, kPlanPause, kPlanDecode, kPlanFinalize };
 
@@ -24,7 +25,7 @@ struct alignas(16) W2Plan {
     int32_t mode;         // W2Mode
     int32_t buf;          // spec buffer the workers fill (kPlanDecode)
     int32_t resolve_prev; // kPlanDecode: spec[buf ^ 1] holds the previous round, to be resolved now
-    int32_t pad;
+    int32_t n_win;        // windows the workers evaluate this round (kPlanDecode: 0 = resolve-only round)
 };
 
 struct alignas(16) W2State {
@@ -50,9 +51,9 @@ struct alignas(16) W2Stats { // per-state time accounting (reported under LORA_H
 };
 
 struct alignas(16) W2Shared {
-    float    red[kW2Waves * 64 + 64];
-    float    specf[kW2Waves][4];
-    int32_t  speci[2][kW2Waves][4];   // [buffer][worker]: decode rounds are double-buffered
+    float    red[kW2MaxWaves * 72 + 8];
+    float    specf[kW2MaxWaves][4];
+    int32_t  speci[2][kW2MaxWaves][4];   // [buffer][worker]: decode rounds are double-buffered
     W2Plan   plan[2];
     Shared   sh;      // words / codewords / decoded bytes (shared with the integer-chain helpers)
     W2State  st;
@@ -65,6 +66,7 @@ struct W2Tabs {
     float        *scratch; // 72 floats per wavefront
 };
 
+template <int WAVES>
 __device__ __forceinline__ void w2_block_argmax_first(float &v, int &idx, float *red)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -79,7 +81,7 @@ __device__ __forceinline__ void w2_block_argmax_first(float &v, int &idx, float 
     __syncthreads();
     v = red[0]; idx = ((int *)red)[16];
 #pragma unroll
-    for (int w = 1; w < kW2Waves; w++) {
+    for (int w = 1; w < WAVES; w++) {
         const float ov = red[w];
         const int oi = ((int *)red)[16 + w];
         if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
@@ -299,21 +301,27 @@ __device__ __forceinline__ void w2_sfd_window(const DevParams &P, const W2Tabs &
 }
 
 // ---- the kernel -----------------------------------------------------------------------------------------
-template <int SF>
+template <int SF, int WAVES>
 __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg &C)
 {
     constexpr int N = 1 << SF, SPS = 8 * N;
+    constexpr int kW2 = 64 * WAVES, kW2Workers = WAVES - 1; // the last wavefront is the control wavefront
+    static_assert(WAVES <= kW2MaxWaves, "W2Shared is sized for kW2MaxWaves wavefronts");
     constexpr uint32_t sps = SPS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W2Shared &W = *reinterpret_cast<W2Shared *>(smem);
     W2State &S = W.st;
     Shared &sh = W.sh;
-    // LDS carve-up after W2Shared: f2[2 sps] | v[3 sps + 40 (padded to 4)] | dd[sps] | twiddle block of the wave demodulator
+    // LDS carve-up after W2Shared: f2[2 sps] | v[3 sps + 40 (padded to 4)] | dd[sps] | twiddle block of the wave
+    // demodulator | partial sums of the SYNC correlation
     float *f2 = reinterpret_cast<float *>(smem + ((sizeof(W2Shared) + 15) & ~(size_t)15));
     float *vl = f2 + 2 * SPS;
     constexpr uint32_t NV = (3u * SPS + 40u + 3u) & ~3u;
     float *ddl = vl + NV;
     v4f *tab4 = reinterpret_cast<v4f *>(ddl + SPS);
+    // SYNC partial sums of the k-slices > 0: on top of f2 when they fit there (the f2 window is dead by then)
+    constexpr bool kPartInF2 = ((kW2 / (SPS / 4)) - 1) * (SPS / 4) * 16 <= 2 * SPS * 4;
+    float4 *part = kPartInF2 ? reinterpret_cast<float4 *>(f2) : reinterpret_cast<float4 *>(tab4 + WaveGeom<SF>::n_v4f);
 
     const uint32_t jid = blockIdx.x;
     if (jid >= C.n_jobs) return;
@@ -331,7 +339,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
 
     // plan for the next round from the TRUE state (control thread only)
     auto plan_from_state = [&](W2Plan &pl) {
-        pl.buf = 0; pl.resolve_prev = 0; pl.pad = 0; pl.pos = S.pos;
+        pl.buf = 0; pl.resolve_prev = 0; pl.n_win = kW2Workers; pl.pos = S.pos;
         if (!S.done) (void)w2_pre_step(S, job, C, sps);
         if (S.done) { pl.mode = kPlanExit; return; }
         if (S.fin_pending) { pl.mode = kPlanFinalize; return; }
@@ -340,7 +348,13 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         case kSync: pl.mode = kPlanSync; break;
         case kFindSfd: pl.mode = kPlanSfd; break;
         case kPause: pl.mode = kPlanPause; break;
-        default: pl.mode = kPlanDecode; break;
+        default:
+            pl.mode = kPlanDecode;
+            if (S.state == kDecodePayload) { // symbols left in the packet (:866-870)
+                const int32_t rem = S.payload_symbols - (int32_t)S.n_words;
+                pl.n_win = rem < kW2Workers ? (rem > 0 ? rem : 1) : kW2Workers;
+            }
+            break;
         }
     };
 
@@ -369,7 +383,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             Q.prev_state = sidx; Q.prev_t = t_start;
         }
         const int64_t wpos = pos + (int64_t)wave * sps;
-        const bool wvalid = !is_ctl && wpos + 2 * (int64_t)sps <= n_items;
+        const bool wvalid = !is_ctl && wave < plan.n_win && wpos + 2 * (int64_t)sps <= n_items;
 
         if (plan.mode == kPlanDetect) {
             float a[4] = {0.f, 0.f, 0.f, 0.f};
@@ -444,9 +458,8 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             }
             float bv = 0.0f; // max_correlation = 0 (:400)
             int bi = 0x7fffffff;
-            if constexpr (groups > 1) { // slices > 0 hand their partial sums to slice 0 (the f2 window is dead by then)
-                __syncthreads();
-                float4 *part = reinterpret_cast<float4 *>(f2);
+            if constexpr (groups > 1) { // slices > 0 hand their partial sums to slice 0
+                if constexpr (kPartInF2) __syncthreads();
                 if (grp > 0) part[(grp - 1u) * tiles + tile] = make_float4(c0, c1, c2, c3);
                 __syncthreads();
                 if (grp == 0) {
@@ -460,7 +473,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 if (c2 > bv) { bv = c2; bi = i0 + 2; }
                 if (c3 > bv) { bv = c3; bi = i0 + 3; }
             }
-            w2_block_argmax_first(bv, bi, W.red);
+            w2_block_argmax_first<WAVES>(bv, bi, W.red);
             if (t0) {
                 const int32_t consumed = (bi == 0x7fffffff) ? 0 : bi; // :771
                 S.state = kFindSfd;
@@ -559,7 +572,13 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                             w2_pre_step(S, job, C, sps);
             }
             if (predicted) {
-                next.mode = kPlanDecode; next.pos = plan.pos + (int64_t)kW2Workers * sps; next.buf = plan.buf ^ 1; next.resolve_prev = 1; next.pad = 0;
+                // the round in flight continues the packet; how much of the packet is left after it?
+                int32_t n_next = kW2Workers;
+                if (S.state == kDecodePayload) {
+                    const int32_t rem = S.payload_symbols - (int32_t)S.n_words - plan.n_win;
+                    n_next = rem < kW2Workers ? (rem > 0 ? rem : 0) : kW2Workers; // 0: nothing left to demodulate, only resolve
+                }
+                next.mode = kPlanDecode; next.pos = plan.pos + (int64_t)plan.n_win * sps; next.buf = plan.buf ^ 1; next.resolve_prev = 1; next.n_win = n_next;
             } else {
                 plan_from_state(next); // this round's results are discarded
             }
@@ -593,14 +612,17 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     }
 }
 
-__global__ __launch_bounds__(kW2, 4) void walker2_kernel_sf7(DevParams P, LaunchCfg C) { walker2_body<7>(P, C); }
-__global__ __launch_bounds__(kW2, 2) void walker2_kernel_sf8(DevParams P, LaunchCfg C) { walker2_body<8>(P, C); }
+constexpr int kW2WavesSf7 = 8, kW2WavesSf8 = 8;
+__global__ __launch_bounds__(64 * kW2WavesSf7, 4) void walker2_kernel_sf7(DevParams P, LaunchCfg C) { walker2_body<7, kW2WavesSf7>(P, C); }
+__global__ __launch_bounds__(64 * kW2WavesSf8, 2) void walker2_kernel_sf8(DevParams P, LaunchCfg C) { walker2_body<8, kW2WavesSf8>(P, C); }
+
+static uint32_t walker2_threads(uint32_t sf) { return 64u * (uint32_t)(sf == 7u ? kW2WavesSf7 : kW2WavesSf8); }
 
 static uint32_t walker2_lds_bytes(uint32_t sf)
 {
-    const uint32_t sps = 8u << sf, n = 1u << sf;
+    const uint32_t sps = 8u << sf;
     const uint32_t nv = (3u * sps + 40u + 3u) & ~3u;
-    (void)n;
+    const uint32_t tiles = sps / 4u, groups = walker2_threads(sf) / tiles; // SYNC: partial sums of the k-slices > 0
     return (uint32_t)((sizeof(W2Shared) + 15) & ~(size_t)15) + (2u * sps + nv + sps) * (uint32_t)sizeof(float) +
-           wave_tables_floats(sf) * (uint32_t)sizeof(float);
+           wave_tables_floats(sf) * (uint32_t)sizeof(float) + ((groups > 1u && (groups - 1u) * tiles * 16u > 2u * sps * 4u) ? (groups - 1u) * tiles * 16u : 0u);
 }
