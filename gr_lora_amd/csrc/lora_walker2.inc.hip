@@ -15,6 +15,7 @@
 // control thread only; the per-round PLAN is double-buffered so that no wavefront can read a plan that is
 // being rewritten.
 
+constexpr int kW2DetectK = 4;   // DETECT windows per worker and round
 constexpr int kW2MaxWaves = 8; // wavefronts per workgroup the shared structures are sized for (16-wave workgroups, one
                                // per CU, were measured slower: all 15 workers hit their load and VALU phases together)
 
@@ -53,6 +54,8 @@ struct alignas(16) W2Stats { // per-state time accounting (reported under LORA_H
 struct alignas(16) W2Shared {
     float    red[kW2MaxWaves * 72 + 8];
     float    specf[kW2MaxWaves][4];
+    float    detf[kW2MaxWaves * kW2DetectK][4]; // DETECT: d0, d1, e1, e2 per window
+    int32_t  detn[kW2MaxWaves];                 // DETECT: valid windows of each worker
     int32_t  speci[2][kW2MaxWaves][4];   // [buffer][worker]: decode rounds are double-buffered
     W2Plan   plan[2];
     Shared   sh;      // words / codewords / decoded bytes (shared with the integer-chain helpers)
@@ -97,7 +100,7 @@ __device__ __forceinline__ float unwrap_diff(float pp, float p2)
 }
 
 // ---- thread-0 bookkeeping (mirrors end_step / the loop-top checks of walker_body) ---------------------
-__device__ bool w2_pre_step(W2State &S, const Job &job, const LaunchCfg &C, uint32_t sps)
+__device__ __forceinline__ bool w2_pre_step(W2State &S, const Job &job, const LaunchCfg &C, uint32_t sps)
 {
     if (S.state == kDetect && !S.in_attempt) {
         if (S.pos >= job.scan_limit) { S.stop_reason = 0; S.done = 1; return false; }
@@ -108,10 +111,11 @@ __device__ bool w2_pre_step(W2State &S, const Job &job, const LaunchCfg &C, uint
     return true;
 }
 
-__device__ void w2_end_step(W2State &S, const Job &job, const LaunchCfg &C, AttemptRec *recs, StepRec *trace, int32_t st_in,
-                            int32_t consumed, int32_t step_bin, int32_t fine, float step_val, long long t_start)
+// `lead`: this lane performs the global stores (the decode rounds run this on the whole control wavefront, uniformly)
+__device__ __forceinline__ void w2_end_step(W2State &S, const Job &job, const LaunchCfg &C, AttemptRec *recs, StepRec *trace, int32_t st_in,
+                            int32_t consumed, int32_t step_bin, int32_t fine, float step_val, long long t_start, bool lead = true)
 {
-    if (trace && S.n_steps < C.trace_cap) {
+    if (trace && lead && S.n_steps < C.trace_cap) {
         StepRec &s = trace[S.n_steps];
         s.state = st_in; s.consumed = consumed; s.pos = S.pos; s.bin = step_bin; s.fine = fine; s.value = step_val;
         s.stream = job.stream_id; s.cycles = (uint32_t)(clock64() - t_start); s.pad = 0;
@@ -119,13 +123,15 @@ __device__ void w2_end_step(W2State &S, const Job &job, const LaunchCfg &C, Atte
     S.n_steps++;
     S.pos += consumed;
     if (S.in_attempt && S.state == kDetect) { // attempt finished: frame published, or sync lost
-        AttemptRec &r = recs[S.n_att];
-        r.status = S.frame_ok ? kAttemptFrame : kAttemptLostSync;
-        if (!S.frame_ok) r.frame_len = 0;
-        r.start_pos = S.att_start; r.trig_pos = S.att_trig; r.hdr_pos = S.att_hdr; r.end_pos = S.pos;
-        r.npush = S.npush;
-        for (int i = 0; i < 4; i++) r.push_tail[i] = S.push_tail[i];
-        r.cr_prev = S.att_cr_prev; r.hdr_ambig = S.att_ambig; r.n_symbols = S.n_sym;
+        if (lead) {
+            AttemptRec &r = recs[S.n_att];
+            r.status = S.frame_ok ? kAttemptFrame : kAttemptLostSync;
+            if (!S.frame_ok) r.frame_len = 0;
+            r.start_pos = S.att_start; r.trig_pos = S.att_trig; r.hdr_pos = S.att_hdr; r.end_pos = S.pos;
+            r.npush = S.npush;
+            for (int i = 0; i < 4; i++) r.push_tail[i] = S.push_tail[i];
+            r.cr_prev = S.att_cr_prev; r.hdr_ambig = S.att_ambig; r.n_symbols = S.n_sym;
+        }
         S.n_att++;
         S.in_attempt = 0;
         S.frame_ok = 0;
@@ -139,7 +145,9 @@ __device__ void w2_end_step(W2State &S, const Job &job, const LaunchCfg &C, Atte
 
 // everything demodulate()/work() do once the bin is known (:506-529, :826-886); thread 0 only.
 // Returns true when the payload is complete: the caller must run the workgroup-wide finalisation.
-__device__ bool w2_post_symbol(const DevParams &P, W2State &S, Shared &sh, uint32_t bin_idx, bool is_first)
+// WAVE: called by the whole (converged) control wavefront with identical arguments; the deinterleaver then uses the lanes.
+template <bool WAVE = false>
+__device__ __forceinline__ bool w2_post_symbol(const DevParams &P, W2State &S, Shared &sh, uint32_t bin_idx, bool is_first)
 {
     const bool reduced = is_first || P.reduced_rate; // :495
     if (reduced) bin_idx = (uint32_t)(lroundf((float)bin_idx / 4.0f) % (long)P.nbins_hdr); // :507-509
@@ -152,7 +160,8 @@ __device__ bool w2_post_symbol(const DevParams &P, W2State &S, Shared &sh, uint3
     if (S.n_words == need) {
         const uint32_t ppm = reduced ? P.sf - 2u : P.sf;
         uint32_t tmp = S.n_cw;
-        deinterleave_block(sh, need, ppm, tmp);
+        if constexpr (WAVE) deinterleave_block_wave(sh, need, ppm, tmp); // ppm <= 8 on this kernel's SFs
+        else deinterleave_block(sh, need, ppm, tmp);
         S.n_cw = (S.n_cw + ppm <= (uint32_t)kMaxCodewords) ? S.n_cw + ppm : (uint32_t)kMaxCodewords;
         S.n_words = 0;
         block_done = true;
@@ -212,6 +221,37 @@ __device__ __forceinline__ void w2_detect_window(const float2 *__restrict__ p, f
         a3 += c2.x * c2.x + c2.y * c2.y;
     }
     out[0] = wave_sum_rows(a0); out[1] = wave_sum_rows(a1); out[2] = wave_sum_rows(a2); out[3] = wave_sum_rows(a3);
+}
+
+// K consecutive DETECT windows (pos, pos + sps, ...) by one wavefront: the K + 1 symbols are read once,
+// each energy sum serves two windows.  Per window the sums are formed exactly as in w2_detect_window.
+template <int SF, int K>
+__device__ __forceinline__ void w2_detect_windows(const float2 *__restrict__ p, int nvalid, float (&out)[K][4])
+{
+    constexpr int SPS = 8 << SF, J = SPS / 64;
+    const int lane = threadIdx.x & 63;
+    float d0[K], d1[K], e[K + 1];
+#pragma unroll
+    for (int i = 0; i < K; i++) { d0[i] = 0.f; d1[i] = 0.f; }
+#pragma unroll
+    for (int s = 0; s <= K; s++) e[s] = 0.f;
+#pragma unroll 4 // 4 (K + 1) loads in flight; a full unroll hoists all 16 (K + 1) and spills
+    for (int j = 0; j < J; j++) {
+        float2 c[K + 1];
+#pragma unroll
+        for (int s = 0; s <= K; s++) c[s] = (s <= nvalid) ? p[s * SPS + j * 64 + lane] : make_float2(0.f, 0.f); // nvalid is wave-uniform
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            d0[i] += c[i].x * c[i + 1].x + c[i].y * c[i + 1].y;
+            d1[i] += c[i].y * c[i + 1].x - c[i].x * c[i + 1].y;
+        }
+#pragma unroll
+        for (int s = 0; s <= K; s++) e[s] += c[s].x * c[s].x + c[s].y * c[s].y;
+    }
+#pragma unroll
+    for (int s = 0; s <= K; s++) e[s] = wave_sum_rows(e[s]);
+#pragma unroll
+    for (int i = 0; i < K; i++) { out[i][0] = wave_sum_rows(d0[i]); out[i][1] = wave_sum_rows(d1[i]); out[i][2] = e[i]; out[i][3] = e[i + 1]; }
 }
 
 // FIND_SFD (:385-390, :283-298, :801-803): Pearson correlation of the window's ifreq with the ideal
@@ -333,12 +373,13 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool is_ctl = wave == kW2Workers;                 // control wavefront
     const bool t0 = threadIdx.x == kW2Workers * 64;         // the control thread: sole owner of the decoder state S
+    if (is_ctl) __builtin_amdgcn_s_setprio(2);              // its serial bookkeeping is on every round's critical path
 
     const WaveTabs FT = wave_tabs_to_lds<SF>(P, tab4, vl, kW2);
     for (uint32_t i = threadIdx.x; i < sps; i += kW2) ddl[i] = P.down_ifreq[i] - P.down_ifreq_avg;
 
     // plan for the next round from the TRUE state (control thread only)
-    auto plan_from_state = [&](W2Plan &pl) {
+    auto plan_from = [&](W2State &S, W2Plan &pl) {
         pl.buf = 0; pl.resolve_prev = 0; pl.n_win = kW2Workers; pl.pos = S.pos;
         if (!S.done) (void)w2_pre_step(S, job, C, sps);
         if (S.done) { pl.mode = kPlanExit; return; }
@@ -357,6 +398,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             break;
         }
     };
+    auto plan_from_state = [&](W2Plan &pl) { plan_from(S, pl); };
 
     if (t0) {
         S = W2State{};
@@ -385,36 +427,83 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         const int64_t wpos = pos + (int64_t)wave * sps;
         const bool wvalid = !is_ctl && wave < plan.n_win && wpos + 2 * (int64_t)sps <= n_items;
 
-        if (plan.mode == kPlanDetect) {
-            float a[4] = {0.f, 0.f, 0.f, 0.f};
-            if (wvalid) w2_detect_window<SF>(X + wpos, a);
-            if (lane == 0 && !is_ctl) { W.specf[wave][0] = a[0]; W.specf[wave][1] = a[1]; W.specf[wave][2] = a[2]; W.specf[wave][3] = a[3]; W.speci[0][wave][0] = wvalid ? 1 : 0; }
-            __syncthreads();
-            if (t0) {
-                for (int w = 0; w < kW2Workers; w++) {
-                    if (w > 0 && !w2_pre_step(S, job, C, sps)) break;
-                    if (!W.speci[0][w][0]) break;
-                    const float d0 = W.specf[w][0], d1 = W.specf[w][1], e1 = W.specf[w][2], e2 = W.specf[w][3];
-                    S.energy_threshold = e2 / 2.0f; // :357
-                    const float pushed = e1 / (float)sps; // :360
-                    if (S.npush >= 4u) { S.push_tail[0] = S.push_tail[1]; S.push_tail[1] = S.push_tail[2]; S.push_tail[2] = S.push_tail[3]; S.push_tail[3] = pushed; }
-                    else S.push_tail[S.npush] = pushed;
-                    S.npush++;
-                    const float sq = sqrtf(e1 * e2);
-                    const float autocorr = hypotf(d0 / sq, d1 / sq); // :363
-                    int32_t consumed = 0;
-                    if (autocorr >= 0.90f) { // :755
-                        S.corr_fails = 0u;
-                        S.state = kSync;
-                        S.in_attempt = 1;
-                        S.att_trig = S.pos; S.att_hdr = -1; S.att_cr_prev = S.cr; S.att_ambig = 0; S.n_sym = 0;
-                    } else {
-                        consumed = (int32_t)sps;
-                    }
-                    w2_end_step(S, job, C, recs, trace, kDetect, consumed, -1, 0, autocorr, t_start);
-                    if (S.state != kDetect || S.done) break;
+        if (plan.mode == kPlanDetect) { // every worker evaluates kW2DetectK consecutive windows
+            if (!is_ctl) {
+                const int64_t dpos = pos + (int64_t)wave * kW2DetectK * sps;
+                int nvalid = 0; // windows of this worker that lie inside the data (:91)
+                if (dpos + 2 * (int64_t)sps <= n_items) {
+                    const int64_t fit = (n_items - dpos) / (int64_t)sps - 1;
+                    nvalid = fit < kW2DetectK ? (int)fit : kW2DetectK;
                 }
-                plan_from_state(next);
+                float a[kW2DetectK][4];
+                if (nvalid > 0) w2_detect_windows<SF, kW2DetectK>(X + dpos, nvalid, a);
+                if (lane == 0) {
+                    W.detn[wave] = nvalid;
+                    for (int i = 0; i < kW2DetectK; i++)
+                        if (i < nvalid) { float *o = W.detf[wave * kW2DetectK + i]; o[0] = a[i][0]; o[1] = a[i][1]; o[2] = a[i][2]; o[3] = a[i][3]; }
+                }
+            }
+            __syncthreads();
+            if (is_ctl) {
+                // the control wavefront evaluates all windows at once (lane q = window q); what the serial replay
+                // of :740-768 would do with them -- stop at the first trigger, at the scan limit or at the end of
+                // the data -- is then applied to the decoder state in one step
+                constexpr int NW = kW2Workers * kW2DetectK;
+                static_assert(NW <= 64, "one lane per DETECT window");
+                const int q = lane;
+                const bool valid = q < NW && (q % kW2DetectK) < W.detn[q / kW2DetectK];
+                float autocorr = 0.0f, pushed = 0.0f, e2 = 0.0f;
+                if (valid) {
+                    const float *o = W.detf[q];
+                    const float d0 = o[0], d1 = o[1], e1 = o[2];
+                    e2 = o[3];
+                    pushed = e1 / (float)sps; // :360
+                    const float sq = sqrtf(e1 * e2);
+                    autocorr = hypotf(d0 / sq, d1 / sq); // :363
+                }
+                const unsigned long long vmask = __ballot(valid), tmask = __ballot(valid && autocorr >= 0.90f); // :755
+                W.red[q] = pushed; W.red[64 + q] = e2; W.red[128 + q] = autocorr;
+                __builtin_amdgcn_wave_barrier();
+                if (t0) {
+                    // steps q >= 1 are preceded by the loop-top checks: in DETECT outside an attempt only the scan limit
+                    // can change between steps (the data end shows up as an invalid window)
+                    int64_t n_lim = (job.scan_limit - S.pos + (int64_t)sps - 1) / (int64_t)sps;
+                    if (n_lim < 1) n_lim = 1;
+                    const int n_valid = (~vmask == 0ull) ? 64 : __builtin_ctzll(~vmask);
+                    int n_max = n_valid < NW ? n_valid : NW;
+                    if ((int64_t)n_max > n_lim) n_max = (int)n_lim;
+                    const int qt = tmask ? __builtin_ctzll(tmask) : 64;
+                    const bool trig = qt < n_max;
+                    const int nd = trig ? qt + 1 : n_max; // DETECT steps executed
+                    if (nd > 0) {
+                        if (trace) { // position-exact trace: one record per step
+                            for (int i = 0; i < nd; i++) {
+                                if (S.n_steps + (uint32_t)i < C.trace_cap) {
+                                    StepRec &r = trace[S.n_steps + (uint32_t)i];
+                                    r.state = kDetect; r.consumed = (trig && i == nd - 1) ? 0 : (int32_t)sps; r.pos = S.pos + (int64_t)i * sps; r.bin = -1; r.fine = 0;
+                                    r.value = W.red[128 + i]; r.stream = job.stream_id; r.cycles = (uint32_t)(clock64() - t_start); r.pad = 0;
+                                }
+                            }
+                        }
+                        for (int i = (nd > 4 ? nd - 4 : 0); i < nd; i++) { // d_pwr_queue keeps the last 4 pushes (:360)
+                            const float pv = W.red[i];
+                            if (S.npush >= 4u) { S.push_tail[0] = S.push_tail[1]; S.push_tail[1] = S.push_tail[2]; S.push_tail[2] = S.push_tail[3]; S.push_tail[3] = pv; }
+                            else S.push_tail[S.npush] = pv;
+                            S.npush++;
+                        }
+                        if (nd > 4) S.npush += (uint32_t)(nd - 4);
+                        S.energy_threshold = W.red[64 + nd - 1] / 2.0f; // :357
+                        S.n_steps += (uint32_t)nd;
+                        S.pos += (int64_t)(trig ? nd - 1 : nd) * sps;
+                        if (trig) {
+                            S.corr_fails = 0u;
+                            S.state = kSync;
+                            S.in_attempt = 1;
+                            S.att_trig = S.pos; S.att_hdr = -1; S.att_cr_prev = S.cr; S.att_ambig = 0; S.n_sym = 0;
+                        }
+                    }
+                    plan_from_state(next);
+                }
             }
             continue;
         }
@@ -548,39 +637,47 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             int32_t wfine = 0;
             if (wvalid) wave_demod_symbol<SF, SF == 7>(P, FT, X + wpos, ws, wfine);
             if (lane == 0) { W.speci[plan.buf][wave][0] = wvalid ? (int32_t)ws : -1; W.speci[plan.buf][wave][1] = wfine; }
-        } else if (t0) {
+        } else { // the whole control wavefront, uniformly (identical values in every lane); t0 does the stores
             bool predicted = true;
+            const long long tr0 = clock64();
+            W2State L = S; // the resolve works on a register copy: every field access in LDS is a ~130-cycle round trip
             if (plan.resolve_prev) {
                 const int rb = plan.buf ^ 1;
                 for (int w = 0; w < kW2Workers; w++) {
-                    if (w > 0 && !w2_pre_step(S, job, C, sps)) break;
-                    if (!(S.state == kDecodeHeader || S.state == kDecodePayload) || W.speci[rb][w][0] < 0) break;
-                    const bool is_first = S.state == kDecodeHeader;
-                    const int32_t st_w = S.state;
+                    if (w > 0 && !w2_pre_step(L, job, C, sps)) break;
+                    if (!(L.state == kDecodeHeader || L.state == kDecodePayload) || W.speci[rb][w][0] < 0) break;
+                    const bool is_first = L.state == kDecodeHeader;
+                    const int32_t st_w = L.state;
                     const uint32_t sres = (uint32_t)W.speci[rb][w][0];
                     const int32_t fw = W.speci[rb][w][1];
                     const uint32_t bin_idx = (sres == 0u && P.demod_mode == 2u) ? 0u : (sres + (uint32_t)N - 1u) % (uint32_t)N;
-                    if (w2_post_symbol(P, S, sh, bin_idx, is_first)) { // payload complete: finalise with all threads
-                        S.fin_pending = 1; S.fin_st = st_w; S.fin_consumed = (int32_t)sps + fw; S.fin_bin = (int32_t)bin_idx; S.fin_fine = fw;
+                    if (w2_post_symbol<true>(P, L, sh, bin_idx, is_first)) { // payload complete: finalise with all threads
+                        L.fin_pending = 1; L.fin_st = st_w; L.fin_consumed = (int32_t)sps + fw; L.fin_bin = (int32_t)bin_idx; L.fin_fine = fw;
                         break;
                     }
-                    w2_end_step(S, job, C, recs, trace, st_w, (int32_t)sps + fw, (int32_t)bin_idx, fw, 0.0f, t_start);
-                    if (S.done || fw != 0) break; // later windows started at the wrong sample
+                    w2_end_step(L, job, C, recs, trace, st_w, (int32_t)sps + fw, (int32_t)bin_idx, fw, 0.0f, t_start, t0);
+                    if (L.done || fw != 0) break; // later windows started at the wrong sample
                 }
                 // is the round the workers are computing right now the true continuation?
-                predicted = !S.done && !S.fin_pending && (S.state == kDecodeHeader || S.state == kDecodePayload) && S.pos == plan.pos &&
-                            w2_pre_step(S, job, C, sps);
+                predicted = !L.done && !L.fin_pending && (L.state == kDecodeHeader || L.state == kDecodePayload) && L.pos == plan.pos &&
+                            w2_pre_step(L, job, C, sps);
             }
+            W2Plan np; // (built in registers, stored by t0)
             if (predicted) {
                 // the round in flight continues the packet; how much of the packet is left after it?
                 int32_t n_next = kW2Workers;
-                if (S.state == kDecodePayload) {
-                    const int32_t rem = S.payload_symbols - (int32_t)S.n_words - plan.n_win;
+                if (L.state == kDecodePayload) {
+                    const int32_t rem = L.payload_symbols - (int32_t)L.n_words - plan.n_win;
                     n_next = rem < kW2Workers ? (rem > 0 ? rem : 0) : kW2Workers; // 0: nothing left to demodulate, only resolve
                 }
-                next.mode = kPlanDecode; next.pos = plan.pos + (int64_t)plan.n_win * sps; next.buf = plan.buf ^ 1; next.resolve_prev = 1; next.n_win = n_next;
+                np.mode = kPlanDecode; np.pos = plan.pos + (int64_t)plan.n_win * sps; np.buf = plan.buf ^ 1; np.resolve_prev = 1; np.n_win = n_next;
             } else {
-                plan_from_state(next); // this round's results are discarded
+                plan_from(L, np); // this round's results are discarded
+            }
+            if (t0) {
+                next = np;
+                S = L;
+                W.stats.cyc[4] += (uint32_t)((clock64() - tr0) >> 6); W.stats.rounds[4]++; // control wavefront's share of a decode round
             }
         }
     }
