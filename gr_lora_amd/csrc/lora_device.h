@@ -94,6 +94,7 @@ struct JobResult {
     uint32_t pad;
     uint32_t cyc[6];       // shader clocks / 64 spent per state (DETECT, SYNC, FIND_SFD, PAUSE, HEADER, PAYLOAD); walker2 only
     uint32_t rounds[6];    // rounds per state
+    uint32_t ctl[4];       // control wavefront inside decode rounds, shader clocks / 64: state copy-in, symbol loop, plan, copy-out
 };
 
 struct StepRec {           // mirrors lora_hip_step_t

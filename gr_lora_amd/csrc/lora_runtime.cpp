@@ -286,6 +286,9 @@ lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vec
         for (uint32_t j = 0; j < nj; j++) for (int i = 0; i < 6; i++) { cyc[i] += 64.0 * out.res[j].cyc[i]; rnd[i] += out.res[j].rounds[i]; }
         fprintf(stderr, "[lora_hip] per-job avg kcycles (rounds): DETECT %.0f (%.1f) SYNC %.0f (%.1f) SFD %.0f (%.1f) PAUSE %.0f (%.1f) HDR %.0f (%.1f) PAYLOAD %.0f (%.1f)\n",
                 cyc[0] / nj / 1e3, rnd[0] / nj, cyc[1] / nj / 1e3, rnd[1] / nj, cyc[2] / nj / 1e3, rnd[2] / nj, cyc[3] / nj / 1e3, rnd[3] / nj, cyc[4] / nj / 1e3, rnd[4] / nj, cyc[5] / nj / 1e3, rnd[5] / nj);
+        double ctl[4] = {0};
+        for (uint32_t j = 0; j < nj; j++) for (int i = 0; i < 4; i++) ctl[i] += 64.0 * out.res[j].ctl[i];
+        fprintf(stderr, "[lora_hip] control wavefront per job, kcycles: copy-in %.0f loop %.0f plan %.0f copy-out %.0f\n", ctl[0] / nj / 1e3, ctl[1] / nj / 1e3, ctl[2] / nj / 1e3, ctl[3] / nj / 1e3);
         std::vector<double> tot(nj);
         for (uint32_t j = 0; j < nj; j++) { double t = 0; for (int i = 0; i < 6; i++) t += 64.0 * out.res[j].cyc[i]; tot[j] = t; }
         std::sort(tot.begin(), tot.end());

@@ -48,7 +48,7 @@ struct alignas(16) W2State {
 struct alignas(16) W2Stats { // per-state time accounting (reported under LORA_HIP_DEBUG), kept out of the hot state
     long long prev_t;
     int32_t   prev_state;
-    uint32_t  cyc[6], rounds[6];
+    uint32_t  cyc[6], rounds[6], ctl[4];
 };
 
 struct alignas(16) W2Shared {
@@ -61,6 +61,7 @@ struct alignas(16) W2Shared {
     Shared   sh;      // words / codewords / decoded bytes (shared with the integer-chain helpers)
     W2State  st;
     W2Stats  stats;
+    uint32_t words_pk[2]; // d_words of the current block, one byte per word (words < 256 for SF <= 8); control thread only
 };
 
 struct W2Tabs {
@@ -147,20 +148,26 @@ __device__ __forceinline__ void w2_end_step(W2State &S, const Job &job, const La
 // Returns true when the payload is complete: the caller must run the workgroup-wide finalisation.
 // WAVE: called by the whole (converged) control wavefront with identical arguments; the deinterleaver then uses the lanes.
 template <bool WAVE = false>
-__device__ __forceinline__ bool w2_post_symbol(const DevParams &P, W2State &S, Shared &sh, uint32_t bin_idx, bool is_first)
+__device__ __forceinline__ bool w2_post_symbol(const DevParams &P, W2State &S, Shared &sh, uint32_t bin_idx, bool is_first, uint32_t *wpk = nullptr)
 {
     const bool reduced = is_first || P.reduced_rate; // :495
-    if (reduced) bin_idx = (uint32_t)(lroundf((float)bin_idx / 4.0f) % (long)P.nbins_hdr); // :507-509
+    if (reduced) bin_idx = (uint32_t)lroundf((float)bin_idx / 4.0f) & (P.nbins_hdr - 1u); // :507-509 (% N/4, a power of two, of a value >= 0)
     const uint32_t word = bin_idx ^ (bin_idx >> 1u); // :512
     const uint32_t need = 4u + (is_first ? 4u : S.cr); // :521
     bool block_done = false;
-    if (S.n_words < 16u) sh.words[S.n_words] = word;
+    if constexpr (WAVE) { // the block's words stay in a register: no LDS round trip per symbol
+        const uint32_t sh8 = 8u * (S.n_words & 3u), ins = (word & 0xffu) << sh8, keep = ~(0xffu << sh8);
+        if (S.n_words < 4u) wpk[0] = (wpk[0] & keep) | ins;
+        else if (S.n_words < 8u) wpk[1] = (wpk[1] & keep) | ins;
+    } else {
+        if (S.n_words < 16u) sh.words[S.n_words] = word;
+    }
     S.n_words++;
     S.n_sym++;
     if (S.n_words == need) {
         const uint32_t ppm = reduced ? P.sf - 2u : P.sf;
         uint32_t tmp = S.n_cw;
-        if constexpr (WAVE) deinterleave_block_wave(sh, need, ppm, tmp); // ppm <= 8 on this kernel's SFs
+        if constexpr (WAVE) deinterleave_block_wave(sh, ((uint64_t)wpk[1] << 32) | wpk[0], need, ppm, tmp); // ppm <= 8 on this kernel's SFs
         else deinterleave_block(sh, need, ppm, tmp);
         S.n_cw = (S.n_cw + ppm <= (uint32_t)kMaxCodewords) ? S.n_cw + ppm : (uint32_t)kMaxCodewords;
         S.n_words = 0;
@@ -640,18 +647,23 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         } else { // the whole control wavefront, uniformly (identical values in every lane); t0 does the stores
             bool predicted = true;
             const long long tr0 = clock64();
+            uint32_t wpk[2] = {W.words_pk[0], W.words_pk[1]};
             W2State L = S; // the resolve works on a register copy: every field access in LDS is a ~130-cycle round trip
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const long long tr1 = clock64();
             if (plan.resolve_prev) {
                 const int rb = plan.buf ^ 1;
+                // lane w fetches worker w's result: one LDS round trip for the round instead of two per symbol
+                const int32_t my_s = lane < kW2Workers ? W.speci[rb][lane][0] : -1, my_f = lane < kW2Workers ? W.speci[rb][lane][1] : 0;
                 for (int w = 0; w < kW2Workers; w++) {
                     if (w > 0 && !w2_pre_step(L, job, C, sps)) break;
-                    if (!(L.state == kDecodeHeader || L.state == kDecodePayload) || W.speci[rb][w][0] < 0) break;
+                    const int32_t sw = __builtin_amdgcn_readlane(my_s, w), fw = __builtin_amdgcn_readlane(my_f, w);
+                    if (!(L.state == kDecodeHeader || L.state == kDecodePayload) || sw < 0) break;
                     const bool is_first = L.state == kDecodeHeader;
                     const int32_t st_w = L.state;
-                    const uint32_t sres = (uint32_t)W.speci[rb][w][0];
-                    const int32_t fw = W.speci[rb][w][1];
+                    const uint32_t sres = (uint32_t)sw;
                     const uint32_t bin_idx = (sres == 0u && P.demod_mode == 2u) ? 0u : (sres + (uint32_t)N - 1u) % (uint32_t)N;
-                    if (w2_post_symbol<true>(P, L, sh, bin_idx, is_first)) { // payload complete: finalise with all threads
+                    if (w2_post_symbol<true>(P, L, sh, bin_idx, is_first, wpk)) { // payload complete: finalise with all threads
                         L.fin_pending = 1; L.fin_st = st_w; L.fin_consumed = (int32_t)sps + fw; L.fin_bin = (int32_t)bin_idx; L.fin_fine = fw;
                         break;
                     }
@@ -662,6 +674,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 predicted = !L.done && !L.fin_pending && (L.state == kDecodeHeader || L.state == kDecodePayload) && L.pos == plan.pos &&
                             w2_pre_step(L, job, C, sps);
             }
+            const long long tr2 = clock64();
             W2Plan np; // (built in registers, stored by t0)
             if (predicted) {
                 // the round in flight continues the packet; how much of the packet is left after it?
@@ -674,9 +687,14 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             } else {
                 plan_from(L, np); // this round's results are discarded
             }
+            const long long tr3 = clock64();
             if (t0) {
                 next = np;
                 S = L;
+                W.words_pk[0] = wpk[0]; W.words_pk[1] = wpk[1];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                W.stats.ctl[0] += (uint32_t)((tr1 - tr0) >> 6); W.stats.ctl[1] += (uint32_t)((tr2 - tr1) >> 6); W.stats.ctl[2] += (uint32_t)((tr3 - tr2) >> 6);
+                W.stats.ctl[3] += (uint32_t)((clock64() - tr3) >> 6);
                 W.stats.cyc[4] += (uint32_t)((clock64() - tr0) >> 6); W.stats.rounds[4]++; // control wavefront's share of a decode round
             }
         }
@@ -706,6 +724,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         W2Stats &Q = W.stats;
         if (Q.prev_state >= 0) { Q.cyc[Q.prev_state] += (uint32_t)((clock64() - Q.prev_t) >> 6); Q.rounds[Q.prev_state]++; }
         for (int i = 0; i < 6; i++) { jr.cyc[i] = Q.cyc[i]; jr.rounds[i] = Q.rounds[i]; }
+        for (int i = 0; i < 4; i++) jr.ctl[i] = Q.ctl[i];
     }
 }
 
