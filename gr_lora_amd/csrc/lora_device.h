@@ -66,6 +66,8 @@ struct Job {
     uint32_t cr_prev;      // d_phdr.cr carried in (constructor value or previous packet's, :655)
     uint32_t max_attempts; // stop after this many attempts (0 = unlimited up to capacity)
     uint32_t stop_at_header; // probe mode
+    int64_t  probe_limit;  // > scan_limit: having reached scan_limit, the job goes on as its successor's probe (stop at the
+                           // next header, no new DETECT step at pos >= probe_limit) and reports that part as the "tail"; 0: off
 };
 
 struct AttemptRec {
@@ -94,6 +96,10 @@ struct JobResult {
     uint32_t pad;
     uint32_t cyc[6];       // shader clocks / 64 spent per state (DETECT, SYNC, FIND_SFD, PAUSE, HEADER, PAYLOAD); walker2 only
     uint32_t rounds[6];    // rounds per state
+    // tail probe (Job.probe_limit): what a separate probe job started from this job's end state would have reported
+    int64_t  tail_final_pos;
+    uint32_t tail_valid, tail_first_rec, tail_n_attempts, tail_final_cr, tail_npush, tail_stop_reason, tail_pad, tail_rsv;
+    float    tail_push_tail[4];
     uint32_t ctl[4];       // control wavefront inside decode rounds, shader clocks / 64: state copy-in, symbol loop, plan, copy-out
 };
 

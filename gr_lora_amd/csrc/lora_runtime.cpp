@@ -286,6 +286,16 @@ lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vec
         for (uint32_t j = 0; j < nj; j++) for (int i = 0; i < 6; i++) { cyc[i] += 64.0 * out.res[j].cyc[i]; rnd[i] += out.res[j].rounds[i]; }
         fprintf(stderr, "[lora_hip] per-job avg kcycles (rounds): DETECT %.0f (%.1f) SYNC %.0f (%.1f) SFD %.0f (%.1f) PAUSE %.0f (%.1f) HDR %.0f (%.1f) PAYLOAD %.0f (%.1f)\n",
                 cyc[0] / nj / 1e3, rnd[0] / nj, cyc[1] / nj / 1e3, rnd[1] / nj, cyc[2] / nj / 1e3, rnd[2] / nj, cyc[3] / nj / 1e3, rnd[3] / nj, cyc[4] / nj / 1e3, rnd[4] / nj, cyc[5] / nj / 1e3, rnd[5] / nj);
+        {
+            double na = 0, nt = 0, ntv = 0; uint32_t sr[4] = {0, 0, 0, 0}, tsr[4] = {0, 0, 0, 0}, tpad = 0;
+            for (uint32_t j = 0; j < nj; j++) {
+                const JobResult &r = out.res[j];
+                na += r.n_attempts; sr[r.stop_reason & 3u]++;
+                if (r.tail_valid) { ntv++; nt += r.tail_n_attempts; tsr[r.tail_stop_reason & 3u]++; tpad += r.tail_pad; }
+            }
+            fprintf(stderr, "[lora_hip] attempts/job %.2f, stop reasons %u/%u/%u/%u; tails %.0f (attempts/tail %.2f, stop reasons %u/%u/%u/%u, pending %u)\n", na / nj, sr[0], sr[1],
+                    sr[2], sr[3], ntv, ntv ? nt / ntv : 0.0, tsr[0], tsr[1], tsr[2], tsr[3], tpad);
+        }
         double ctl[4] = {0};
         for (uint32_t j = 0; j < nj; j++) for (int i = 0; i < 4; i++) ctl[i] += 64.0 * out.res[j].ctl[i];
         fprintf(stderr, "[lora_hip] control wavefront per job, kcycles: copy-in %.0f loop %.0f plan %.0f copy-out %.0f\n", ctl[0] / nj / 1e3, ctl[1] / nj / 1e3, ctl[2] / nj / 1e3, ctl[3] / nj / 1e3);
@@ -298,7 +308,7 @@ lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vec
     }
     // copy back only the attempt records that were written
     uint32_t max_att = 0;
-    for (uint32_t j = 0; j < nj; j++) max_att = std::max(max_att, out.res[j].n_attempts);
+    for (uint32_t j = 0; j < nj; j++) max_att = std::max(max_att, out.res[j].n_attempts + (out.res[j].tail_valid ? out.res[j].tail_n_attempts : 0u));
     if (max_att > recs_per_job) max_att = recs_per_job;
     out.recs.resize((size_t)nj * recs_per_job);
     if (max_att) {

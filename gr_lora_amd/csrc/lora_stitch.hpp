@@ -101,6 +101,15 @@ int run_serial(Env &env, StreamDesc &sd, Cursor &cur, int64_t limit, bool tracin
         int s = env.run_jobs(jobs, rpj, trace_cap, out);
         if (s != 0) return s;
         const JobResult &jr = out.res[0];
+        if (getenv("LORA_HIP_DEBUG_JOBS")) {
+            fprintf(stderr, "[serial] start %lld limit %lld cr %u | final_pos %lld cr %u n_att %u stop %u pad %u npush %u\n", (long long)j.start, (long long)j.scan_limit, j.cr_prev,
+                    (long long)jr.final_pos, jr.final_cr, jr.n_attempts, jr.stop_reason, jr.pad, jr.npush);
+            for (uint32_t a = 0; a < jr.n_attempts && a < rpj; a++) {
+                const AttemptRec &t = out.rec(0, a);
+                fprintf(stderr, "[serial]    rec %u status %u start %lld trig %lld hdr %lld end %lld nsym %u npush %u\n", a, t.status, (long long)t.start_pos, (long long)t.trig_pos, (long long)t.hdr_pos,
+                        (long long)t.end_pos, t.n_symbols, t.npush);
+            }
+        }
         for (uint32_t a = 0; a < out.n_done(0); a++) adopt(env, out.rec(0, a), sd);
         if (tracing) env.append_trace(out, 0, trace_cap, sd.abs_base);
         cur.cr = jr.final_cr;
@@ -118,8 +127,12 @@ inline int cr_class(uint32_t cr) { return cr >= 3u ? 2 : (cr >= 1u ? 1 : 0); }
 // Every stream is cut into fixed segments.  Round 1 runs one walker job per
 // segment, each starting in DETECT at its segment boundary (a guess: the true
 // decoder arrives there with some other window phase and possibly mid-packet).
-// Round 2 runs, for every segment, a probe that starts from the END state of the
+// Round 2 is, for every segment, a probe that starts from the END state of the
 // preceding segment's job and walks DETECT/SYNC/FIND_SFD up to the first header.
+// Normally the preceding job has run it itself (Job.probe_limit: having reached its
+// own limit it carries on as that probe and reports it as its "tail"); a separate
+// probe job is launched only where no such tail exists (header-less segments in
+// between, kernels without the feature).
 // The host then stitches: if the probe enters DECODE_HEADER at the same sample
 // as one of the segment job's attempts, the two trajectories are identical from
 // there on (the decoder state at header entry is position + d_phdr.cr), and the
@@ -165,9 +178,14 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
         j.stream_off = sd.off; j.stream_len = sd.len; j.start = segs[k].b0; j.scan_limit = segs[k].b1;
         j.stream_id = sd.id; j.cr_prev = (k == first_seg[segs[k].stream]) ? sd.cr_in : env.ctor_cr();
         j.max_attempts = 0; j.stop_at_header = 0;
+        // tail probe: past its own limit the job continues as the next segment's probe (same limit an explicit probe gets)
+        const bool has_next = k + 1 < segs.size() && segs[k + 1].stream == segs[k].stream;
+        static const bool no_tail = getenv("LORA_HIP_NO_TAIL") != nullptr; // diagnostics: separate probe jobs, as the generic kernels need
+        j.probe_limit = (segmenting && has_next && !no_tail) ? std::min<int64_t>((int64_t)sd.len, segs[k + 1].b1 + 16ll * sps) : 0;
         max_span = std::max<uint64_t>(max_span, (uint64_t)(segs[k].b1 - segs[k].b0));
     }
-    const uint32_t rpj1 = recs_for(max_span, sps);
+    const uint32_t rpj2 = 8;
+    const uint32_t rpj1 = recs_for(max_span, sps) + (segmenting ? rpj2 : 0u);
     const uint32_t trace_cap = tracing ? (uint32_t)std::min<uint64_t>(2ull * (max_span / sps) + 64ull, 1ull << 22) : 0u;
     RunOut R1;
     env.count_jobs((uint32_t)jobs.size());
@@ -176,7 +194,20 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
     int s = env.run_jobs(jobs, rpj1, trace_cap, R1);
     if (s != 0) return s;
     const auto tp1 = std::chrono::steady_clock::now();
-
+    if (getenv("LORA_HIP_DEBUG_JOBS")) { // diagnostics: every segment job's result, comparable between the device and the CPU simulation
+        for (size_t k = 0; k < jobs.size(); k++) {
+            const JobResult &r = R1.res[k];
+            fprintf(stderr, "[job] %zu start %lld limit %lld probe_limit %lld | final_pos %lld cr %u n_att %u stop %u pad %u npush %u | tail %u: first %u n_att %u final_pos %lld cr %u stop %u pad %u npush %u\n",
+                    k, (long long)jobs[k].start, (long long)jobs[k].scan_limit, (long long)jobs[k].probe_limit, (long long)r.final_pos, r.final_cr, r.n_attempts, r.stop_reason, r.pad,
+                    r.npush, r.tail_valid, r.tail_first_rec, r.tail_n_attempts, (long long)r.tail_final_pos, r.tail_final_cr, r.tail_stop_reason, r.tail_pad, r.tail_npush);
+            const uint32_t n = r.n_attempts + (r.tail_valid ? r.tail_n_attempts : 0u);
+            for (uint32_t a = 0; a < n && a < rpj1; a++) {
+                const AttemptRec &t = R1.rec(k, a);
+                fprintf(stderr, "[job]    rec %u status %u start %lld trig %lld hdr %lld end %lld nsym %u npush %u cr_prev %u ambig %u len %u\n", a, t.status, (long long)t.start_pos,
+                        (long long)t.trig_pos, (long long)t.hdr_pos, (long long)t.end_pos, t.n_symbols, t.npush, t.cr_prev, t.hdr_ambig, t.frame_len);
+            }
+        }
+    }
     // ---- round 2: probes along the speculative chain.  Only segments whose own job
     // reached a header get a probe; it starts from the end state of the previous
     // header-bearing job and scans through any header-less segments in between.
@@ -189,7 +220,7 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
         return false;
     };
     auto job_ok = [&](size_t k) { return !R1.res[k].pad && R1.res[k].stop_reason != 2u; };
-    struct Probe { uint32_t stream; size_t target; Cursor start; int job; };
+    struct Probe { uint32_t stream; size_t target; Cursor start; int job; int tail_of; }; // job: index into pjobs, or -1 with tail_of = the job whose tail it is
     std::vector<Probe> probes;
     std::vector<size_t> first_probe(streams.size() + 1, 0);
     std::vector<Job> pjobs;
@@ -200,11 +231,16 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
         const StreamDesc &sd = streams[i];
         bool chain = job_ok(f), pending = false;
         Cursor cur{R1.res[f].final_pos, R1.res[f].final_cr};
+        size_t cur_job = f; // the job whose end state `cur` is
         auto add_probe = [&](size_t target, int64_t limit) {
+            if (R1.res[cur_job].tail_valid && jobs[cur_job].probe_limit == limit) { // that job has already run this probe
+                probes.push_back(Probe{(uint32_t)i, target, cur, -1, (int)cur_job});
+                return;
+            }
             Job j{};
             j.stream_off = sd.off; j.stream_len = sd.len; j.start = cur.pos; j.scan_limit = limit;
             j.stream_id = sd.id; j.cr_prev = cur.cr; j.max_attempts = 0; j.stop_at_header = 1;
-            probes.push_back(Probe{(uint32_t)i, target, cur, (int)pjobs.size()});
+            probes.push_back(Probe{(uint32_t)i, target, cur, (int)pjobs.size(), -1});
             pjobs.push_back(j);
         };
         for (size_t k = f + 1; k < e && chain; k++) {
@@ -213,18 +249,54 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
             add_probe(k, std::min<int64_t>((int64_t)sd.len, segs[k].b1 + 16ll * sps));
             chain = job_ok(k);
             cur = Cursor{R1.res[k].final_pos, R1.res[k].final_cr};
+            cur_job = k;
             pending = false;
         }
         if (chain && pending) add_probe(e - 1, (int64_t)sd.len); // header-less tail still has to be walked
     }
     first_probe[streams.size()] = probes.size();
     RunOut R2;
-    const uint32_t rpj2 = 8;
     if (!pjobs.empty()) {
         env.count_probes((uint32_t)pjobs.size());
         s = env.run_jobs(pjobs, rpj2, 0, R2);
         if (s != 0) return s;
     }
+    if (getenv("LORA_HIP_DEBUG_JOBS")) {
+        for (size_t k = 0; k < pjobs.size(); k++) {
+            const JobResult &r = R2.res[k];
+            fprintf(stderr, "[probe] %zu start %lld limit %lld cr %u | final_pos %lld cr %u n_att %u stop %u pad %u npush %u\n", k, (long long)pjobs[k].start, (long long)pjobs[k].scan_limit,
+                    pjobs[k].cr_prev, (long long)r.final_pos, r.final_cr, r.n_attempts, r.stop_reason, r.pad, r.npush);
+            for (uint32_t a = 0; a < r.n_attempts && a < rpj2; a++) {
+                const AttemptRec &t = R2.rec(k, a);
+                fprintf(stderr, "[probe]    rec %u status %u start %lld trig %lld hdr %lld end %lld nsym %u npush %u cr_prev %u ambig %u\n", a, t.status, (long long)t.start_pos, (long long)t.trig_pos,
+                        (long long)t.hdr_pos, (long long)t.end_pos, t.n_symbols, t.npush, t.cr_prev, t.hdr_ambig);
+            }
+        }
+    }
+    // one view per probe, whether it ran as its own job or as the tail of the preceding segment's job
+    struct ProbeView { JobResult res; const AttemptRec *recs; uint32_t cap; int64_t limit; };
+    std::vector<ProbeView> pv(probes.size());
+    for (size_t q = 0; q < probes.size(); q++) {
+        ProbeView &v = pv[q];
+        if (probes[q].job >= 0) {
+            const size_t pj = (size_t)probes[q].job;
+            v.res = R2.res[pj]; v.recs = &R2.recs[pj * rpj2]; v.cap = rpj2; v.limit = pjobs[pj].scan_limit;
+        } else {
+            const size_t tj = (size_t)probes[q].tail_of;
+            const JobResult &jr = R1.res[tj];
+            v.res = JobResult{};
+            v.res.final_pos = jr.tail_final_pos; v.res.n_attempts = jr.tail_n_attempts; v.res.final_cr = jr.tail_final_cr;
+            v.res.npush = jr.tail_npush;
+            for (int t = 0; t < 4; t++) v.res.push_tail[t] = jr.tail_push_tail[t];
+            v.res.stop_reason = jr.tail_stop_reason; v.res.pad = jr.tail_pad;
+            const uint32_t first = std::min(jr.tail_first_rec, rpj1);
+            v.recs = &R1.recs[tj * rpj1 + first]; v.cap = rpj1 - first; v.limit = jobs[tj].probe_limit;
+        }
+    }
+    auto pv_done = [&](const ProbeView &v) { // attempts that ran to completion (cf. RunOut::n_done)
+        const uint32_t n = v.res.pad ? v.res.n_attempts - 1u : v.res.n_attempts;
+        return n < v.cap ? n : v.cap;
+    };
 
     const auto tp2 = std::chrono::steady_clock::now();
     // ---- stitch, stream by stream, in stream order
@@ -259,21 +331,26 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
                 if (s != 0) return s;
                 continue;
             }
-            const size_t pj = (size_t)pb.job;
-            const JobResult &pr = R2.res[pj];
+            const ProbeView &view = pv[q];
+            const JobResult &pr = view.res;
             // lost-sync attempts the true trajectory went through before the header
-            for (uint32_t a = 0; a < R2.n_done(pj); a++) adopt(env, R2.rec(pj, a), sd);
+            for (uint32_t a = 0; a < pv_done(view); a++) adopt(env, view.recs[a], sd);
             if (!pr.pad) { // no header before the probe's limit
                 cur = Cursor{pr.final_pos, pr.final_cr};
                 sd.pwr.apply(pr.npush, pr.push_tail);
-                covered = std::max(covered, std::min<int64_t>(pjobs[pj].scan_limit, b1));
+                covered = std::max(covered, std::min<int64_t>(view.limit, b1));
                 if (pr.stop_reason == 2u || (cur.pos < b1 && cur.pos + 2 * (int64_t)sps <= (int64_t)sd.len)) {
                     s = serial_to(b1, "probe ended without a header");
                     if (s != 0) return s;
                 }
                 continue;
             }
-            const AttemptRec &L = R2.rec(pj, std::min(pr.n_attempts, rpj2) - 1u);
+            if (pr.n_attempts > view.cap) { // the pending attempt's record did not fit
+                s = serial_to(b1, "probe out of records");
+                if (s != 0) return s;
+                continue;
+            }
+            const AttemptRec &L = view.recs[pr.n_attempts - 1u];
             if (L.status != kAttemptAtHeader) { // ran out of data before reaching a header
                 cur.pos = L.start_pos;
                 sd.incomplete = true;
@@ -294,6 +371,16 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
                 }
             }
             if (match < 0) {
+                if (dbg) {
+                    fprintf(stderr, "[lora_hip] probe for segment %zu [%lld, %lld): start %lld cr %u -> trig %lld hdr %lld\n", pb.target, (long long)segs[pb.target].b0, (long long)segs[pb.target].b1,
+                            (long long)pb.start.pos, pb.start.cr, (long long)L.trig_pos, (long long)L.hdr_pos);
+                    for (size_t k = pb.target ? pb.target - 1 : 0; k <= pb.target; k++)
+                        for (uint32_t a = 0; a < std::min(R1.res[k].n_attempts, rpj1); a++) {
+                            const AttemptRec &r = R1.rec(k, a);
+                            fprintf(stderr, "[lora_hip]    job %zu [%lld, %lld) rec %u status %u start %lld trig %lld hdr %lld end %lld\n", k, (long long)segs[k].b0, (long long)segs[k].b1, a, r.status,
+                                    (long long)r.start_pos, (long long)r.trig_pos, (long long)r.hdr_pos, (long long)r.end_pos);
+                        }
+                }
                 cur = Cursor{L.start_pos, L.cr_prev};
                 s = serial_to(b1, "no segment job entered the same header");
                 if (s != 0) return s;
@@ -332,8 +419,8 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
     if (dbg_t) {
         const auto tp3 = std::chrono::steady_clock::now();
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        fprintf(stderr, "[lora_hip] round1 %.3f ms (%zu jobs, rpj %u), round2 %.3f ms (%zu probes), stitch %.3f ms, walker %.3f ms\n",
-                ms(tp0, tp1), jobs.size(), rpj1, ms(tp1, tp2), pjobs.size(), ms(tp2, tp3), env.walker_ms());
+        fprintf(stderr, "[lora_hip] round1 %.3f ms (%zu jobs, rpj %u), round2 %.3f ms (%zu probe jobs, %zu tail probes), stitch %.3f ms, walker %.3f ms\n",
+                ms(tp0, tp1), jobs.size(), rpj1, ms(tp1, tp2), pjobs.size(), probes.size() - pjobs.size(), ms(tp2, tp3), env.walker_ms());
     }
     return 0;
 }

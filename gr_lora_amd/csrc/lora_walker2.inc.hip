@@ -721,6 +721,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         jr.stop_reason = (uint32_t)S.stop_reason;
         jr.n_steps = S.n_steps < C.trace_cap ? S.n_steps : C.trace_cap;
         jr.pad = in_attempt ? 1u : 0u;
+        jr.tail_valid = 0; // Job.probe_limit is not implemented by this kernel: the host launches explicit probe jobs
         W2Stats &Q = W.stats;
         if (Q.prev_state >= 0) { Q.cyc[Q.prev_state] += (uint32_t)((clock64() - Q.prev_t) >> 6); Q.rounds[Q.prev_state]++; }
         for (int i = 0; i < 6; i++) { jr.cyc[i] = Q.cyc[i]; jr.rounds[i] = Q.rounds[i]; }

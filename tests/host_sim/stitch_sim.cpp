@@ -18,7 +18,8 @@ struct SimEnv {
     size_t n_items;
     uint32_t sps_, ctor_cr_, seg_symbols, slots;
     std::vector<SimFrame> frames;
-    uint32_t n_jobs = 0, n_probes = 0, n_slow = 0;
+    uint32_t n_jobs = 0, n_probes = 0, n_slow = 0, n_tails = 0;
+    bool tail_probes = true; // emulate Job.probe_limit (walker2); false: the generic kernels' behaviour (explicit probe jobs only)
 
     uint32_t sps() const { return sps_; }
     uint32_t ctor_cr() const { return ctor_cr_; }
@@ -32,6 +33,16 @@ struct SimEnv {
         out.res.assign(jobs.size(), JobResult{});
         out.recs.assign(jobs.size() * (size_t)rpj, AttemptRec{});
         std::vector<oracle_attempt_t> tmp(rpj + 1);
+        auto put_recs = [&](size_t j, uint32_t first, uint32_t n) {
+            for (uint32_t a = 0; a < n && first + a < rpj; a++) {
+                AttemptRec &d = out.recs[j * (size_t)rpj + first + a];
+                const oracle_attempt_t &s = tmp[a];
+                d.start_pos = s.start_pos; d.trig_pos = s.trig_pos; d.hdr_pos = s.hdr_pos; d.end_pos = s.end_pos;
+                d.status = s.status; d.npush = s.npush; std::memcpy(d.push_tail, s.push_tail, sizeof d.push_tail);
+                d.cr_prev = s.cr_prev; d.hdr_ambig = s.hdr_ambig; d.frame_len = s.frame_len; d.n_symbols = s.n_symbols;
+                std::memcpy(d.frame, s.frame, s.frame_len);
+            }
+        };
         for (size_t j = 0; j < jobs.size(); j++) {
             const Job &jb = jobs[j];
             oracle_job_result_t r{};
@@ -41,13 +52,18 @@ struct SimEnv {
             jr.final_pos = r.final_pos; jr.n_attempts = r.n_attempts; jr.final_cr = r.final_cr; jr.npush = r.npush;
             std::memcpy(jr.push_tail, r.push_tail, sizeof jr.push_tail);
             jr.stop_reason = r.stop_reason; jr.pad = r.pad;
-            for (uint32_t a = 0; a < r.n_attempts && a < rpj; a++) {
-                AttemptRec &d = out.recs[j * (size_t)rpj + a];
-                const oracle_attempt_t &s = tmp[a];
-                d.start_pos = s.start_pos; d.trig_pos = s.trig_pos; d.hdr_pos = s.hdr_pos; d.end_pos = s.end_pos;
-                d.status = s.status; d.npush = s.npush; std::memcpy(d.push_tail, s.push_tail, sizeof d.push_tail);
-                d.cr_prev = s.cr_prev; d.hdr_ambig = s.hdr_ambig; d.frame_len = s.frame_len; d.n_symbols = s.n_symbols;
-                std::memcpy(d.frame, s.frame, s.frame_len);
+            put_recs(j, 0, r.n_attempts);
+            // tail probe, with the device's semantics: having reached its scan limit the job goes on as a fresh probe job
+            if (tail_probes && jb.probe_limit > jb.scan_limit && r.stop_reason == 0u && !r.pad) {
+                oracle_job_result_t t{};
+                const uint32_t first = r.n_attempts, cap = rpj > first ? rpj - first : 0u;
+                lora_oracle_run_job(o, iq + 2 * jb.stream_off, (size_t)jb.stream_len, r.final_pos, jb.probe_limit, r.final_cr, 0, 1, cap,
+                                    tmp.data(), &t);
+                jr.tail_valid = 1; jr.tail_first_rec = first; jr.tail_final_pos = t.final_pos; jr.tail_n_attempts = t.n_attempts;
+                jr.tail_final_cr = t.final_cr; jr.tail_npush = t.npush; std::memcpy(jr.tail_push_tail, t.push_tail, sizeof jr.tail_push_tail);
+                jr.tail_stop_reason = t.stop_reason; jr.tail_pad = t.pad;
+                put_recs(j, first, t.n_attempts);
+                n_tails++;
             }
         }
         return 0;
@@ -70,12 +86,13 @@ struct SimEnv {
 } // namespace
 
 extern "C" int stitch_sim_decode(const float *iq, size_t n_items, int sf, int ctor_cr, int crc, int reduced_rate, int demod,
-                                 uint32_t segment_symbols, uint32_t resident_slots, uint8_t *out, size_t cap, int *lens,
+                                 uint32_t segment_symbols, uint32_t resident_slots, int tail_probes, uint8_t *out, size_t cap, int *lens,
                                  long long *hdr_pos, int max_frames, uint32_t *stats)
 {
     lora_oracle_t *o = lora_oracle_create(1e6f, 125000, (uint8_t)sf, 0, (uint8_t)ctor_cr, crc, reduced_rate, 0, demod);
     if (!o) return -1;
     SimEnv env{o, iq, n_items, lora_oracle_sps(o), (uint32_t)ctor_cr, segment_symbols, resident_slots};
+    env.tail_probes = tail_probes != 0;
     std::vector<StreamDesc> sds(1);
     sds[0].off = 0; sds[0].len = n_items; sds[0].id = 0; sds[0].cr_in = (uint32_t)ctor_cr; sds[0].abs_base = 0;
     const int rc = decode_streams(env, sds);
@@ -88,6 +105,6 @@ extern "C" int stitch_sim_decode(const float *iq, size_t n_items, int sf, int ct
         std::memcpy(out + used, f.blob.data(), f.blob.size());
         lens[n] = (int)f.blob.size(); hdr_pos[n] = f.hdr_pos; used += f.blob.size(); n++;
     }
-    stats[0] = env.n_jobs; stats[1] = env.n_probes; stats[2] = env.n_slow; stats[3] = sds[0].incomplete ? 1u : 0u;
+    stats[0] = env.n_jobs; stats[1] = env.n_probes; stats[2] = env.n_slow; stats[3] = sds[0].incomplete ? 1u : 0u; stats[4] = env.n_tails;
     return n;
 }

@@ -25,23 +25,23 @@ def sim(oracle_mod):
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-o", SIM_LIB, src, "-L", os.path.join(ROOT, "oracle"),
                                "-llora_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
     L = C.CDLL(SIM_LIB)
-    L.stitch_sim_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
+    L.stitch_sim_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int,
                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
 
-    def run(iq, sf, ctor_cr=4, demod=2, reduced=False, seg=0, slots=512):
+    def run(iq, sf, ctor_cr=4, demod=2, reduced=False, seg=0, slots=512, tails=True):
         a = np.ascontiguousarray(iq, dtype=np.complex64)
         out = np.zeros(1 << 20, dtype=np.uint8)
         lens = np.zeros(4096, dtype=np.int32)
         hp = np.zeros(4096, dtype=np.int64)
-        st = np.zeros(4, dtype=np.uint32)
-        n = L.stitch_sim_decode(a.ctypes.data, a.size, sf, ctor_cr, 1, int(reduced), demod, seg, slots, out.ctypes.data, out.size,
+        st = np.zeros(8, dtype=np.uint32)
+        n = L.stitch_sim_decode(a.ctypes.data, a.size, sf, ctor_cr, 1, int(reduced), demod, seg, slots, int(tails), out.ctypes.data, out.size,
                                 lens.ctypes.data, hp.ctypes.data, 4096, st.ctypes.data)
         assert n >= 0, n
         frames, off = [], 0
         for i in range(n):
             frames.append(bytes(out[off:off + lens[i]]))
             off += int(lens[i])
-        return frames, hp[:n].tolist(), dict(jobs=int(st[0]), probes=int(st[1]), slow=int(st[2]), incomplete=int(st[3]))
+        return frames, hp[:n].tolist(), dict(jobs=int(st[0]), probes=int(st[1]), slow=int(st[2]), incomplete=int(st[3]), tails=int(st[4]))
     return run
 
 
@@ -51,8 +51,9 @@ def _serial(O, iq, sf, ctor_cr=4, demod=2, reduced=False):
     return o.frames(), o.frame_positions()
 
 
+@pytest.mark.parametrize("tails", [True, False])
 @pytest.mark.parametrize("seg", [16, 23, 40, 64, 150, 0])
-def test_segmented_equals_serial(sim, oracle_mod, seg):
+def test_segmented_equals_serial(sim, oracle_mod, seg, tails):
     cfg = synth.TxConfig(sf=7, cr=4)
     rng = np.random.default_rng(900 + seg)
     payloads = [bytes(rng.integers(0, 256, int(rng.integers(1, 48)), dtype=np.uint8)) for _ in range(30)]
@@ -60,10 +61,13 @@ def test_segmented_equals_serial(sim, oracle_mod, seg):
     gaps[5] = 0; gaps[6] = 1; gaps[7] = cfg.sps // 2; gaps[8] = 2 * cfg.sps + 3
     st = synth.build_stream(payloads, cfg, gaps=gaps)
     want, wpos = _serial(oracle_mod, st.iq, 7)
-    got, gpos, stats = sim(st.iq, 7, seg=seg, slots=40)
+    got, gpos, stats = sim(st.iq, 7, seg=seg, slots=40, tails=tails)
     assert got == want and gpos == wpos
     assert stats["jobs"] >= (st.iq.size // (seg * cfg.sps) if seg else 2)
-    assert stats["probes"] > 0
+    if tails: # the probes ride on the segment jobs; explicit probe jobs only across header-less segments
+        assert stats["tails"] > 0 and stats["probes"] <= stats["tails"]
+    else:
+        assert stats["probes"] > 0 and stats["tails"] == 0
 
 
 def test_fast_path_dominates_on_regular_traffic(sim, oracle_mod):
@@ -86,8 +90,9 @@ def test_noise_and_stale_cr_carry(sim, oracle_mod, sf, cr, noise_db):
     st = synth.build_stream(payloads, cfg, rng=rng, noise_sigma=(10 ** (noise_db / 20.0) if noise_db else 0.0))
     want, wpos = _serial(oracle_mod, st.iq, sf)
     for seg in (20, 57):
-        got, gpos, _ = sim(st.iq, sf, seg=seg)
-        assert got == want and gpos == wpos
+        for tails in (True, False):
+            got, gpos, _ = sim(st.iq, sf, seg=seg, tails=tails)
+            assert got == want and gpos == wpos
 
 
 def test_gradient_mode_and_truncated_stream(sim, oracle_mod):
