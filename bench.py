@@ -110,8 +110,8 @@ def main():
 
     def step():
         h.decode_device(d_iq.data_ptr(), n_items, offs, lens, stream)
-        buf, infos = h.drain_raw()
-        slots, counts = gather.gather_raw(buf, infos, dev)   # RCCL all_gather of the frames when N > 1
+        mine = h.drain_slots(gather.SLOT_BYTES)              # frames straight into the exchange layout
+        slots, counts = gather.gather_slots(mine, dev)       # RCCL all_gather of the frames when N > 1
         return slots, counts
 
     # correctness of what is being timed (outside the timed region): frames as gathered, this rank's share

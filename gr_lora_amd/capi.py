@@ -20,7 +20,7 @@ FLAG_TRACE = 1
 EXPORTS = [
     "lora_hip_abi_version", "lora_hip_strerror", "lora_hip_last_error", "lora_hip_create", "lora_hip_destroy",
     "lora_hip_get_geometry", "lora_hip_set_sf", "lora_hip_set_samp_rate", "lora_hip_work", "lora_hip_flush",
-    "lora_hip_decode_device", "lora_hip_frames_available", "lora_hip_poll_frame", "lora_hip_drain_frames", "lora_hip_demod_symbols_device", "lora_hip_demod_symbols_ex_device",
+    "lora_hip_decode_device", "lora_hip_frames_available", "lora_hip_poll_frame", "lora_hip_drain_frames", "lora_hip_drain_slots", "lora_hip_demod_symbols_device", "lora_hip_demod_symbols_ex_device",
     "lora_hip_last_timing", "lora_hip_trace", "lora_hip_trace_clear",
 ]
 
@@ -93,6 +93,7 @@ def load():
     L.lora_hip_frames_available.argtypes = [vp]
     L.lora_hip_poll_frame.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(FrameInfo)]
     L.lora_hip_drain_frames.argtypes = [vp, vp, C.c_size_t, C.POINTER(FrameInfo), C.c_size_t, C.POINTER(C.c_size_t)]
+    L.lora_hip_drain_slots.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t)]
     L.lora_hip_demod_symbols_device.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int, vp, vp]
     L.lora_hip_demod_symbols_ex_device.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int, vp, vp, vp]
     L.lora_hip_last_timing.argtypes = [vp, C.POINTER(Timing)]
@@ -223,6 +224,14 @@ class Handle:
         if not bufs:
             return np.empty(0, dtype=np.uint8), np.empty(0, dtype=self.INFO_DTYPE)
         return np.concatenate(bufs), np.concatenate(infos)
+
+    def drain_slots(self, slot_bytes: int) -> np.ndarray:
+        """All queued frames as fixed-size slots uint8[n, slot_bytes]: u32 stream | u32 length | i64 header_pos | blob | zeros."""
+        n_avail = self.frames_available()
+        out = np.empty((max(n_avail, 1), slot_bytes), dtype=np.uint8)
+        n = C.c_size_t(0)
+        self._check(self.L.lora_hip_drain_slots(self.h, out.ctypes.data, slot_bytes, n_avail, C.byref(n)))
+        return out[: n.value]
 
     def timing(self) -> Timing:
         t = Timing()

@@ -29,9 +29,45 @@ namespace {
 constexpr int kLoratapLen = 15; // sizeof(loratap_header_t), include/lora/loratap.h:35-55
 constexpr uint32_t kWorkBudget = 64u * 1024u + 64u; // LDS work area cap (bytes)
 
-struct Frame {
-    std::vector<uint8_t> blob;
-    lora_hip_frame_info_t info;
+// Published frames wait here for poll/drain: blobs back to back in one byte arena (no allocation per frame).
+struct FrameQueue {
+    struct Ref { size_t off; lora_hip_frame_info_t info; };
+    std::vector<uint8_t> bytes;
+    std::vector<Ref> refs;
+    size_t head = 0; // first frame not yet handed out
+    size_t size() const { return refs.size() - head; }
+    bool empty() const { return head == refs.size(); }
+    uint8_t *push(uint32_t len, const lora_hip_frame_info_t &info)
+    {
+        const size_t off = bytes.size();
+        bytes.resize(off + len, 0);
+        refs.push_back(Ref{off, info});
+        return bytes.data() + off;
+    }
+    const Ref &front() const { return refs[head]; }
+    const uint8_t *front_bytes() const { return bytes.data() + refs[head].off; }
+    void pop()
+    {
+        if (++head == refs.size()) { refs.clear(); bytes.clear(); head = 0; }
+    }
+};
+
+// Page-locked host staging buffer, grown on demand.
+template <typename T>
+struct PinnedBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = n + n / 4 + 16;
+        hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
 
 // loratap_header.rssi.snr = (uint8_t)(10.0f * log10(d_snr) + 0.5) (:597).  The
@@ -84,7 +120,10 @@ struct lora_hip_decoder {
     std::vector<StepRec> h_trace;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // outputs
-    std::deque<Frame> frames;
+    FrameQueue frames;
+    PinnedBuf<Job> p_jobs;             // staging for run_jobs: jobs up, results and the first attempt records down
+    PinnedBuf<JobResult> p_res;
+    PinnedBuf<AttemptRec> p_recs;
     std::vector<lora_hip_step_t> trace;
     lora_hip_timing_t timing{};
     std::string err;
@@ -245,15 +284,14 @@ lora_hip_status build_tables(lora_hip_decoder *h)
 // Publishes the frame of one completed attempt (msg_lora_frame, :588-609).
 void publish(lora_hip_decoder *h, const AttemptRec &r, StreamDesc &sd)
 {
-    Frame f;
-    f.blob.assign((size_t)kLoratapLen + r.frame_len, 0);
-    f.blob[13] = snr_byte(sd.pwr.snr); // loratap_header.rssi.snr, byte offset 13
-    std::memcpy(f.blob.data() + kLoratapLen, r.frame, r.frame_len);
-    f.info.stream = sd.id;
-    f.info.length = (uint32_t)f.blob.size();
-    f.info.header_pos = sd.abs_base + r.hdr_pos;
-    f.info.end_pos = sd.abs_base + r.end_pos;
-    h->frames.push_back(std::move(f));
+    lora_hip_frame_info_t info;
+    info.stream = sd.id;
+    info.length = (uint32_t)kLoratapLen + r.frame_len;
+    info.header_pos = sd.abs_base + r.hdr_pos;
+    info.end_pos = sd.abs_base + r.end_pos;
+    uint8_t *blob = h->frames.push(info.length, info); // zero-filled loratap header
+    blob[13] = snr_byte(sd.pwr.snr);                   // loratap_header.rssi.snr, byte offset 13
+    std::memcpy(blob + kLoratapLen, r.frame, r.frame_len);
 }
 
 // Runs the walker over a set of jobs and brings results back to the host.
@@ -271,7 +309,13 @@ lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vec
     const bool need_scratch = !h->P.ifreq_in_lds_2;
     if (need_scratch) HIP_TRY(h, h->d_scratch.reserve((size_t)nj * 2u * h->P.sps));
     if (trace_cap) HIP_TRY(h, h->d_trace.reserve((size_t)nj * trace_cap));
-    HIP_TRY(h, hipMemcpyAsync(h->d_jobs.p, jobs.data(), nj * sizeof(Job), hipMemcpyHostToDevice, st));
+    constexpr uint32_t kEagerRecs = 4; // attempt records per job fetched together with the results (most jobs have <= 4)
+    const uint32_t eager = std::min(kEagerRecs, recs_per_job);
+    HIP_TRY(h, h->p_jobs.reserve(nj));
+    HIP_TRY(h, h->p_res.reserve(nj));
+    HIP_TRY(h, h->p_recs.reserve((size_t)nj * eager));
+    std::memcpy(h->p_jobs.p, jobs.data(), nj * sizeof(Job));
+    HIP_TRY(h, hipMemcpyAsync(h->d_jobs.p, h->p_jobs.p, nj * sizeof(Job), hipMemcpyHostToDevice, st));
     LaunchCfg c{};
     c.iq = d_iq; c.jobs = h->d_jobs.p; c.results = h->d_results.p; c.recs = h->d_recs.p; c.recs_per_job = recs_per_job;
     c.scratch = need_scratch ? h->d_scratch.p : nullptr;
@@ -279,8 +323,11 @@ lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vec
     HIP_TRY(h, hipEventRecord(h->ev0, st));
     if (launch_walker(h->P, c, st) != 0) return fail(h, LORA_HIP_ERR_HIP, "walker launch failed: %s", hipGetErrorString(hipGetLastError()));
     HIP_TRY(h, hipEventRecord(h->ev1, st));
-    HIP_TRY(h, hipMemcpyAsync(out.res.data(), h->d_results.p, nj * sizeof(JobResult), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(h->p_res.p, h->d_results.p, nj * sizeof(JobResult), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpy2DAsync(h->p_recs.p, eager * sizeof(AttemptRec), h->d_recs.p, recs_per_job * sizeof(AttemptRec), eager * sizeof(AttemptRec), nj,
+                                hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipStreamSynchronize(st));
+    std::memcpy(out.res.data(), h->p_res.p, nj * sizeof(JobResult));
     if (getenv("LORA_HIP_DEBUG") && h->P.use_fast >= 2u) {
         double cyc[6] = {0}, rnd[6] = {0};
         for (uint32_t j = 0; j < nj; j++) for (int i = 0; i < 6; i++) { cyc[i] += 64.0 * out.res[j].cyc[i]; rnd[i] += out.res[j].rounds[i]; }
@@ -311,16 +358,20 @@ lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vec
     for (uint32_t j = 0; j < nj; j++) max_att = std::max(max_att, out.res[j].n_attempts + (out.res[j].tail_valid ? out.res[j].tail_n_attempts : 0u));
     if (max_att > recs_per_job) max_att = recs_per_job;
     out.recs.resize((size_t)nj * recs_per_job);
-    if (max_att) {
-        HIP_TRY(h, hipMemcpy2DAsync(out.recs.data(), recs_per_job * sizeof(AttemptRec), h->d_recs.p,
-                                    recs_per_job * sizeof(AttemptRec), max_att * sizeof(AttemptRec), nj,
-                                    hipMemcpyDeviceToHost, st));
+    for (uint32_t j = 0; j < nj; j++) // the eagerly fetched records
+        std::memcpy(&out.recs[(size_t)j * recs_per_job], h->p_recs.p + (size_t)j * eager, std::min(eager, max_att) * sizeof(AttemptRec));
+    bool more = false;
+    if (max_att > eager) { // rare: some job made more attempts than were fetched with the results
+        HIP_TRY(h, hipMemcpy2DAsync(out.recs.data() + eager, recs_per_job * sizeof(AttemptRec), h->d_recs.p + eager,
+                                    recs_per_job * sizeof(AttemptRec), (max_att - eager) * sizeof(AttemptRec), nj, hipMemcpyDeviceToHost, st));
+        more = true;
     }
     if (trace_cap) {
         h->h_trace.resize((size_t)nj * trace_cap);
         HIP_TRY(h, hipMemcpyAsync(h->h_trace.data(), h->d_trace.p, (size_t)nj * trace_cap * sizeof(StepRec), hipMemcpyDeviceToHost, st));
+        more = true;
     }
-    HIP_TRY(h, hipStreamSynchronize(st));
+    if (more) HIP_TRY(h, hipStreamSynchronize(st));
     float ms = 0.0f;
     HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->timing.walker_ms += ms;
@@ -441,6 +492,7 @@ void lora_hip_destroy(lora_hip_decoder_t *h)
     if (h->d_up_ifreq_v) (void)hipFree(h->d_up_ifreq_v);
     h->d_jobs.release(); h->d_results.release(); h->d_recs.release(); h->d_scratch.release();
     h->d_trace.release(); h->d_staging.release(); h->d_offsets.release(); h->d_bins.release();
+    h->p_jobs.release(); h->p_res.release(); h->p_recs.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
@@ -537,12 +589,12 @@ lora_hip_status lora_hip_poll_frame(lora_hip_decoder_t *h, uint8_t *buf, size_t 
 {
     if (!h || !len) return LORA_HIP_ERR_ARG;
     if (h->frames.empty()) { *len = 0; return LORA_HIP_OK; }
-    const Frame &f = h->frames.front();
-    *len = f.blob.size();
-    if (!buf || cap < f.blob.size()) return LORA_HIP_ERR_OVERFLOW;
-    std::memcpy(buf, f.blob.data(), f.blob.size());
+    const FrameQueue::Ref &f = h->frames.front();
+    *len = f.info.length;
+    if (!buf || cap < f.info.length) return LORA_HIP_ERR_OVERFLOW;
+    std::memcpy(buf, h->frames.front_bytes(), f.info.length);
     if (info) *info = f.info;
-    h->frames.pop_front();
+    h->frames.pop();
     return LORA_HIP_OK;
 }
 
@@ -552,13 +604,33 @@ lora_hip_status lora_hip_drain_frames(lora_hip_decoder_t *h, uint8_t *buf, size_
     if (!h || !n_frames || (max_frames && (!buf || !infos))) return LORA_HIP_ERR_ARG;
     size_t n = 0, used = 0;
     while (n < max_frames && !h->frames.empty()) {
-        const Frame &f = h->frames.front();
-        if (used + f.blob.size() > cap) break;
-        std::memcpy(buf + used, f.blob.data(), f.blob.size());
+        const FrameQueue::Ref &f = h->frames.front();
+        if (used + f.info.length > cap) break;
+        std::memcpy(buf + used, h->frames.front_bytes(), f.info.length);
         infos[n] = f.info;
-        used += f.blob.size();
+        used += f.info.length;
         n++;
-        h->frames.pop_front();
+        h->frames.pop();
+    }
+    *n_frames = n;
+    return LORA_HIP_OK;
+}
+
+lora_hip_status lora_hip_drain_slots(lora_hip_decoder_t *h, uint8_t *slots, size_t slot_bytes, size_t max_slots, size_t *n_frames)
+{
+    if (!h || !n_frames || slot_bytes < 16u || (max_slots && !slots)) return LORA_HIP_ERR_ARG;
+    size_t n = 0;
+    while (n < max_slots && !h->frames.empty()) {
+        const FrameQueue::Ref &f = h->frames.front();
+        if (16u + (size_t)f.info.length > slot_bytes) return LORA_HIP_ERR_OVERFLOW;
+        uint8_t *s = slots + n * slot_bytes;
+        std::memcpy(s, &f.info.stream, 4);
+        std::memcpy(s + 4, &f.info.length, 4);
+        std::memcpy(s + 8, &f.info.header_pos, 8);
+        std::memcpy(s + 16, h->frames.front_bytes(), f.info.length);
+        std::memset(s + 16 + f.info.length, 0, slot_bytes - 16u - f.info.length);
+        n++;
+        h->frames.pop();
     }
     *n_frames = n;
     return LORA_HIP_OK;

@@ -96,6 +96,24 @@ def gather_raw(buf: np.ndarray, infos: np.ndarray, device: torch.device, group=N
     return torch.stack(slots).cpu().numpy(), counts
 
 
+def gather_slots(mine: np.ndarray, device: torch.device, group=None):
+    """gather_raw for frames already in slot form (Handle.drain_slots(SLOT_BYTES)): no repacking on this rank."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return mine[None], [int(mine.shape[0])]
+    world = dist.get_world_size(group)
+    cnt = torch.tensor([mine.shape[0]], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(counts, cnt, group=group)
+    counts = [int(c.item()) for c in counts]
+    cap = max(1, max(counts))
+    padded = np.zeros((cap, SLOT_BYTES), dtype=np.uint8)
+    padded[: mine.shape[0]] = mine
+    t = torch.from_numpy(padded).to(device)
+    slots = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(slots, t, group=group)
+    return torch.stack(slots).cpu().numpy(), counts
+
+
 def shard_streams(n_streams: int, rank: int, world: int) -> List[int]:
     """Static partition: stream c -> rank c mod world."""
     return [c for c in range(n_streams) if c % world == rank]

@@ -146,6 +146,11 @@ lora_hip_status lora_hip_poll_frame(lora_hip_decoder_t *h, uint8_t *buf, size_t 
 lora_hip_status lora_hip_drain_frames(lora_hip_decoder_t *h, uint8_t *buf, size_t cap, lora_hip_frame_info_t *infos,
                                       size_t max_frames, size_t *n_frames);
 
+/* Pops up to max_slots frames into fixed-size slots of slot_bytes each (the layout the multi-GPU frame gather
+ * exchanges): u32 stream | u32 length | i64 header_pos | blob | zero padding.  OVERFLOW if a blob does not fit. */
+lora_hip_status lora_hip_drain_slots(lora_hip_decoder_t *h, uint8_t *slots, size_t slot_bytes, size_t max_slots,
+                                     size_t *n_frames);
+
 /* ---- symbol-level access for the +-1-bin tests (get_shift_fft :430-464, gradient :466-491) -------------- */
 /* offsets (host array, n entries): symbol start item indices into d_iq; bins_out (host, n entries):
  * the raw return value of the selected demodulator (FFT: shift s; GRAD: s-1).                              */

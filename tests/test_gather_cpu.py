@@ -27,6 +27,9 @@ def _worker(rank, world, port, q):
     mine = gather.shard_streams(7, rank, world)
     frames = [(bytes([rank, s]) * (3 + s), s, 1000 * s + rank) for s in mine]
     allf = gather.gather_frames(frames, torch.device("cpu"))
+    # the slot form bench.py exchanges (Handle.drain_slots output): same result through gather_slots
+    slots, counts = gather.gather_slots(gather.pack_frames(frames, len(frames)), torch.device("cpu"))
+    assert [gather.unpack_frames(slots[r], counts[r]) for r in range(world)] == allf
     q.put((rank, allf))
     dist.destroy_process_group()
 
@@ -70,3 +73,11 @@ def test_pack_raw_equals_pack_frames():
     assert (gather.pack_raw(buf, infos, 40) == gather.pack_frames(frames, 40)).all()
     slots, counts = gather.gather_raw(buf, infos, torch.device("cpu"))
     assert counts == [37] and gather.unpack_frames(slots[0], 37) == frames
+
+
+def test_gather_slots_single_process():
+    rng = np.random.default_rng(3)
+    frames = [(bytes(rng.integers(0, 256, int(rng.integers(18, 276)), dtype=np.uint8)), int(rng.integers(0, 8)), int(rng.integers(0, 1 << 40))) for _ in range(11)]
+    mine = gather.pack_frames(frames, len(frames))
+    slots, counts = gather.gather_slots(mine, torch.device("cpu"))
+    assert counts == [11] and gather.unpack_frames(slots[0], 11) == frames

@@ -176,6 +176,24 @@ def test_wave_demod_shift_and_fine_sync_vs_oracle(torch_cuda, oracle_mod, sf):
         h.close()
 
 
+def test_drain_slots_equals_poll(torch_cuda, oracle_mod):
+    """lora_hip_drain_slots (the exchange layout of the multi-GPU frame gather) carries the frames lora_hip_poll_frame returns."""
+    from gr_lora_amd import capi, gather
+    cfg = synth.TxConfig(sf=7, cr=4)
+    rng = np.random.default_rng(77)
+    payloads = [bytes(rng.integers(0, 256, int(rng.integers(1, 200)), dtype=np.uint8)) for _ in range(9)]
+    st = synth.build_stream(payloads, cfg, rng=rng)
+    dev = _to_dev(torch_cuda, st.iq)
+    h = capi.Handle(sf=7, cr=4, demod=capi.DEMOD_FFT_COMPAT)
+    h.decode_device(dev.data_ptr(), st.iq.size, [0], [st.iq.size], 0)
+    want = [(g, i.stream, i.header_pos) for g, i in h.drain()]
+    h.decode_device(dev.data_ptr(), st.iq.size, [0], [st.iq.size], 0)
+    slots = h.drain_slots(gather.SLOT_BYTES)
+    assert slots.shape == (len(want), gather.SLOT_BYTES) and h.frames_available() == 0
+    assert gather.unpack_frames(slots, len(want)) == want and len(want) == 9
+    h.close()
+
+
 def test_streaming_chunks_equal_batch(torch_cuda, oracle_mod):
     """lora_hip_work() with arbitrary chunking publishes the same frames (decoder_impl::work contract)."""
     from gr_lora_amd import capi
