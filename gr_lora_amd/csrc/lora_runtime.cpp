@@ -299,7 +299,7 @@ lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vec
                          uint32_t trace_cap, hipStream_t st, RunOut &out)
 {
     const uint32_t nj = (uint32_t)jobs.size();
-    out.rpj = recs_per_job;
+    out.rpj = recs_per_job; out.cap = recs_per_job;
     out.res.assign(nj, JobResult{});
     out.recs.clear();
     if (nj == 0) return LORA_HIP_OK;
@@ -328,7 +328,8 @@ lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vec
                                 hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipStreamSynchronize(st));
     std::memcpy(out.res.data(), h->p_res.p, nj * sizeof(JobResult));
-    if (getenv("LORA_HIP_DEBUG") && h->P.use_fast >= 2u) {
+    static const bool dbg_stats = getenv("LORA_HIP_DEBUG") != nullptr;
+    if (dbg_stats && h->P.use_fast >= 2u) {
         double cyc[6] = {0}, rnd[6] = {0};
         for (uint32_t j = 0; j < nj; j++) for (int i = 0; i < 6; i++) { cyc[i] += 64.0 * out.res[j].cyc[i]; rnd[i] += out.res[j].rounds[i]; }
         fprintf(stderr, "[lora_hip] per-job avg kcycles (rounds): DETECT %.0f (%.1f) SYNC %.0f (%.1f) SFD %.0f (%.1f) PAUSE %.0f (%.1f) HDR %.0f (%.1f) PAYLOAD %.0f (%.1f)\n",
@@ -357,12 +358,15 @@ lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vec
     uint32_t max_att = 0;
     for (uint32_t j = 0; j < nj; j++) max_att = std::max(max_att, out.res[j].n_attempts + (out.res[j].tail_valid ? out.res[j].tail_n_attempts : 0u));
     if (max_att > recs_per_job) max_att = recs_per_job;
-    out.recs.resize((size_t)nj * recs_per_job);
+    // host copy of the records: only as many per job as the busiest job wrote (a 58-deep array per job would be 10 MB to clear)
+    const uint32_t stride = std::max(max_att, 1u);
+    out.rpj = stride;
+    out.recs.resize((size_t)nj * stride);
     for (uint32_t j = 0; j < nj; j++) // the eagerly fetched records
-        std::memcpy(&out.recs[(size_t)j * recs_per_job], h->p_recs.p + (size_t)j * eager, std::min(eager, max_att) * sizeof(AttemptRec));
+        std::memcpy(&out.recs[(size_t)j * stride], h->p_recs.p + (size_t)j * eager, std::min(eager, max_att) * sizeof(AttemptRec));
     bool more = false;
     if (max_att > eager) { // rare: some job made more attempts than were fetched with the results
-        HIP_TRY(h, hipMemcpy2DAsync(out.recs.data() + eager, recs_per_job * sizeof(AttemptRec), h->d_recs.p + eager,
+        HIP_TRY(h, hipMemcpy2DAsync(out.recs.data() + eager, stride * sizeof(AttemptRec), h->d_recs.p + eager,
                                     recs_per_job * sizeof(AttemptRec), (max_att - eager) * sizeof(AttemptRec), nj, hipMemcpyDeviceToHost, st));
         more = true;
     }

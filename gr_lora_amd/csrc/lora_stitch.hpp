@@ -57,14 +57,15 @@ struct StreamDesc {
 struct RunOut {
     std::vector<JobResult> res;
     std::vector<AttemptRec> recs;
-    uint32_t rpj = 0;
+    uint32_t rpj = 0; // records stored per job (stride of `recs`): every record the jobs wrote, at most `cap`
+    uint32_t cap = 0; // record capacity the jobs ran with
     const AttemptRec &rec(size_t job, uint32_t a) const { return recs[job * rpj + a]; }
     // attempts that ran to completion (the last one is pending when JobResult.pad is set)
     uint32_t n_done(size_t job) const
     {
         const JobResult &r = res[job];
         const uint32_t n = r.pad ? r.n_attempts - 1u : r.n_attempts;
-        return n < rpj ? n : rpj;
+        return n < cap ? n : cap;
     }
 };
 
@@ -101,10 +102,11 @@ int run_serial(Env &env, StreamDesc &sd, Cursor &cur, int64_t limit, bool tracin
         int s = env.run_jobs(jobs, rpj, trace_cap, out);
         if (s != 0) return s;
         const JobResult &jr = out.res[0];
-        if (getenv("LORA_HIP_DEBUG_JOBS")) {
+        static const bool dbg_jobs = getenv("LORA_HIP_DEBUG_JOBS") != nullptr;
+        if (dbg_jobs) {
             fprintf(stderr, "[serial] start %lld limit %lld cr %u | final_pos %lld cr %u n_att %u stop %u pad %u npush %u\n", (long long)j.start, (long long)j.scan_limit, j.cr_prev,
                     (long long)jr.final_pos, jr.final_cr, jr.n_attempts, jr.stop_reason, jr.pad, jr.npush);
-            for (uint32_t a = 0; a < jr.n_attempts && a < rpj; a++) {
+            for (uint32_t a = 0; a < jr.n_attempts && a < out.cap; a++) {
                 const AttemptRec &t = out.rec(0, a);
                 fprintf(stderr, "[serial]    rec %u status %u start %lld trig %lld hdr %lld end %lld nsym %u npush %u\n", a, t.status, (long long)t.start_pos, (long long)t.trig_pos, (long long)t.hdr_pos,
                         (long long)t.end_pos, t.n_symbols, t.npush);
@@ -194,14 +196,15 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
     int s = env.run_jobs(jobs, rpj1, trace_cap, R1);
     if (s != 0) return s;
     const auto tp1 = std::chrono::steady_clock::now();
-    if (getenv("LORA_HIP_DEBUG_JOBS")) { // diagnostics: every segment job's result, comparable between the device and the CPU simulation
+    static const bool dbg_jobs = getenv("LORA_HIP_DEBUG_JOBS") != nullptr;
+    if (dbg_jobs) { // diagnostics: every segment job's result, comparable between the device and the CPU simulation
         for (size_t k = 0; k < jobs.size(); k++) {
             const JobResult &r = R1.res[k];
             fprintf(stderr, "[job] %zu start %lld limit %lld probe_limit %lld | final_pos %lld cr %u n_att %u stop %u pad %u npush %u | tail %u: first %u n_att %u final_pos %lld cr %u stop %u pad %u npush %u\n",
                     k, (long long)jobs[k].start, (long long)jobs[k].scan_limit, (long long)jobs[k].probe_limit, (long long)r.final_pos, r.final_cr, r.n_attempts, r.stop_reason, r.pad,
                     r.npush, r.tail_valid, r.tail_first_rec, r.tail_n_attempts, (long long)r.tail_final_pos, r.tail_final_cr, r.tail_stop_reason, r.tail_pad, r.tail_npush);
             const uint32_t n = r.n_attempts + (r.tail_valid ? r.tail_n_attempts : 0u);
-            for (uint32_t a = 0; a < n && a < rpj1; a++) {
+            for (uint32_t a = 0; a < n && a < R1.cap; a++) {
                 const AttemptRec &t = R1.rec(k, a);
                 fprintf(stderr, "[job]    rec %u status %u start %lld trig %lld hdr %lld end %lld nsym %u npush %u cr_prev %u ambig %u len %u\n", a, t.status, (long long)t.start_pos,
                         (long long)t.trig_pos, (long long)t.hdr_pos, (long long)t.end_pos, t.n_symbols, t.npush, t.cr_prev, t.hdr_ambig, t.frame_len);
@@ -212,7 +215,7 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
     // reached a header get a probe; it starts from the end state of the previous
     // header-bearing job and scans through any header-less segments in between.
     auto has_header = [&](size_t k) {
-        const uint32_t nall = std::min(R1.res[k].n_attempts, rpj1);
+        const uint32_t nall = std::min(R1.res[k].n_attempts, R1.cap);
         for (uint32_t a = 0; a < nall; a++) {
             const AttemptRec &r = R1.rec(k, a);
             if (r.hdr_pos >= 0 && (r.status == kAttemptFrame || r.status == kAttemptOutOfData)) return true;
@@ -261,12 +264,12 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
         s = env.run_jobs(pjobs, rpj2, 0, R2);
         if (s != 0) return s;
     }
-    if (getenv("LORA_HIP_DEBUG_JOBS")) {
+    if (dbg_jobs) {
         for (size_t k = 0; k < pjobs.size(); k++) {
             const JobResult &r = R2.res[k];
             fprintf(stderr, "[probe] %zu start %lld limit %lld cr %u | final_pos %lld cr %u n_att %u stop %u pad %u npush %u\n", k, (long long)pjobs[k].start, (long long)pjobs[k].scan_limit,
                     pjobs[k].cr_prev, (long long)r.final_pos, r.final_cr, r.n_attempts, r.stop_reason, r.pad, r.npush);
-            for (uint32_t a = 0; a < r.n_attempts && a < rpj2; a++) {
+            for (uint32_t a = 0; a < r.n_attempts && a < R2.cap; a++) {
                 const AttemptRec &t = R2.rec(k, a);
                 fprintf(stderr, "[probe]    rec %u status %u start %lld trig %lld hdr %lld end %lld nsym %u npush %u cr_prev %u ambig %u\n", a, t.status, (long long)t.start_pos, (long long)t.trig_pos,
                         (long long)t.hdr_pos, (long long)t.end_pos, t.n_symbols, t.npush, t.cr_prev, t.hdr_ambig);
@@ -280,7 +283,7 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
         ProbeView &v = pv[q];
         if (probes[q].job >= 0) {
             const size_t pj = (size_t)probes[q].job;
-            v.res = R2.res[pj]; v.recs = &R2.recs[pj * rpj2]; v.cap = rpj2; v.limit = pjobs[pj].scan_limit;
+            v.res = R2.res[pj]; v.recs = R2.recs.data() + pj * R2.rpj; v.cap = R2.cap; v.limit = pjobs[pj].scan_limit;
         } else {
             const size_t tj = (size_t)probes[q].tail_of;
             const JobResult &jr = R1.res[tj];
@@ -289,8 +292,8 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
             v.res.npush = jr.tail_npush;
             for (int t = 0; t < 4; t++) v.res.push_tail[t] = jr.tail_push_tail[t];
             v.res.stop_reason = jr.tail_stop_reason; v.res.pad = jr.tail_pad;
-            const uint32_t first = std::min(jr.tail_first_rec, rpj1);
-            v.recs = &R1.recs[tj * rpj1 + first]; v.cap = rpj1 - first; v.limit = jobs[tj].probe_limit;
+            const uint32_t first = std::min(jr.tail_first_rec, R1.cap);
+            v.recs = R1.recs.data() + tj * R1.rpj + first; v.cap = R1.cap - first; v.limit = jobs[tj].probe_limit;
         }
     }
     auto pv_done = [&](const ProbeView &v) { // attempts that ran to completion (cf. RunOut::n_done)
@@ -361,7 +364,7 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
             size_t mk = 0;
             for (size_t k = f + 1; k <= pb.target && match < 0; k++) {
                 if (segs[k].b1 <= cur.pos) continue;
-                const uint32_t nall = std::min(R1.res[k].n_attempts, rpj1);
+                const uint32_t nall = std::min(R1.res[k].n_attempts, R1.cap);
                 for (uint32_t a = 0; a < nall; a++) {
                     const AttemptRec &r = R1.rec(k, a);
                     if (r.hdr_pos != L.hdr_pos || (r.status != kAttemptFrame && r.status != kAttemptOutOfData)) continue;
@@ -375,7 +378,7 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
                     fprintf(stderr, "[lora_hip] probe for segment %zu [%lld, %lld): start %lld cr %u -> trig %lld hdr %lld\n", pb.target, (long long)segs[pb.target].b0, (long long)segs[pb.target].b1,
                             (long long)pb.start.pos, pb.start.cr, (long long)L.trig_pos, (long long)L.hdr_pos);
                     for (size_t k = pb.target ? pb.target - 1 : 0; k <= pb.target; k++)
-                        for (uint32_t a = 0; a < std::min(R1.res[k].n_attempts, rpj1); a++) {
+                        for (uint32_t a = 0; a < std::min(R1.res[k].n_attempts, R1.cap); a++) {
                             const AttemptRec &r = R1.rec(k, a);
                             fprintf(stderr, "[lora_hip]    job %zu [%lld, %lld) rec %u status %u start %lld trig %lld hdr %lld end %lld\n", k, (long long)segs[k].b0, (long long)segs[k].b1, a, r.status,
                                     (long long)r.start_pos, (long long)r.trig_pos, (long long)r.hdr_pos, (long long)r.end_pos);

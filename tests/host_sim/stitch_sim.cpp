@@ -29,7 +29,7 @@ struct SimEnv {
     bool implicit() const { return false; }
     int run_jobs(const std::vector<Job> &jobs, uint32_t rpj, uint32_t, RunOut &out)
     {
-        out.rpj = rpj;
+        out.rpj = rpj; out.cap = rpj;
         out.res.assign(jobs.size(), JobResult{});
         out.recs.assign(jobs.size() * (size_t)rpj, AttemptRec{});
         std::vector<oracle_attempt_t> tmp(rpj + 1);
