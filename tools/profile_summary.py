@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/prof_<tag>/ (tools/profile_round.sh) into the files committed under profiles/:
+   profiles/<round>_<tag>_kernel_stats.csv   per-kernel stats (rocprofv3 --stats)
+   profiles/<round>_<tag>_pmc_traffic.json   HBM bytes per pass of the walker kernel (FETCH_SIZE / WRITE_SIZE)"""
+import collections, csv, glob, json, os, shutil, sys
+
+tag = sys.argv[1]
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
+src = os.path.join("gpurun_out", "prof_" + tag)
+stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+assert stats, "no kernel_stats.csv"
+shutil.copy(stats[0], os.path.join("profiles", "%s_%s_sf7_1024pkt_kernel_stats.csv" % (rnd, tag)))
+
+def per_dispatch(kind, counter):
+    out = collections.defaultdict(list)  # grid size -> values
+    for path in glob.glob(os.path.join(src, kind, "**", "*counter_collection.csv"), recursive=True):
+        acc, meta = collections.defaultdict(float), {}
+        for row in csv.DictReader(open(path)):
+            if row["Counter_Name"] != counter or "walker" not in row["Kernel_Name"]:
+                continue
+            acc[row["Dispatch_Id"]] += float(row["Counter_Value"])
+            meta[row["Dispatch_Id"]] = (row["Kernel_Name"].split("(")[0], row["Grid_Size"])
+        for d, v in acc.items():
+            out[meta[d]].append(v)
+    return out
+
+fetch, write = per_dispatch("fetch", "FETCH_SIZE"), per_dispatch("write", "WRITE_SIZE")
+line = json.loads([l for l in open(os.path.join(src, "stats.log")).read().splitlines() if l.startswith("{\"metric\"")][-1])
+disp = {}
+fetch_raw = write_raw = 0.0
+for key in sorted(set(fetch) | set(write)):
+    f = sum(fetch.get(key, [0])) / max(1, len(fetch.get(key, [])))
+    w = sum(write.get(key, [0])) / max(1, len(write.get(key, [])))
+    disp["%s grid %s" % key] = {"fetch_kb_avg": f, "write_kb_avg": w, "dispatches_fetch_pass": len(fetch.get(key, []))}
+    fetch_raw += f * 1024.0
+    write_raw += w * 1024.0
+res = {
+    "command": "tools/profile_round.sh %s: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline" % tag,
+    "workload_items": line["config"]["items_per_gpu"],
+    "units": "FETCH_SIZE / WRITE_SIZE are KB per dispatch (rocprofv3); one pass = one dispatch of each grid size listed",
+    "dispatches": disp,
+    "fetch_bytes_per_pass_raw": fetch_raw,
+    "write_bytes_per_pass_raw": write_raw,
+    "gfx950_fetch_correction": "x2 (MI355X_MICROARCH.md, HBM section: FETCH_SIZE tallies 128-B requests at 64 B); calibrated for this kernel's access "
+                               "pattern (8 B per lane, 512 contiguous bytes per wave instruction) with tools/calib_fetch.hip: FETCH_SIZE = 0.500 x bytes read; "
+                               "WRITE_SIZE is uncalibrated",
+    "hbm_bytes_per_pass_corrected": 2.0 * fetch_raw + write_raw,
+    "algorithmic_bytes_per_pass": 8 * line["config"]["items_per_gpu"],
+}
+json.dump(res, open(os.path.join("profiles", "%s_%s_pmc_traffic.json" % (rnd, tag)), "w"), indent=1)
+print(json.dumps(res, indent=1)[:1500])
