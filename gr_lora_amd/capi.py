@@ -25,6 +25,18 @@ EXPORTS = [
 ]
 
 
+EXPORTS_CHANNELIZER = [
+    "lora_hip_channelizer_create", "lora_hip_channelizer_destroy", "lora_hip_channelizer_last_error", "lora_hip_channelizer_taps",
+    "lora_hip_channelizer_output_items", "lora_hip_channelizer_run_device", "lora_hip_channelizer_work", "lora_hip_channelizer_apply_cfo",
+    "lora_hip_channelizer_last_kernel_ms",
+]
+
+
+class ChannelizerConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("samp_rate", C.c_float), ("center_freq", C.c_float), ("channel_list", C.POINTER(C.c_float)),
+                ("n_channels", C.c_uint32), ("bandwidth", C.c_uint32), ("decimation", C.c_uint32), ("device", C.c_int32)]
+
+
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("samp_rate", C.c_float), ("bandwidth", C.c_uint32),
                 ("sf", C.c_uint8), ("implicit", C.c_uint8), ("cr", C.c_uint8), ("crc", C.c_uint8),
@@ -101,6 +113,19 @@ def load():
     L.lora_hip_trace.argtypes = [vp, C.POINTER(C.POINTER(Step))]
     L.lora_hip_trace_clear.argtypes = [vp]
     L.lora_hip_trace_clear.restype = None
+    L.lora_hip_channelizer_create.argtypes = [C.POINTER(ChannelizerConfig), C.POINTER(vp)]
+    L.lora_hip_channelizer_destroy.argtypes = [vp]
+    L.lora_hip_channelizer_destroy.restype = None
+    L.lora_hip_channelizer_last_error.argtypes = [vp]
+    L.lora_hip_channelizer_last_error.restype = C.c_char_p
+    L.lora_hip_channelizer_taps.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.lora_hip_channelizer_output_items.argtypes = [vp, C.c_size_t]
+    L.lora_hip_channelizer_output_items.restype = C.c_size_t
+    L.lora_hip_channelizer_run_device.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]
+    L.lora_hip_channelizer_work.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.lora_hip_channelizer_apply_cfo.argtypes = [vp, C.c_float]
+    L.lora_hip_channelizer_last_kernel_ms.argtypes = [vp]
+    L.lora_hip_channelizer_last_kernel_ms.restype = C.c_float
     _lib = L
     return L
 
@@ -245,3 +270,63 @@ class Handle:
 
     def trace_clear(self):
         self.L.lora_hip_trace_clear(self.h)
+
+
+class Channelizer:
+    """lora_hip_channelizer_* (include/lora_hip_channelizer.h): the frequency-translating FIR in front of the decoder."""
+
+    def __init__(self, samp_rate, center_freq, channel_list, bandwidth, decimation=1, device=0):
+        self.L = load()
+        self.n_channels = len(channel_list)
+        self._chan = (C.c_float * self.n_channels)(*[float(c) for c in channel_list])
+        cfg = ChannelizerConfig(struct_size=C.sizeof(ChannelizerConfig), samp_rate=float(samp_rate), center_freq=float(center_freq),
+                                channel_list=self._chan, n_channels=self.n_channels, bandwidth=int(bandwidth), decimation=int(decimation), device=int(device))
+        self.h = C.c_void_p()
+        st = self.L.lora_hip_channelizer_create(C.byref(cfg), C.byref(self.h))
+        if st != 0:
+            raise LoraHipError(st, self.L.lora_hip_strerror(st).decode())
+
+    def _check(self, st):
+        if st != 0:
+            raise LoraHipError(st, (self.L.lora_hip_channelizer_last_error(self.h) or b"").decode() or self.L.lora_hip_strerror(st).decode())
+
+    def taps(self) -> np.ndarray:
+        n = C.c_size_t(0)
+        self._check(self.L.lora_hip_channelizer_taps(self.h, None, 0, C.byref(n)))
+        t = np.zeros(n.value, dtype=np.float32)
+        self._check(self.L.lora_hip_channelizer_taps(self.h, t.ctypes.data, t.size, C.byref(n)))
+        return t
+
+    def output_items(self, n_in: int) -> int:
+        return int(self.L.lora_hip_channelizer_output_items(self.h, n_in))
+
+    def work(self, x) -> np.ndarray:
+        """Host buffers in and out: complex64[n_in] -> complex64[n_channels, n_out]."""
+        a = np.ascontiguousarray(x, dtype=np.complex64)
+        no = self.output_items(a.size)
+        out = np.zeros((self.n_channels, max(no, 1)), dtype=np.complex64)
+        n = C.c_size_t(0)
+        self._check(self.L.lora_hip_channelizer_work(self.h, a.ctypes.data, a.size, out.ctypes.data, out.shape[1], C.byref(n)))
+        return out[:, : n.value]
+
+    def run_device(self, d_in: int, n_in: int, d_out: int, out_stride: int, stream: int = 0) -> int:
+        n = C.c_size_t(0)
+        self._check(self.L.lora_hip_channelizer_run_device(self.h, d_in, n_in, d_out, out_stride, C.byref(n), stream))
+        return int(n.value)
+
+    def apply_cfo(self, cfo: float):
+        self._check(self.L.lora_hip_channelizer_apply_cfo(self.h, float(cfo)))
+
+    def kernel_ms(self) -> float:
+        return float(self.L.lora_hip_channelizer_last_kernel_ms(self.h))
+
+    def close(self):
+        if self.h:
+            self.L.lora_hip_channelizer_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -139,48 +139,54 @@ class decoder(_MsgBlock):
 
 
 def low_pass_taps(gain, fs, cutoff, transition):
-    """gr::filter::firdes::low_pass(gain, fs, cutoff, transition, WIN_HAMMING):
-    ntaps = int(53 * fs / (22 * transition)) made odd; windowed sinc normalised to `gain` at DC."""
+    """gr::filter::firdes::low_pass(gain, fs, cutoff, transition, WIN_HAMMING) as GNU Radio 3.9 computes it:
+    ntaps = int(53 * fs / (22 * transition)) made odd, float Hamming window, float taps, normalised so that the DC
+    gain (taps[M] + 2 * sum of one side) is `gain`.  Same steps as firdes_low_pass in csrc/lora_channelizer.hip."""
     ntaps = int(53.0 * fs / (22.0 * transition))
     if ntaps % 2 == 0:
         ntaps += 1
     m = (ntaps - 1) // 2
-    n = np.arange(-m, m + 1, dtype=np.float64)
     fw = 2.0 * np.pi * cutoff / fs
-    w = 0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(ntaps) / (ntaps - 1))
+    w = (0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(ntaps) / (ntaps - 1))).astype(np.float32)
+    n = np.arange(-m, m + 1, dtype=np.float64)
     with np.errstate(invalid="ignore", divide="ignore"):
-        taps = np.where(n == 0, fw / np.pi, np.sin(n * fw) / (n * np.pi)) * w
-    taps *= gain / taps.sum()
-    return taps.astype(np.float32)
+        taps = np.where(n == 0, fw / np.pi * w, np.sin(n * fw) / (n * np.pi) * w).astype(np.float32)
+    fmax = float(taps[m]) + 2.0 * float(taps[m + 1:].astype(np.float64).sum())
+    return (taps.astype(np.float64) * (gain / fmax)).astype(np.float32)
 
 
 class channelizer:
     """gr::lora::channelizer: freq_xlating_fir_filter_ccf(decimation, low_pass(1, fs, bw/2 + 15 kHz,
-    10 kHz, Hamming), channel_list[0] - center_freq, fs)  (lib/channelizer_impl.cc:46-57).
-    Streaming host implementation (keeps filter history and oscillator phase across calls)."""
+    10 kHz, Hamming), channel_list[0] - center_freq, fs)  (lib/channelizer_impl.cc:46-57), on the GPU through
+    lora_hip_channelizer_* (include/lora_hip_channelizer.h).  Like the reference only channel_list[0] is output.
+    There is no host fall-back: without the HIP library and a device the constructor raises."""
 
-    def __init__(self, samp_rate, center_freq, channel_list, bandwidth, decimation=1):
+    def __init__(self, samp_rate, center_freq, channel_list, bandwidth, decimation=1, device=0):
+        from . import capi
         self.fs = float(samp_rate)
+        self.center_freq = float(center_freq)
+        self.channel_list = list(channel_list)
+        self.bandwidth = int(bandwidth)
         self.decimation = int(decimation)
-        self.taps = low_pass_taps(1.0, samp_rate, bandwidth / 2.0 + 15000.0, 10000.0)
-        self.freq_offset = float(channel_list[0]) - float(center_freq)
-        self._hist = np.zeros(len(self.taps) - 1, dtype=np.complex64)
-        self._n = 0
-        self._skip = 0
+        self.device = device
+        self._h = capi.Channelizer(samp_rate, center_freq, self.channel_list[:1], bandwidth, decimation, device)
+        self.taps = self._h.taps()
 
     def work(self, x) -> np.ndarray:
         x = np.asarray(x, dtype=np.complex64)
         if x.size == 0:
             return x
-        n = np.arange(self._n, self._n + x.size, dtype=np.float64)
-        lo = np.exp(-2j * np.pi * self.freq_offset * n / self.fs).astype(np.complex64)
-        self._n += x.size
-        buf = np.concatenate([self._hist, x * lo])
-        y = np.convolve(buf, self.taps.astype(np.complex64), mode="valid")
-        self._hist = buf[-(len(self.taps) - 1):]
-        y = y[self._skip::self.decimation]
-        self._skip = (self._skip - x.size) % self.decimation
-        return y.astype(np.complex64)
+        return self._h.work(x)[0]
+
+    def apply_cfo(self, cfo):                       # channelizer_impl.cc:68-71
+        self._h.apply_cfo(cfo)
+
+    def retune(self, center_freq):
+        """A new capture centre frequency (filter history and oscillator phase start over)."""
+        from . import capi
+        self._h.close()
+        self.center_freq = float(center_freq)
+        self._h = capi.Channelizer(self.fs, self.center_freq, self.channel_list[:1], self.bandwidth, self.decimation, self.device)
 
 
 class lora_receiver(_MsgBlock):
@@ -201,7 +207,7 @@ class lora_receiver(_MsgBlock):
         self.conj = conj
         self.disable_channelization = disable_channelization
         self.disable_drift_correction = disable_drift_correction
-        self.channelizer = channelizer(samp_rate, center_freq, channel_list, bandwidth, decimation)
+        self.channelizer = None if disable_channelization else channelizer(samp_rate, center_freq, channel_list, bandwidth, decimation)
         self.decoder = decoder(samp_rate / decimation, bandwidth, sf, implicit, cr, crc, reduced_rate,
                                disable_drift_correction, **decoder_kw)
         self.message_port_register_out("frames")     # message_port_register_hier_out('frames')
@@ -234,7 +240,8 @@ class lora_receiver(_MsgBlock):
     def set_center_freq(self, center_freq):
         # upstream calls a channelizer method that does not exist (lora_receiver.py:89); here it retunes
         self.center_freq = center_freq
-        self.channelizer.freq_offset = float(self.channel_list[0]) - float(center_freq)
+        if self.channelizer is not None:
+            self.channelizer.retune(center_freq)
 
 
 class message_socket_sink(_MsgBlock):

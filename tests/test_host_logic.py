@@ -29,6 +29,12 @@ def test_c_abi_exports_every_declared_symbol():
     exported = set(re.findall(r" T (lora_hip_[a-z_]+)", out))
     assert declared <= exported
     assert lib.lora_hip_abi_version() == 1
+    # the channeliser's header
+    hdr2 = open(os.path.join(ROOT, "include", "lora_hip_channelizer.h")).read()
+    declared2 = set(re.findall(r"\b(lora_hip_channelizer_[a-z_]+)\s*\(", hdr2))
+    assert declared2 == set(capi.EXPORTS_CHANNELIZER) and declared2 <= exported
+    for name in declared2:
+        assert getattr(lib, name) is not None
 
 
 def test_create_fails_loudly_without_gpu_or_with_bad_sf():
@@ -60,11 +66,19 @@ def test_firdes_low_pass_shape():
     assert w[np.abs(f) < 60e3].min() > 0.98 and w[np.abs(f) > 100e3].max() < 0.01
 
 
-def test_channelizer_streaming_equals_one_shot():
+def test_firdes_restatements_agree():
+    """The host mirror's taps and the oracle's restatement of firdes::low_pass are the same float vector."""
+    from oracle import channelizer_oracle as co
+    assert np.array_equal(lora.low_pass_taps(1.0, 1e6, 125000 // 2 + 15000.0, 10000.0), co.firdes_low_pass(1.0, 1e6, 125000 // 2 + 15000.0, 10000.0))
+    assert len(co.firdes_low_pass(1.0, 2e6, 77500.0, 10000.0)) == 481
+
+
+def test_channelizer_oracle_streaming_equals_one_shot():
+    from oracle import channelizer_oracle as co
     rng = np.random.default_rng(0)
     x = (rng.standard_normal(50000) + 1j * rng.standard_normal(50000)).astype(np.complex64)
-    a = lora.channelizer(1e6, 868.0e6, [868.1e6], 125000, 1).work(x)
-    c = lora.channelizer(1e6, 868.0e6, [868.1e6], 125000, 1)
+    a = co.Channelizer(1e6, 868.0e6, 868.1e6, 125000, 1).work(x)
+    c = co.Channelizer(1e6, 868.0e6, 868.1e6, 125000, 1)
     parts, pos = [], 0
     while pos < x.size:
         n = int(rng.integers(1, 5000))
@@ -72,7 +86,11 @@ def test_channelizer_streaming_equals_one_shot():
         pos += n
     b = np.concatenate(parts)
     assert a.size == b.size == x.size
-    assert np.allclose(a, b, atol=1e-4)
+    assert np.allclose(a, b, atol=1e-9)
+    # decimation keeps its phase across chunks
+    d = co.Channelizer(1e6, 868.0e6, 868.1e6, 125000, 4)
+    parts = [d.work(x[i:i + 4099]) for i in range(0, x.size, 4099)]
+    assert np.allclose(np.concatenate(parts), co.Channelizer(1e6, 868.0e6, 868.1e6, 125000, 4).work(x), atol=1e-9)
 
 
 def test_message_socket_sink_layers():
@@ -110,8 +128,9 @@ def test_config1_plumbing_on_oracle(tmp_path, oracle_mod):
     meta = sigmf.read_meta(base + ".sigmf-meta")
     lc = sigmf.LoRaConfig(meta["transmit_freq"], meta["sf"], meta["cr"], meta["bw"], meta["prlen"], meta["crc"], meta["implicit"])
     assert lc.cr_num == 4 and lc.string_repr() == "868.1 MHz, SF 7, CR 4/8, BW 125 kHz, prlen 8, crc on, implicit off"
-    chan = lora.channelizer(meta["sample_rate"], meta["capture_freq"], [meta["transmit_freq"]], lc.bw, 1)
+    from oracle import channelizer_oracle as co
+    chan = co.Channelizer(meta["sample_rate"], meta["capture_freq"], meta["transmit_freq"], lc.bw, 1)
     data = sigmf.read_data(base + ".sigmf-data")
-    bb = np.concatenate([chan.work(data[i:i + 65536]) for i in range(0, data.size, 65536)])
+    bb = np.concatenate([chan.work(data[i:i + 65536]) for i in range(0, data.size, 65536)]).astype(np.complex64)
     frames = oracle_mod.decode_stream(bb, demod=0, sf=7, cr=lc.cr_num, crc=True)
     assert [f[15:] for f in frames] == [README_BYTES] * meta["times"]
