@@ -117,3 +117,43 @@ def test_config1_channelised_trace_decodes_on_gpu(torch_cuda, oracle_mod):
     want = oracle_mod.decode_stream(bb, demod=0, sf=7, cr=4, crc=True)
     assert [f[15:] for f in frames] == [bytes.fromhex("049040deadbeef700d")] * 5
     assert [f[15:] for f in frames] == [f[15:] for f in want]
+
+
+def test_wideband_four_channels_device_resident(torch_cuda, oracle_mod):
+    """What N1 is for: one wide-band capture holding four LoRa channels -> one channeliser launch (4 rows in HBM) ->
+    one lora_hip_decode_device call over the 4 rows as independent streams, no host hop in between.  Frames per channel
+    equal channeliser-oracle -> decoder-oracle per channel, and the transmitted payloads."""
+    from gr_lora_amd import capi
+    from oracle import channelizer_oracle as co
+    torch = torch_cuda
+    cfg = synth.TxConfig(sf=7, cr=4)
+    offsets = [-300e3, -100e3, 100e3, 300e3]
+    rng = np.random.default_rng(44)
+    streams, n = [], 0
+    for c in range(4):
+        payloads = [bytes(rng.integers(0, 256, int(rng.integers(4, 40)), dtype=np.uint8)) for _ in range(6)]
+        st = synth.build_stream(payloads, cfg, rng=rng, lead=int(rng.integers(3000, 40000)))
+        streams.append(st)
+        n = max(n, st.iq.size)
+    t = np.arange(n, dtype=np.float64)
+    wide = np.zeros(n, dtype=np.complex128)
+    for c, st in enumerate(streams):
+        wide[: st.iq.size] += st.iq * np.exp(2j * np.pi * offsets[c] * t[: st.iq.size] / 1e6)
+    wide = wide.astype(np.complex64)
+    chans = [868.0e6 + f for f in offsets]
+    ch = capi.Channelizer(1e6, 868.0e6, chans, 125000, 1)
+    d_in = torch.from_numpy(wide.view(np.float32)).to("cuda:0")
+    d_out = torch.empty((4, 2 * n), dtype=torch.float32, device="cuda:0")
+    assert ch.run_device(d_in.data_ptr(), n, d_out.data_ptr(), n) == n
+    h = capi.Handle(sf=7, cr=4, demod=capi.DEMOD_FFT_COMPAT)
+    h.decode_device(d_out.data_ptr(), 4 * n, [c * n for c in range(4)], [n] * 4, 0)
+    got = {}
+    for blob, info in h.drain():
+        got.setdefault(info.stream, []).append(blob)
+    for c, st in enumerate(streams):
+        bb = co.Channelizer(1e6, 868.0e6, chans[c], 125000, 1).work(wide).astype(np.complex64)
+        want = oracle_mod.decode_stream(bb, demod=2, sf=7, cr=4)
+        assert [g[15:] for g in got.get(c, [])] == [synth.expected_frame_tail(p, cfg) for p in st.payloads]
+        assert got.get(c, []) == want
+    ch.close()
+    h.close()
