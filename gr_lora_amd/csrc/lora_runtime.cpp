@@ -199,8 +199,8 @@ lora_hip_status build_tables(lora_hip_decoder *h)
     P.enable_fine_sync = c.disable_drift_correction ? 0u : 1u;
     P.demod_mode = (uint32_t)c.demod;
     P.ctor_cr = c.cr & 7u; P.ctor_crc = c.crc ? 1u : 0u;
-    // 0: generic kernels only, 1: walker_body with wave-per-symbol decode rounds, 2 (default): walker2
-    P.use_fast = getenv("LORA_HIP_NO_FAST") ? 0u : (getenv("LORA_HIP_FAST_MODE") ? (uint32_t)atoi(getenv("LORA_HIP_FAST_MODE")) : 2u);
+    // walker2 (wave-per-symbol rounds) where it applies; LORA_HIP_NO_FAST=1 forces the generic kernels (diagnostics)
+    P.use_fast = getenv("LORA_HIP_NO_FAST") ? 0u : 1u;
     // get_shift_fft working set: D/G polyphase rows of N points (+1 pad) must fit the LDS budget
     uint32_t G = 1;
     while ((size_t)(D / G) * (N + 1u) * sizeof(float2) > kWorkBudget && G < D) G <<= 1;
@@ -329,7 +329,7 @@ lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vec
     HIP_TRY(h, hipStreamSynchronize(st));
     std::memcpy(out.res.data(), h->p_res.p, nj * sizeof(JobResult));
     static const bool dbg_stats = getenv("LORA_HIP_DEBUG") != nullptr;
-    if (dbg_stats && h->P.use_fast >= 2u) {
+    if (dbg_stats && h->P.use_fast) {
         double cyc[6] = {0}, rnd[6] = {0};
         for (uint32_t j = 0; j < nj; j++) for (int i = 0; i < 6; i++) { cyc[i] += 64.0 * out.res[j].cyc[i]; rnd[i] += out.res[j].rounds[i]; }
         fprintf(stderr, "[lora_hip] per-job avg kcycles (rounds): DETECT %.0f (%.1f) SYNC %.0f (%.1f) SFD %.0f (%.1f) PAUSE %.0f (%.1f) HDR %.0f (%.1f) PAYLOAD %.0f (%.1f)\n",
