@@ -22,7 +22,9 @@
 // Streaming state (filter history, absolute sample index for the oscillator, decimation phase) lives in the handle.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -258,18 +260,20 @@ extern "C" {
 
 lora_hip_status lora_hip_channelizer_create(const lora_hip_channelizer_config_t *cfg, lora_hip_channelizer_t **out)
 {
-    if (!cfg || !out || cfg->struct_size < sizeof(lora_hip_channelizer_config_t)) return LORA_HIP_ERR_ARG;
+    if (!cfg || !out || cfg->struct_size < offsetof(lora_hip_channelizer_config_t, cutoff_hz)) return LORA_HIP_ERR_ARG;
     *out = nullptr;
     if (!cfg->channel_list || cfg->n_channels == 0 || cfg->decimation == 0 || !(cfg->samp_rate > 0.0f)) return LORA_HIP_ERR_BAD_CONFIG;
     if (cfg->decimation > (uint32_t)kMaxDecim) return LORA_HIP_ERR_BAD_CONFIG; // the generic path stages 256 D + taps items in LDS
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || cfg->device < 0 || cfg->device >= ndev) return LORA_HIP_ERR_NO_DEVICE;
     auto *h = new lora_hip_channelizer;
-    h->cfg = *cfg;
+    std::memcpy(&h->cfg, cfg, std::min<size_t>(cfg->struct_size, sizeof h->cfg)); // older callers: no design overrides
     h->device = cfg->device;
     h->channels.assign(cfg->channel_list, cfg->channel_list + cfg->n_channels);
     h->cfg.channel_list = nullptr;
-    h->taps = firdes_low_pass(1.0, cfg->samp_rate, (double)(cfg->bandwidth / 2u) + 15000.0, 10000.0); // :46 (integer bandwidth/2)
+    const double cutoff = h->cfg.cutoff_hz > 0.0f ? (double)h->cfg.cutoff_hz : (double)(cfg->bandwidth / 2u) + 15000.0; // :46 (integer bandwidth/2)
+    const double transition = h->cfg.transition_hz > 0.0f ? (double)h->cfg.transition_hz : 10000.0;
+    h->taps = firdes_low_pass(1.0, cfg->samp_rate, cutoff, transition);
     h->chan.resize(h->channels.size());
     h->ntaps_pad = ((int)h->taps.size() + 15) & ~15;
     h->tile_in = kThreads * (cfg->decimation == 1 ? kOutD1 : 1) * (int)cfg->decimation;

@@ -11,14 +11,16 @@ import numpy as np
 
 def write_trace(path_base: str, iq: np.ndarray, sample_rate: float, capture_freq: float, transmit_freq: float, sf: int,
                 cr: str, bw: int, prlen: int, crc: bool, implicit: bool, expected_hex: str, times: int,
-                hw: str = "synthetic") -> Tuple[str, str]:
+                hw: str = "synthetic", frequency_offset: float = 0) -> Tuple[str, str]:
+    """`frequency_offset` is the capture's LO calibration offset (generate_test_suites.py -F, default 0): the harness
+    removes it with an extra translating filter in front of the receiver (qa_testsuite.py:233)."""
     data_path, meta_path = path_base + ".sigmf-data", path_base + ".sigmf-meta"
     np.ascontiguousarray(iq, dtype=np.complex64).tofile(data_path)
     meta = {
         "global": {"core:datatype": "cf32_le", "core:version": "0.0.1", "core:sample_rate": sample_rate,
                    "core:hw": hw, "core:description": "synthetic LoRa capture (gr_lora_amd.synth)"},
         "captures": [{"core:sample_start": 0, "core:frequency": capture_freq,
-                      "lora:frequency": transmit_freq, "lora:frequency_offset": transmit_freq - capture_freq,
+                      "lora:frequency": transmit_freq, "lora:frequency_offset": frequency_offset,
                       "lora:sf": sf, "lora:cr": cr, "lora:bw": bw, "lora:prlen": prlen, "lora:crc": crc,
                       "lora:implicit": implicit, "test:expected": expected_hex, "test:times": times}],
         "annotations": [],
@@ -34,7 +36,7 @@ def read_meta(meta_path: str) -> Dict:
     return {"sample_rate": g["core:sample_rate"], "capture_freq": c["core:frequency"],
             "transmit_freq": c["lora:frequency"], "sf": c["lora:sf"], "cr": c["lora:cr"], "bw": int(c["lora:bw"]),
             "prlen": c["lora:prlen"], "crc": c["lora:crc"], "implicit": c["lora:implicit"],
-            "expected": c["test:expected"], "times": c["test:times"]}
+            "expected": c["test:expected"], "times": c["test:times"], "frequency_offset": c.get("lora:frequency_offset", 0)}
 
 
 def read_data(data_path: str) -> np.ndarray:

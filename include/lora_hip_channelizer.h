@@ -32,6 +32,11 @@ typedef struct lora_hip_channelizer_config {
     uint32_t bandwidth;      /* arg 4 */
     uint32_t decimation;     /* arg 5 (>= 1) */
     int32_t  device;         /* HIP device ordinal */
+    /* Filter design overrides, 0 = the channeliser's own (cutoff bandwidth/2 + 15 kHz, transition 10 kHz, :46).  The
+     * reference's test harness runs a second freq_xlating_fir_filter with low_pass(1, fs, 200 kHz, 100 kHz) in front of
+     * the receiver (python/qa_testsuite.py:233); apps/qa_testsuite.py builds that one through these fields.           */
+    float    cutoff_hz;
+    float    transition_hz;
 } lora_hip_channelizer_config_t;
 
 typedef struct lora_hip_channelizer lora_hip_channelizer_t;
