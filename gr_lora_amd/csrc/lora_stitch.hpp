@@ -132,9 +132,9 @@ inline int cr_class(uint32_t cr) { return cr >= 3u ? 2 : (cr >= 1u ? 1 : 0); }
 // Round 2 is, for every segment, a probe that starts from the END state of the
 // preceding segment's job and walks DETECT/SYNC/FIND_SFD up to the first header.
 // Normally the preceding job has run it itself (Job.probe_limit: having reached its
-// own limit it carries on as that probe and reports it as its "tail"); a separate
-// probe job is launched only where no such tail exists (header-less segments in
-// between, kernels without the feature).
+// own limit the workgroup runs that probe as a second phase and reports it as its
+// "tail"); a separate probe job is launched only where no such tail exists
+// (header-less segments in between, kernels without the feature).
 // The host then stitches: if the probe enters DECODE_HEADER at the same sample
 // as one of the segment job's attempts, the two trajectories are identical from
 // there on (the decoder state at header entry is position + d_phdr.cr), and the

@@ -61,6 +61,8 @@ struct alignas(16) W2Shared {
     Shared   sh;      // words / codewords / decoded bytes (shared with the integer-chain helpers)
     W2State  st;
     W2Stats  stats;
+    int64_t  ph_start;    // hand-over from the job proper to its tail probe (Job.probe_limit): start position,
+    uint32_t ph_go, ph_cr, ph_natt, ph_pad; // go flag, d_phdr.cr, attempt records used so far
     uint32_t words_pk[2]; // d_words of the current block, one byte per word (words < 256 for SF <= 8); control thread only
 };
 
@@ -101,11 +103,11 @@ __device__ __forceinline__ float unwrap_diff(float pp, float p2)
 }
 
 // ---- thread-0 bookkeeping (mirrors end_step / the loop-top checks of walker_body) ---------------------
-__device__ __forceinline__ bool w2_pre_step(W2State &S, const Job &job, const LaunchCfg &C, uint32_t sps)
+__device__ __forceinline__ bool w2_pre_step(W2State &S, const Job &job, uint32_t rec_cap, uint32_t sps)
 {
     if (S.state == kDetect && !S.in_attempt) {
         if (S.pos >= job.scan_limit) { S.stop_reason = 0; S.done = 1; return false; }
-        if (S.n_att >= C.recs_per_job) { S.stop_reason = 2; S.done = 1; return false; }
+        if (S.n_att >= rec_cap) { S.stop_reason = 2; S.done = 1; return false; }
         if (job.max_attempts && S.n_att >= job.max_attempts) { S.stop_reason = 3; S.done = 1; return false; }
     }
     if (S.pos + 2 * (int64_t)sps > (int64_t)job.stream_len) { S.stop_reason = 1; S.done = 1; return false; } // :91
@@ -372,7 +374,8 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
 
     const uint32_t jid = blockIdx.x;
     if (jid >= C.n_jobs) return;
-    const Job job = C.jobs[jid];
+    Job job = C.jobs[jid];           // (phase 1 rewrites start / limits: the job carries on as the next segment's probe)
+    uint32_t rec_cap = C.recs_per_job; // ... with what is left of the attempt-record capacity
     const float2 *__restrict__ X = C.iq + job.stream_off;
     const int64_t n_items = (int64_t)job.stream_len;
     AttemptRec *recs = C.recs + (size_t)jid * C.recs_per_job;
@@ -388,7 +391,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     // plan for the next round from the TRUE state (control thread only)
     auto plan_from = [&](W2State &S, W2Plan &pl) {
         pl.buf = 0; pl.resolve_prev = 0; pl.n_win = kW2Workers; pl.pos = S.pos;
-        if (!S.done) (void)w2_pre_step(S, job, C, sps);
+        if (!S.done) (void)w2_pre_step(S, job, rec_cap, sps);
         if (S.done) { pl.mode = kPlanExit; return; }
         if (S.fin_pending) { pl.mode = kPlanFinalize; return; }
         switch (S.state) {
@@ -407,16 +410,20 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     };
     auto plan_from_state = [&](W2Plan &pl) { plan_from(S, pl); };
 
+    W2Tabs T{vl, ddl, W.red};
+    // Phase 0 is the job proper.  Phase 1 (Job.probe_limit): having reached its scan limit the workgroup runs what a
+    // separate probe job started from its end state would run -- a FRESH job (state re-initialised, tables kept) that
+    // stops at the next header -- and reports it as the "tail"; the host then needs no second launch.
+    for (int phase = 0; phase < 2; phase++) {
     if (t0) {
         S = W2State{};
         S.state = kDetect; S.pos = job.start; S.cr = job.cr_prev; S.has_crc = P.ctor_crc;
         S.phdr[1] = (uint8_t)((P.ctor_cr << 5) | (P.ctor_crc << 4));
         S.att_start = job.start; S.att_trig = -1; S.att_hdr = -1; S.att_cr_prev = job.cr_prev;
-        W.stats = W2Stats{};
+        if (phase == 0) W.stats = W2Stats{};
         W.stats.prev_state = -1;
         plan_from_state(W.plan[0]);
     }
-    W2Tabs T{vl, ddl, W.red};
 
     for (uint32_t it = 0;; it++) {
         __syncthreads(); // plan[it & 1] and everything the control thread wrote are visible; plan[(it+1) & 1] is free
@@ -587,7 +594,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             __syncthreads();
             if (t0) {
                 for (int w = 0; w < kW2Workers; w++) {
-                    if (w > 0 && !w2_pre_step(S, job, C, sps)) break;
+                    if (w > 0 && !w2_pre_step(S, job, rec_cap, sps)) break;
                     if (!W.speci[0][w][0]) break;
                     const float cw = W.specf[w][0];
                     int32_t fw = 0;
@@ -656,7 +663,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 // lane w fetches worker w's result: one LDS round trip for the round instead of two per symbol
                 const int32_t my_s = lane < kW2Workers ? W.speci[rb][lane][0] : -1, my_f = lane < kW2Workers ? W.speci[rb][lane][1] : 0;
                 for (int w = 0; w < kW2Workers; w++) {
-                    if (w > 0 && !w2_pre_step(L, job, C, sps)) break;
+                    if (w > 0 && !w2_pre_step(L, job, rec_cap, sps)) break;
                     const int32_t sw = __builtin_amdgcn_readlane(my_s, w), fw = __builtin_amdgcn_readlane(my_f, w);
                     if (!(L.state == kDecodeHeader || L.state == kDecodePayload) || sw < 0) break;
                     const bool is_first = L.state == kDecodeHeader;
@@ -672,7 +679,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 }
                 // is the round the workers are computing right now the true continuation?
                 predicted = !L.done && !L.fin_pending && (L.state == kDecodeHeader || L.state == kDecodePayload) && L.pos == plan.pos &&
-                            w2_pre_step(L, job, C, sps);
+                            w2_pre_step(L, job, rec_cap, sps);
             }
             const long long tr2 = clock64();
             W2Plan np; // (built in registers, stored by t0)
@@ -704,7 +711,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     __syncthreads();
     if (t0) {
         const bool in_attempt = S.in_attempt != 0;
-        if (in_attempt && S.n_att < C.recs_per_job) {
+        if (in_attempt && S.n_att < rec_cap) {
             AttemptRec &r = recs[S.n_att];
             r.status = (S.stop_reason == 3) ? kAttemptAtHeader : kAttemptOutOfData;
             r.start_pos = S.att_start; r.trig_pos = S.att_trig; r.hdr_pos = S.att_hdr; r.end_pos = S.pos;
@@ -713,20 +720,50 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             r.cr_prev = S.att_cr_prev; r.hdr_ambig = S.att_ambig; r.n_symbols = S.n_sym; r.frame_len = 0;
         }
         JobResult &jr = C.results[jid];
-        jr.final_pos = in_attempt ? S.att_start : S.pos;
-        jr.n_attempts = S.n_att + (in_attempt ? 1u : 0u);
-        jr.final_cr = S.cr;
-        jr.npush = in_attempt ? 0u : S.npush;
-        for (int i = 0; i < 4; i++) jr.push_tail[i] = S.push_tail[i];
-        jr.stop_reason = (uint32_t)S.stop_reason;
-        jr.n_steps = S.n_steps < C.trace_cap ? S.n_steps : C.trace_cap;
-        jr.pad = in_attempt ? 1u : 0u;
-        jr.tail_valid = 0; // Job.probe_limit is not implemented by this kernel: the host launches explicit probe jobs
-        W2Stats &Q = W.stats;
-        if (Q.prev_state >= 0) { Q.cyc[Q.prev_state] += (uint32_t)((clock64() - Q.prev_t) >> 6); Q.rounds[Q.prev_state]++; }
-        for (int i = 0; i < 6; i++) { jr.cyc[i] = Q.cyc[i]; jr.rounds[i] = Q.rounds[i]; }
-        for (int i = 0; i < 4; i++) jr.ctl[i] = Q.ctl[i];
+        const int64_t e_pos = in_attempt ? S.att_start : S.pos;
+        const uint32_t e_natt = S.n_att + (in_attempt ? 1u : 0u), e_npush = in_attempt ? 0u : S.npush, e_pad = in_attempt ? 1u : 0u;
+        bool go = false;
+        if (phase == 0) {
+            jr.final_pos = e_pos;
+            jr.n_attempts = e_natt;
+            jr.final_cr = S.cr;
+            jr.npush = e_npush;
+            for (int i = 0; i < 4; i++) jr.push_tail[i] = S.push_tail[i];
+            jr.stop_reason = (uint32_t)S.stop_reason;
+            jr.n_steps = S.n_steps < C.trace_cap ? S.n_steps : C.trace_cap;
+            jr.pad = e_pad;
+            jr.tail_valid = 0;
+            go = job.probe_limit > job.scan_limit && S.stop_reason == 0 && !in_attempt && !trace && e_natt < C.recs_per_job;
+            W.ph_go = go ? 1u : 0u; W.ph_start = e_pos; W.ph_cr = S.cr; W.ph_natt = e_natt; W.ph_pad = 0;
+        } else {
+            jr.tail_valid = 1; jr.tail_first_rec = W.ph_natt;
+            jr.tail_final_pos = e_pos; jr.tail_n_attempts = e_natt; jr.tail_final_cr = S.cr; jr.tail_npush = e_npush;
+            for (int i = 0; i < 4; i++) jr.tail_push_tail[i] = S.push_tail[i];
+            jr.tail_stop_reason = (uint32_t)S.stop_reason; jr.tail_pad = e_pad; jr.tail_rsv = 0;
+        }
+        if (!go) { // last phase of this job: the per-state time accounting goes out with it
+            W2Stats &Q = W.stats;
+            if (Q.prev_state >= 0) { Q.cyc[Q.prev_state] += (uint32_t)((clock64() - Q.prev_t) >> 6); Q.rounds[Q.prev_state]++; }
+            for (int i = 0; i < 6; i++) { jr.cyc[i] = Q.cyc[i]; jr.rounds[i] = Q.rounds[i]; }
+            for (int i = 0; i < 4; i++) jr.ctl[i] = Q.ctl[i];
+        }
     }
+    if (phase == 1) break;
+    __syncthreads();
+    if (!W.ph_go) break;
+    // the probe: a job from the end state of the job proper to the next header (what decode_streams would launch)
+    { // wave-uniform values: keep them in SGPRs
+        const int64_t st = W.ph_start;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)st), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)st >> 32));
+        const uint32_t natt = __builtin_amdgcn_readfirstlane(W.ph_natt);
+        job.start = (int64_t)(((uint64_t)hi << 32) | lo);
+        job.cr_prev = __builtin_amdgcn_readfirstlane(W.ph_cr);
+        job.scan_limit = job.probe_limit; job.stop_at_header = 1; job.max_attempts = 0;
+        recs += natt;
+        rec_cap = C.recs_per_job - natt;
+    }
+    __syncthreads(); // everyone has read the hand-over before the control thread re-initialises the state
+    } // phase
 }
 
 constexpr int kW2WavesSf7 = 8, kW2WavesSf8 = 8;
