@@ -101,6 +101,7 @@ struct JobResult {
     uint32_t tail_valid, tail_first_rec, tail_n_attempts, tail_final_cr, tail_npush, tail_stop_reason, tail_pad, tail_rsv;
     float    tail_push_tail[4];
     uint32_t ctl[4];       // control wavefront inside decode rounds, shader clocks / 64: state copy-in, symbol loop, plan, copy-out
+    uint32_t dbg[6];       // diagnostics (walker2): HW_ID, XCC_ID, s_memrealtime (100 MHz) at the start and the end of the job, clock64 / 64 likewise
 };
 
 struct StepRec {           // mirrors lora_hip_step_t
@@ -124,7 +125,19 @@ struct LaunchCfg {
     StepRec *trace;          // n_jobs * trace_cap or nullptr
     uint32_t trace_cap;
     uint32_t n_jobs;
+    uint32_t *balance;       // kBalanceWords words, zero-initialised once (walker2: progress exchange between the workgroups of a CU), or nullptr
 };
+constexpr uint32_t kBalanceCus = 2048;                 // (XCC_ID, SE, SH, CU) flattened
+constexpr uint32_t kBalanceWords = 3u * kBalanceCus;   // per CU: remaining work of its two workgroups, claim counter
+
+// burst envelope pre-pass (segment planning): one entry per stream, blocks of one symbol
+struct EnvStream {
+    uint64_t off;          // first item of the stream
+    uint32_t first_block;  // index of its first block in E
+    uint32_t n_blocks;
+};
+int launch_envelope(const float2 *iq, const EnvStream *d_streams, uint32_t n_streams, uint32_t total_blocks, uint32_t sps, float *d_E,
+                    unsigned long long *d_edges, uint32_t edge_cap, uint32_t *d_ctl, void *stream);
 
 int launch_walker(const DevParams &p, const LaunchCfg &c, void *stream);
 int launch_demod_symbols(const DevParams &p, const float2 *iq, const int64_t *d_offsets, uint32_t n,

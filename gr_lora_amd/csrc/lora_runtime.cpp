@@ -124,6 +124,14 @@ struct lora_hip_decoder {
     PinnedBuf<Job> p_jobs;             // staging for run_jobs: jobs up, results and the first attempt records down
     PinnedBuf<JobResult> p_res;
     PinnedBuf<AttemptRec> p_recs;
+    // burst-envelope pre-pass (segment planning)
+    DevBuf<uint32_t> d_balance;             // LaunchCfg::balance, zeroed when allocated
+    DevBuf<EnvStream> d_env_streams;
+    DevBuf<float> d_env_E;
+    DevBuf<unsigned long long> d_env_buf;   // [0] edge count, then the edge list
+    PinnedBuf<EnvStream> p_env_streams;
+    PinnedBuf<unsigned long long> p_env_buf;
+    float envelope_ms = 0.0f;
     std::vector<lora_hip_step_t> trace;
     lora_hip_timing_t timing{};
     std::string err;
@@ -320,6 +328,12 @@ lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vec
     c.iq = d_iq; c.jobs = h->d_jobs.p; c.results = h->d_results.p; c.recs = h->d_recs.p; c.recs_per_job = recs_per_job;
     c.scratch = need_scratch ? h->d_scratch.p : nullptr;
     c.trace = trace_cap ? h->d_trace.p : nullptr; c.trace_cap = trace_cap; c.n_jobs = nj;
+    static const bool no_balance = getenv("LORA_HIP_NO_BALANCE") != nullptr;
+    if (!h->d_balance.p && !no_balance) {
+        HIP_TRY(h, h->d_balance.reserve(kBalanceWords));
+        HIP_TRY(h, hipMemsetAsync(h->d_balance.p, 0, kBalanceWords * sizeof(uint32_t), st));
+    }
+    c.balance = no_balance ? nullptr : h->d_balance.p;
     HIP_TRY(h, hipEventRecord(h->ev0, st));
     if (launch_walker(h->P, c, st) != 0) return fail(h, LORA_HIP_ERR_HIP, "walker launch failed: %s", hipGetErrorString(hipGetLastError()));
     HIP_TRY(h, hipEventRecord(h->ev1, st));
@@ -353,6 +367,17 @@ lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vec
         double mean = 0; for (double t : tot) mean += t; mean /= nj;
         fprintf(stderr, "[lora_hip] job kcycles over %u jobs: min %.0f p50 %.0f p90 %.0f max %.0f mean %.0f\n", nj, tot[0] / 1e3, tot[nj / 2] / 1e3,
                 tot[(size_t)(nj * 0.9)] / 1e3, tot[nj - 1] / 1e3, mean / 1e3);
+    }
+    if (const char *tl = getenv("LORA_HIP_JOB_TIMELINE")) { // diagnostics: one line per job, appended to the named file
+        if (FILE *f = fopen(tl, "a")) {
+            fprintf(f, "# launch of %u jobs: job hw_id xcc_id t_start t_end(100MHz) cyc[6] x64 start scan_limit n_att\n", nj);
+            for (uint32_t j = 0; j < nj; j++) {
+                const JobResult &r = out.res[j];
+                fprintf(f, "%u %u %u %u %u %u %u %u %u %u %u %lld %lld %u %u %u %u %u\n", j, r.dbg[0], r.dbg[1], r.dbg[2], r.dbg[3], r.cyc[0], r.cyc[1], r.cyc[2], r.cyc[3], r.cyc[4], r.cyc[5],
+                        (long long)jobs[j].start, (long long)jobs[j].scan_limit, r.n_attempts, r.dbg[5] - r.dbg[4], r.rounds[5], r.rounds[0], r.rounds[2]);
+            }
+            fclose(f);
+        }
     }
     // copy back only the attempt records that were written
     uint32_t max_att = 0;
@@ -395,6 +420,53 @@ void append_trace(lora_hip_decoder *h, const RunOut &out, uint32_t job_index, ui
     }
 }
 
+// Gap starts of every stream (item positions, ascending) from the energy envelope; see envelope_kernel.
+lora_hip_status quiet_edges(lora_hip_decoder *h, const float2 *d_iq, const std::vector<StreamDesc> &streams, hipStream_t st,
+                            std::vector<std::vector<int64_t>> &edges)
+{
+    const uint32_t sps = h->P.sps, ns = (uint32_t)streams.size();
+    HIP_TRY(h, h->p_env_streams.reserve(ns));
+    uint64_t nb = 0;
+    for (uint32_t i = 0; i < ns; i++) {
+        const uint64_t n = streams[i].len / sps;
+        if (n == 0 || nb + n > 0xffffffffull) return LORA_HIP_ERR_ARG; // caller falls back to the fixed grid
+        h->p_env_streams.p[i] = EnvStream{streams[i].off, (uint32_t)nb, (uint32_t)n};
+        nb += n;
+    }
+    const uint32_t head = 1u;                                        // the edge count, in 8-byte units
+    const uint32_t cap = (uint32_t)std::min<uint64_t>(nb / 8u + 64u, 1u << 20);
+    constexpr uint32_t kEager = 4096;                                // edges fetched together with the count
+    HIP_TRY(h, h->d_env_streams.reserve(ns));
+    HIP_TRY(h, h->d_env_E.reserve(nb));
+    HIP_TRY(h, h->d_env_buf.reserve((size_t)head + cap));
+    HIP_TRY(h, h->p_env_buf.reserve((size_t)head + cap));
+    HIP_TRY(h, hipMemcpyAsync(h->d_env_streams.p, h->p_env_streams.p, ns * sizeof(EnvStream), hipMemcpyHostToDevice, st));
+    unsigned long long *buf = h->d_env_buf.p;
+    static const bool dbg = getenv("LORA_HIP_DEBUG") != nullptr;
+    if (dbg) HIP_TRY(h, hipEventRecord(h->ev0, st));
+    if (launch_envelope(d_iq, h->d_env_streams.p, ns, (uint32_t)nb, sps, h->d_env_E.p, buf + head, cap, (uint32_t *)buf, st) != 0)
+        return fail(h, LORA_HIP_ERR_HIP, "envelope launch failed: %s", hipGetErrorString(hipGetLastError()));
+    if (dbg) HIP_TRY(h, hipEventRecord(h->ev1, st));
+    const uint32_t eager = std::min(cap, kEager);
+    HIP_TRY(h, hipMemcpyAsync(h->p_env_buf.p, buf, ((size_t)head + eager) * 8u, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    if (dbg) { float ms = 0; if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->envelope_ms = ms; }
+    const uint32_t n_found = *(const uint32_t *)h->p_env_buf.p;
+    if (n_found > cap) return LORA_HIP_ERR_ARG;                  // more gaps than the list holds: not burst traffic
+    if (n_found > eager) {
+        HIP_TRY(h, hipMemcpyAsync(h->p_env_buf.p + head + eager, buf + head + eager, (size_t)(n_found - eager) * 8u, hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipStreamSynchronize(st));
+    }
+    unsigned long long *e = h->p_env_buf.p + head;
+    std::sort(e, e + n_found);                                       // by stream, then position (the device appends in any order)
+    edges.assign(ns, {});
+    for (uint32_t k = 0; k < n_found; k++) {
+        const uint32_t si = (uint32_t)(e[k] >> 40);
+        if (si < ns) edges[si].push_back((int64_t)(e[k] & ((1ull << 40) - 1ull)) * (int64_t)sps);
+    }
+    return LORA_HIP_OK;
+}
+
 // The device environment of the scheduler (lora_stitch.hpp): jobs are run by the walker kernels.
 struct DeviceEnv {
     lora_hip_decoder *h;
@@ -410,6 +482,10 @@ struct DeviceEnv {
     }
     bool tracing() const { return (h->cfg.flags & LORA_HIP_FLAG_TRACE) != 0; }
     bool implicit() const { return h->P.implicit != 0; }
+    bool quiet_edges(const std::vector<StreamDesc> &streams, std::vector<std::vector<int64_t>> &edges)
+    {
+        return ::quiet_edges(h, d_iq, streams, st, edges) == LORA_HIP_OK;
+    }
     int run_jobs(const std::vector<Job> &jobs, uint32_t rpj, uint32_t trace_cap, RunOut &out)
     {
         return ::run_jobs(h, d_iq, jobs, rpj, trace_cap, st, out) == LORA_HIP_OK ? 0 : -1;
@@ -419,6 +495,11 @@ struct DeviceEnv {
     void count_jobs(uint32_t n) { h->timing.jobs += n; }
     void count_probes(uint32_t n) { h->timing.probes += n; }
     void count_slow_path() { h->timing.slow_path_relaunches++; }
+    void note_plan(bool burst_aware, size_t n_segs)
+    {
+        static const bool dbg = getenv("LORA_HIP_DEBUG") != nullptr;
+        if (dbg) fprintf(stderr, "[lora_hip] segment plan: %s, %zu segments (envelope kernels %.3f ms)\n", burst_aware ? "burst-aware" : "fixed grid", n_segs, burst_aware ? h->envelope_ms : 0.0f);
+    }
     double walker_ms() const { return h->timing.walker_ms; }
 };
 
@@ -497,6 +578,7 @@ void lora_hip_destroy(lora_hip_decoder_t *h)
     h->d_jobs.release(); h->d_results.release(); h->d_recs.release(); h->d_scratch.release();
     h->d_trace.release(); h->d_staging.release(); h->d_offsets.release(); h->d_bins.release();
     h->p_jobs.release(); h->p_res.release(); h->p_recs.release();
+    h->d_balance.release(); h->d_env_streams.release(); h->d_env_E.release(); h->d_env_buf.release(); h->p_env_streams.release(); h->p_env_buf.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;

@@ -6,8 +6,9 @@
 //
 // Env must provide:  uint32_t sps(), ctor_cr(), segment_symbols(), resident_slots();  bool tracing(), implicit();
 //   int  run_jobs(const std::vector<Job> &, uint32_t recs_per_job, uint32_t trace_cap, RunOut &);   (0 = ok)
+//   bool quiet_edges(const std::vector<StreamDesc> &, std::vector<std::vector<int64_t>> &);   (gap starts per stream, false = none)
 //   void publish(const AttemptRec &, StreamDesc &);   void append_trace(const RunOut &, uint32_t job, uint32_t cap, int64_t base);
-//   void count_jobs(uint32_t), count_probes(uint32_t), count_slow_path();   double walker_ms();
+//   void count_jobs(uint32_t), count_probes(uint32_t), count_slow_path(), note_plan(bool burst_aware, size_t n_segments);   double walker_ms();
 #pragma once
 #include <algorithm>
 #include <chrono>
@@ -124,6 +125,63 @@ int run_serial(Env &env, StreamDesc &sd, Cursor &cur, int64_t limit, bool tracin
 
 inline int cr_class(uint32_t cr) { return cr >= 3u ? 2 : (cr >= 1u ? 1 : 0); }
 
+// Burst-aware segment plan.  `edges[i]` holds the positions where stream i goes quiet (the start of every gap between
+// bursts, ascending).  Cuts are placed only at such positions and chosen greedily so that every segment carries about
+// the same load (items plus a fixed acquisition cost per burst) and the whole plan is at most `slots` segments: one
+// resident wave of workgroups, each with the same number of packets.  Compared with the fixed grid this removes the
+// spread between jobs that happen to hold one packet more than their neighbours, the scan from a cut in mid-packet
+// to the next preamble, and the failed attempt on the truncated packet.  Returns false (fixed grid) when the streams
+// do not look like dense burst traffic.  Only where the cuts are changes, never what is decoded.
+inline bool plan_burst_segments(const std::vector<StreamDesc> &streams, const std::vector<std::vector<int64_t>> &edges, uint32_t sps,
+                                uint32_t slots, uint64_t nominal, std::vector<std::vector<int64_t>> &cuts)
+{
+    if (edges.size() != streams.size() || slots == 0) return false;
+    size_t n_edges = 0;
+    for (const auto &e : edges) n_edges += e.size();
+    if (n_edges < slots) return false;                       // fewer bursts than workgroups: the fixed grid spreads the scan better
+    const int64_t acq = 40ll * sps;                          // DETECT + SYNC + FIND_SFD of one packet, in items of payload work
+    auto weight = [&](const std::vector<int64_t> &e, size_t k, int64_t len) { // burst k (up to its gap), k == size(): the rest
+        const int64_t a = k ? e[k - 1] : 0;
+        return k < e.size() ? (e[k] - a) + acq : len - a;
+    };
+    double total = 0;
+    for (size_t i = 0; i < streams.size(); i++)
+        for (size_t k = 0; k <= edges[i].size(); k++) total += (double)weight(edges[i], k, (int64_t)streams[i].len);
+    double target = total / slots;
+    for (int attempt = 0; attempt < 12; attempt++, target *= 1.07) {
+        size_t n_segs = 0;
+        cuts.assign(streams.size(), {});
+        for (size_t i = 0; i < streams.size(); i++) {
+            const std::vector<int64_t> &e = edges[i];
+            const int64_t len = (int64_t)streams[i].len;
+            double acc = 0;
+            for (size_t k = 0; k < e.size(); k++) {
+                acc += (double)weight(e, k, len);
+                if (acc >= target - 0.5 * (double)weight(e, k + 1, len) && len - e[k] > 8ll * sps && e[k] > (cuts[i].empty() ? 0 : cuts[i].back())) {
+                    cuts[i].push_back(e[k]);
+                    acc = 0;
+                }
+            }
+            // stretches without a gap (back-to-back or weak packets): fall back to the grid inside them
+            std::vector<int64_t> c;
+            int64_t prev = 0;
+            for (size_t k = 0; k <= cuts[i].size(); k++) {
+                const int64_t b = k < cuts[i].size() ? cuts[i][k] : len;
+                if ((uint64_t)(b - prev) > 3u * nominal) {
+                    const uint64_t parts = ((uint64_t)(b - prev) + 2u * nominal - 1u) / (2u * nominal);
+                    for (uint64_t q = 1; q < parts; q++) c.push_back(prev + (int64_t)((uint64_t)(b - prev) * q / parts));
+                }
+                if (k < cuts[i].size()) c.push_back(b);
+                prev = b;
+            }
+            cuts[i].swap(c);
+            n_segs += cuts[i].size() + 1u;
+        }
+        if (n_segs <= slots) return true;
+    }
+    return false;
+}
+
 // Decodes a set of independent streams.
 //
 // Every stream is cut into fixed segments.  Round 1 runs one walker job per
@@ -156,6 +214,15 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
     if (seg < 16ull * sps) seg = 16ull * sps;
     const bool segmenting = !tracing && !env.implicit();
 
+    // auto mode on a batch worth cutting up: look for the gaps between bursts and plan the cuts around them
+    std::vector<std::vector<int64_t>> cuts;
+    bool planned = false;
+    static const bool no_plan = getenv("LORA_HIP_NO_BURST_PLAN") != nullptr;
+    if (segmenting && env.segment_symbols() == 0 && !no_plan && total > 2ull * seg) {
+        std::vector<std::vector<int64_t>> edges;
+        if (env.quiet_edges(streams, edges)) planned = plan_burst_segments(streams, edges, sps, slots, seg, cuts);
+    }
+
     struct Seg { uint32_t stream; int64_t b0, b1; };
     std::vector<Seg> segs;
     std::vector<size_t> first_seg(streams.size() + 1, 0);
@@ -163,6 +230,12 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
         first_seg[i] = segs.size();
         StreamDesc &sd = streams[i];
         sd.cr_out = sd.cr_in; sd.final_pos = 0; sd.incomplete = false;
+        if (planned) { // burst-aware cuts
+            int64_t prev = 0;
+            for (int64_t c : cuts[i]) { segs.push_back(Seg{(uint32_t)i, prev, c}); prev = c; }
+            segs.push_back(Seg{(uint32_t)i, prev, (int64_t)sd.len});
+            continue;
+        }
         uint64_t n = 1;
         if (segmenting && sd.len > seg + seg / 2) n = (sd.len + seg - 1) / seg;
         for (uint64_t k = 0; k < n; k++)
@@ -170,6 +243,7 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
     }
     first_seg[streams.size()] = segs.size();
     if (segs.empty()) return 0;
+    env.note_plan(planned, segs.size());
 
     // ---- round 1: every segment speculatively
     std::vector<Job> jobs(segs.size());

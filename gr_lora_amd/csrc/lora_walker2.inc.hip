@@ -27,6 +27,8 @@ struct alignas(16) W2Plan {
     int32_t buf;          // spec buffer the workers fill (kPlanDecode)
     int32_t resolve_prev; // kPlanDecode: spec[buf ^ 1] holds the previous round, to be resolved now
     int32_t n_win;        // windows the workers evaluate this round (kPlanDecode: 0 = resolve-only round)
+    int32_t prev_n;       // kPlanDecode with resolve_prev: windows of the previous round (it ended n_win * sps before pos)
+    int32_t pad;
 };
 
 struct alignas(16) W2State {
@@ -63,6 +65,8 @@ struct alignas(16) W2Shared {
     W2Stats  stats;
     int64_t  ph_start;    // hand-over from the job proper to its tail probe (Job.probe_limit): start position,
     uint32_t ph_go, ph_cr, ph_natt, ph_pad; // go flag, d_phdr.cr, attempt records used so far
+    uint32_t det_streak;  // consecutive DETECT rounds planned so far (control thread): the first of a streak looks at fewer windows
+    uint32_t prio;        // priority of the worker wavefronts for the coming rounds (see the balance exchange in the round loop)
     uint32_t words_pk[2]; // d_words of the current block, one byte per word (words < 256 for SF <= 8); control thread only
 };
 
@@ -272,10 +276,13 @@ __device__ __forceinline__ void w2_sfd_window(const DevParams &P, const W2Tabs &
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));
     float f[J];
+    const v2f *__restrict__ pv = reinterpret_cast<const v2f *>(p);
 #pragma unroll
-    for (int j = 0; j < J; j++) {
-        const int n = j * 64 + lane;
-        f[j] = (n >= 1) ? ifreq_prod(p[n - 1], p[n]) : 0.0f; // ifreq[n-1]; the n-1 loads hit the lines just fetched
+    for (int j = 0; j < J; j += 2) { // two samples per packed evaluation (same arithmetic as the demodulator's)
+        const int n0 = j * 64 + lane, n1 = n0 + 64;
+        const v2f fp = ifreq_prod_pk(pv[n0 >= 1 ? n0 - 1 : 0], pv[n0], pv[n1 - 1], pv[n1]); // ifreq[n-1]; the n-1 loads hit the lines just fetched
+        f[j] = (n0 >= 1) ? fp.x : 0.0f;
+        f[j + 1] = fp.y;
     }
     // one-pass Pearson over the n = sps-1 points k = 0 .. sps-2
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
@@ -323,17 +330,26 @@ __device__ __forceinline__ void w2_sfd_window(const DevParams &P, const W2Tabs &
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int i = lane - 31; // this lane's lag
+    // running sums of the head (lanes 0..31) and of the tail (lanes 32..63): lane 32 + q ends up with T_{q+1}, lane q with
+    // H_{q+1}.  At most 32 terms of magnitude < pi: float keeps them to ~1e-6, far below the spacing of the c_i.
+    float ps = scr[lane];
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        const float up = __shfl_up(ps, o, 32);
+        if ((lane & 31) >= o) ps += up;
+    }
+    const float hsum = __shfl(ps, lane < 31 ? 30 - lane : 0, 64); // H_{-i} for the negative lags
     float c_i = -3.0e38f;
     if (lane <= 62) {
         const double a = P.sync_a, b = P.sync_b;
         const double wd = (double)T.v[2 * SPS - 1] - (a + b * (double)(SPS - 1));
-        double edge = 0.0;
+        double edge;
         float wrap_f;
         if (i >= 0) {
-            for (int q = 0; q < i; q++) edge -= (double)scr[32 + q];   // T_i
+            edge = i > 0 ? -(double)ps : 0.0;                           // -T_i
             wrap_f = scr[32 + i];                                       // fe[sps-1-i]
         } else {
-            for (int q = 0; q < -i; q++) edge += (double)scr[q];       // H_{-i}
+            edge = (double)hsum;                                        // H_{-i}
             wrap_f = scr[-i - 1];                                       // fe[-i-1]
         }
         c_i = (float)(a * g0 + b * ((double)i * g0 + g1) + b * (double)SPS * edge + wd * (double)wrap_f);
@@ -349,6 +365,69 @@ __device__ __forceinline__ void w2_sfd_window(const DevParams &P, const W2Tabs &
     fine_out = -lag;
 }
 
+// SYNC (:770-783, detect_upchirp :392-413): this thread's best shift of the sliding correlation of f[0 .. 2 sps) with the
+// ideal upchirp ifreq.  Kept out of line: it runs once per packet and its double-precision temporaries would otherwise
+// raise the register pressure of the whole state machine.
+template <int SF, int WAVES>
+__device__ __attribute__((noinline)) void w2_sync_closed_form(const float *f2, double *pre, double sync_a, double sync_b, float &bv, int &bi)
+{
+    constexpr uint32_t sps = 8u << SF, kW2 = 64u * WAVES;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+                // C[i] = sum_{k < n} f[i+k] u[k], n = sps-1, i < sps.  d_upchirp_ifreq is a line a + b k (up to float noise
+                // ~1e-5 of the peak, below the rounding of the reference's own float sum), so
+                //   C[i] = a S0[i] + b S1[i],   S0[i] = sum_k f[i+k],   S1[i] = sum_k k f[i+k]
+                // and both come from prefix sums of f and (t - sps) f in double: O(sps) instead of O(sps^2).
+                // Prefixes are kept per chunk of CH samples (256 chunks); a thread adds the few samples up to its shift.
+                constexpr uint32_t NCH = 256u, CH = 2u * sps / NCH, n = sps - 1u;
+                double sF = 0.0, sG = 0.0;
+                if (threadIdx.x < NCH) {
+    #pragma unroll
+                    for (uint32_t q = 0; q < CH; q += 4u) {
+                        const uint32_t t = threadIdx.x * CH + q;
+                        const float4 fv = *reinterpret_cast<const float4 *>(f2 + t);
+                        const double tc = (double)((int)t - (int)sps);
+                        sF += ((double)fv.x + (double)fv.y) + ((double)fv.z + (double)fv.w);
+                        sG += tc * (double)fv.x + (tc + 1.0) * (double)fv.y + (tc + 2.0) * (double)fv.z + (tc + 3.0) * (double)fv.w;
+                    }
+                }
+                double iF = sF, iG = sG; // inclusive scan over the wavefront's chunks
+    #pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const double uF = __shfl_up(iF, o, 64), uG = __shfl_up(iG, o, 64);
+                    if (lane >= o) { iF += uF; iG += uG; }
+                }
+                if (threadIdx.x < NCH && lane == 63) { pre[2u * NCH + wave] = iF; pre[2u * NCH + 4u + wave] = iG; }
+                __syncthreads();
+                if (threadIdx.x < NCH) { // exclusive prefix of every chunk
+                    double oF = iF - sF, oG = iG - sG;
+                    for (int w = 0; w < wave; w++) { oF += pre[2u * NCH + w]; oG += pre[2u * NCH + 4u + w]; }
+                    pre[threadIdx.x] = oF; pre[NCH + threadIdx.x] = oG;
+                }
+                __syncthreads();
+                constexpr uint32_t R = sps / kW2; // consecutive shifts per thread
+                const uint32_t i0 = threadIdx.x * R;
+                auto prefix_at = [&](uint32_t j, double &F, double &G) { // sums over t < j
+                    const uint32_t c = j / CH;
+                    F = pre[c]; G = pre[NCH + c];
+                    for (uint32_t t = c * CH; t < j; t++) { const double fv = (double)f2[t]; F += fv; G += (double)((int)t - (int)sps) * fv; }
+                };
+                double F0, G0, F1, G1;
+                prefix_at(i0, F0, G0);
+                prefix_at(i0 + n, F1, G1);
+                double s0 = F1 - F0, s1 = (G1 - G0) + (double)((int)sps - (int)i0) * s0;
+                bv = 0.0f; // max_correlation = 0 (:400)
+                bi = 0x7fffffff;
+    #pragma unroll
+                for (uint32_t r = 0; r < R; r++) {
+                    const uint32_t i = i0 + r;
+                    const float c = (float)(sync_a * s0 + sync_b * s1);
+                    if (c > bv) { bv = c; bi = (int)i; }
+                    const double fin = (double)f2[i + n], fout = (double)f2[i];
+                    s0 += fin - fout;
+                    s1 += (double)n * fin - s0;
+                }
+}
+
 // ---- the kernel -----------------------------------------------------------------------------------------
 template <int SF, int WAVES>
 __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg &C)
@@ -362,15 +441,13 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     W2State &S = W.st;
     Shared &sh = W.sh;
     // LDS carve-up after W2Shared: f2[2 sps] | v[3 sps + 40 (padded to 4)] | dd[sps] | twiddle block of the wave
-    // demodulator | partial sums of the SYNC correlation
+    // demodulator | chunk prefix sums of the SYNC correlation
     float *f2 = reinterpret_cast<float *>(smem + ((sizeof(W2Shared) + 15) & ~(size_t)15));
     float *vl = f2 + 2 * SPS;
     constexpr uint32_t NV = (3u * SPS + 40u + 3u) & ~3u;
     float *ddl = vl + NV;
     v4f *tab4 = reinterpret_cast<v4f *>(ddl + SPS);
-    // SYNC partial sums of the k-slices > 0: on top of f2 when they fit there (the f2 window is dead by then)
-    constexpr bool kPartInF2 = ((kW2 / (SPS / 4)) - 1) * (SPS / 4) * 16 <= 2 * SPS * 4;
-    float4 *part = kPartInF2 ? reinterpret_cast<float4 *>(f2) : reinterpret_cast<float4 *>(tab4 + WaveGeom<SF>::n_v4f);
+    double *pre = reinterpret_cast<double *>(tab4 + WaveGeom<SF>::n_v4f); // SYNC: chunk prefix sums (2 x 256) + per-wavefront totals
 
     const uint32_t jid = blockIdx.x;
     if (jid >= C.n_jobs) return;
@@ -385,17 +462,23 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     const bool t0 = threadIdx.x == kW2Workers * 64;         // the control thread: sole owner of the decoder state S
     if (is_ctl) __builtin_amdgcn_s_setprio(2);              // its serial bookkeeping is on every round's critical path
 
+    const uint32_t dbg_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime(), dbg_c0 = (uint32_t)(clock64() >> 6);
     const WaveTabs FT = wave_tabs_to_lds<SF>(P, tab4, vl, kW2);
     for (uint32_t i = threadIdx.x; i < sps; i += kW2) ddl[i] = P.down_ifreq[i] - P.down_ifreq_avg;
 
     // plan for the next round from the TRUE state (control thread only)
     auto plan_from = [&](W2State &S, W2Plan &pl) {
-        pl.buf = 0; pl.resolve_prev = 0; pl.n_win = kW2Workers; pl.pos = S.pos;
+        pl.buf = 0; pl.resolve_prev = 0; pl.n_win = kW2Workers; pl.pos = S.pos; pl.prev_n = 0; pl.pad = 0;
         if (!S.done) (void)w2_pre_step(S, job, rec_cap, sps);
         if (S.done) { pl.mode = kPlanExit; return; }
         if (S.fin_pending) { pl.mode = kPlanFinalize; return; }
+        if (S.state != kDetect) W.det_streak = 0u;
         switch (S.state) {
-        case kDetect: pl.mode = kPlanDetect; break;
+        case kDetect:
+            // windows per worker: a preamble usually follows within a few symbols of a job's start or a packet's end, so
+            // the first round of a streak evaluates one window per worker and only the following ones kW2DetectK
+            pl.mode = kPlanDetect; pl.n_win = W.det_streak++ == 0u ? 1 : kW2DetectK;
+            return;
         case kSync: pl.mode = kPlanSync; break;
         case kFindSfd: pl.mode = kPlanSfd; break;
         case kPause: pl.mode = kPlanPause; break;
@@ -411,6 +494,20 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     auto plan_from_state = [&](W2Plan &pl) { plan_from(S, pl); };
 
     W2Tabs T{vl, ddl, W.red};
+    // Balance between the two workgroups of a CU.  The SIMDs favour the older wavefronts, so of two equal jobs sharing a
+    // CU the one dispatched first runs ahead and finishes early, and the other then runs out its rest alone at well under
+    // the CU's throughput (measured: 407 vs 495 us for equal work).  Each control thread therefore publishes its job's
+    // remaining work every round and reads its neighbour's; the workers of the job with more left run at raised priority.
+    uint32_t *bal_mine = nullptr, *bal_other = nullptr;
+    uint32_t bal_rem = 0xffffffffu, bal_seen = 0u, bal_slot = 0u; // control thread only
+    if (t0) W.prio = 0u;
+    if (t0 && C.balance) {
+        const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        const uint32_t cu = ((xcc & 7u) << 8) | ((hw >> 8) & 0xffu);
+        bal_slot = atomicAdd(&C.balance[2u * kBalanceCus + cu], 1u) & 1u;
+        bal_mine = C.balance + 2u * cu + bal_slot;
+        bal_other = C.balance + 2u * cu + (bal_slot ^ 1u);
+    }
     // Phase 0 is the job proper.  Phase 1 (Job.probe_limit): having reached its scan limit the workgroup runs what a
     // separate probe job started from its end state would run -- a FRESH job (state re-initialised, tables kept) that
     // stops at the next header -- and reports it as the "tail"; the host then needs no second launch.
@@ -422,6 +519,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         S.att_start = job.start; S.att_trig = -1; S.att_hdr = -1; S.att_cr_prev = job.cr_prev;
         if (phase == 0) W.stats = W2Stats{};
         W.stats.prev_state = -1;
+        W.det_streak = 0u;
         plan_from_state(W.plan[0]);
     }
 
@@ -438,19 +536,34 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             if (Q.prev_state >= 0) { Q.cyc[Q.prev_state] += (uint32_t)((t_start - Q.prev_t) >> 6); Q.rounds[Q.prev_state]++; }
             Q.prev_state = sidx; Q.prev_t = t_start;
         }
+        if (t0 && bal_mine) { // decision from the previous round's sample (that load has long returned), then the next sample
+            W.prio = (bal_rem > bal_seen || (bal_rem == bal_seen && bal_slot != 0u)) ? 1u : 0u; // a tie goes to the younger workgroup
+            const int64_t target = phase == 0 ? job.scan_limit + (job.probe_limit > job.scan_limit ? 12 * (int64_t)sps : 0) : pos + 6 * (int64_t)sps;
+            const int64_t left = (target - pos) / (int64_t)sps;
+            bal_rem = left < 1 ? 1u : (left > 0x3fffffff ? 0x3fffffffu : (uint32_t)left);
+            __hip_atomic_store(bal_mine, bal_rem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bal_seen = __hip_atomic_load(bal_other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!is_ctl) { // (s_setprio takes an immediate)
+            if (W.prio) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
         const int64_t wpos = pos + (int64_t)wave * sps;
         const bool wvalid = !is_ctl && wave < plan.n_win && wpos + 2 * (int64_t)sps <= n_items;
 
-        if (plan.mode == kPlanDetect) { // every worker evaluates kW2DetectK consecutive windows
+        if (plan.mode == kPlanDetect) { // every worker evaluates kd (1 or kW2DetectK) consecutive windows
+            const int kd = plan.n_win;
             if (!is_ctl) {
-                const int64_t dpos = pos + (int64_t)wave * kW2DetectK * sps;
+                const int64_t dpos = pos + (int64_t)wave * kd * sps;
                 int nvalid = 0; // windows of this worker that lie inside the data (:91)
                 if (dpos + 2 * (int64_t)sps <= n_items) {
                     const int64_t fit = (n_items - dpos) / (int64_t)sps - 1;
-                    nvalid = fit < kW2DetectK ? (int)fit : kW2DetectK;
+                    nvalid = fit < kd ? (int)fit : kd;
                 }
                 float a[kW2DetectK][4];
-                if (nvalid > 0) w2_detect_windows<SF, kW2DetectK>(X + dpos, nvalid, a);
+                if (nvalid > 0) {
+                    if (kd == 1) w2_detect_window<SF>(X + dpos, a[0]);
+                    else w2_detect_windows<SF, kW2DetectK>(X + dpos, nvalid, a);
+                }
                 if (lane == 0) {
                     W.detn[wave] = nvalid;
                     for (int i = 0; i < kW2DetectK; i++)
@@ -462,13 +575,15 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 // the control wavefront evaluates all windows at once (lane q = window q); what the serial replay
                 // of :740-768 would do with them -- stop at the first trigger, at the scan limit or at the end of
                 // the data -- is then applied to the decoder state in one step
-                constexpr int NW = kW2Workers * kW2DetectK;
-                static_assert(NW <= 64, "one lane per DETECT window");
+                constexpr int NWmax = kW2Workers * kW2DetectK;
+                static_assert(NWmax <= 64, "one lane per DETECT window");
+                const int NW = kW2Workers * kd;
                 const int q = lane;
-                const bool valid = q < NW && (q % kW2DetectK) < W.detn[q / kW2DetectK];
+                const int qw = q / kd, qi = q - qw * kd; // worker and its window
+                const bool valid = q < NW && qi < W.detn[qw];
                 float autocorr = 0.0f, pushed = 0.0f, e2 = 0.0f;
                 if (valid) {
-                    const float *o = W.detf[q];
+                    const float *o = W.detf[qw * kW2DetectK + qi];
                     const float d0 = o[0], d1 = o[1], e1 = o[2];
                     e2 = o[3];
                     pushed = e1 / (float)sps; // :360
@@ -479,9 +594,10 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 W.red[q] = pushed; W.red[64 + q] = e2; W.red[128 + q] = autocorr;
                 __builtin_amdgcn_wave_barrier();
                 if (t0) {
+                    W2State L = S; // register copy: every field access in LDS is a ~130-cycle round trip
                     // steps q >= 1 are preceded by the loop-top checks: in DETECT outside an attempt only the scan limit
                     // can change between steps (the data end shows up as an invalid window)
-                    int64_t n_lim = (job.scan_limit - S.pos + (int64_t)sps - 1) / (int64_t)sps;
+                    int64_t n_lim = (job.scan_limit - L.pos + (int64_t)sps - 1) / (int64_t)sps;
                     if (n_lim < 1) n_lim = 1;
                     const int n_valid = (~vmask == 0ull) ? 64 : __builtin_ctzll(~vmask);
                     int n_max = n_valid < NW ? n_valid : NW;
@@ -492,31 +608,36 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                     if (nd > 0) {
                         if (trace) { // position-exact trace: one record per step
                             for (int i = 0; i < nd; i++) {
-                                if (S.n_steps + (uint32_t)i < C.trace_cap) {
-                                    StepRec &r = trace[S.n_steps + (uint32_t)i];
-                                    r.state = kDetect; r.consumed = (trig && i == nd - 1) ? 0 : (int32_t)sps; r.pos = S.pos + (int64_t)i * sps; r.bin = -1; r.fine = 0;
+                                if (L.n_steps + (uint32_t)i < C.trace_cap) {
+                                    StepRec &r = trace[L.n_steps + (uint32_t)i];
+                                    r.state = kDetect; r.consumed = (trig && i == nd - 1) ? 0 : (int32_t)sps; r.pos = L.pos + (int64_t)i * sps; r.bin = -1; r.fine = 0;
                                     r.value = W.red[128 + i]; r.stream = job.stream_id; r.cycles = (uint32_t)(clock64() - t_start); r.pad = 0;
                                 }
                             }
                         }
                         for (int i = (nd > 4 ? nd - 4 : 0); i < nd; i++) { // d_pwr_queue keeps the last 4 pushes (:360)
                             const float pv = W.red[i];
-                            if (S.npush >= 4u) { S.push_tail[0] = S.push_tail[1]; S.push_tail[1] = S.push_tail[2]; S.push_tail[2] = S.push_tail[3]; S.push_tail[3] = pv; }
-                            else S.push_tail[S.npush] = pv;
-                            S.npush++;
+                            if (L.npush >= 4u) { L.push_tail[0] = L.push_tail[1]; L.push_tail[1] = L.push_tail[2]; L.push_tail[2] = L.push_tail[3]; L.push_tail[3] = pv; }
+                            else { // (no dynamic index: that would put the whole copy in scratch)
+                                const uint32_t k = L.npush;
+                                if (k == 0u) L.push_tail[0] = pv; else if (k == 1u) L.push_tail[1] = pv; else if (k == 2u) L.push_tail[2] = pv; else L.push_tail[3] = pv;
+                            }
+                            L.npush++;
                         }
-                        if (nd > 4) S.npush += (uint32_t)(nd - 4);
-                        S.energy_threshold = W.red[64 + nd - 1] / 2.0f; // :357
-                        S.n_steps += (uint32_t)nd;
-                        S.pos += (int64_t)(trig ? nd - 1 : nd) * sps;
+                        if (nd > 4) L.npush += (uint32_t)(nd - 4);
+                        L.energy_threshold = W.red[64 + nd - 1] / 2.0f; // :357
+                        L.n_steps += (uint32_t)nd;
+                        L.pos += (int64_t)(trig ? nd - 1 : nd) * sps;
                         if (trig) {
-                            S.corr_fails = 0u;
-                            S.state = kSync;
-                            S.in_attempt = 1;
-                            S.att_trig = S.pos; S.att_hdr = -1; S.att_cr_prev = S.cr; S.att_ambig = 0; S.n_sym = 0;
+                            L.corr_fails = 0u;
+                            L.state = kSync;
+                            L.in_attempt = 1;
+                            L.att_trig = L.pos; L.att_hdr = -1; L.att_cr_prev = L.cr; L.att_ambig = 0; L.n_sym = 0;
                         }
                     }
-                    plan_from_state(next);
+                    W2Plan np;
+                    plan_from(L, np);
+                    next = np; S = L;
                 }
             }
             continue;
@@ -528,60 +649,18 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             __syncthreads();
             if (t0) f2[2u * sps - 1u] = f2[2u * sps - 2u]; // :243
             __syncthreads();
-            // C[i] = sum_{k < sps-1} f[i+k] u[k]; a thread owns 4 consecutive shifts and a slice of k
-            constexpr uint32_t tiles = sps / 4u, groups = kW2 / tiles; // SF7: 256 tiles x 2 slices, SF8: 512 x 1
-            const uint32_t tile = threadIdx.x % tiles, grp = threadIdx.x / tiles;
-            constexpr uint32_t kq = sps - 4u;                // taps handled 4 at a time
-            constexpr uint32_t slice = ((kq / groups) + 3u) & ~3u;
-            const uint32_t k_lo = grp * slice, k_hi = (grp + 1u == groups) ? kq : (grp + 1u) * slice;
-            const float *u = vl + sps; // d_upchirp_ifreq == d_upchirp_ifreq_v[sps ..] for k < sps-1
-            const float *fp = f2 + 4u * tile;
-            float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-            {
-                // software-pipelined: the loads of step k+4 are issued before the 16 FMAs of step k
-                float4 lo = *reinterpret_cast<const float4 *>(fp + k_lo);
-                float4 hi = *reinterpret_cast<const float4 *>(fp + k_lo + 4u);
-                float4 uk = *reinterpret_cast<const float4 *>(u + k_lo);
-                for (uint32_t k = k_lo; k < k_hi; k += 4u) {
-                    const uint32_t kn = (k + 4u < k_hi) ? k + 4u : k; // last step re-reads its own (in-range) data
-                    const float4 hi2 = *reinterpret_cast<const float4 *>(fp + kn + 4u);
-                    const float4 uk2 = *reinterpret_cast<const float4 *>(u + kn);
-                    c0 += lo.x * uk.x; c1 += lo.y * uk.x; c2 += lo.z * uk.x; c3 += lo.w * uk.x;
-                    c0 += lo.y * uk.y; c1 += lo.z * uk.y; c2 += lo.w * uk.y; c3 += hi.x * uk.y;
-                    c0 += lo.z * uk.z; c1 += lo.w * uk.z; c2 += hi.x * uk.z; c3 += hi.y * uk.z;
-                    c0 += lo.w * uk.w; c1 += hi.x * uk.w; c2 += hi.y * uk.w; c3 += hi.z * uk.w;
-                    lo = hi; hi = hi2; uk = uk2;
-                }
-                if (grp + 1u == groups) {
-                    for (uint32_t k = kq; k < sps - 1u; k++) { // 3 leftover taps
-                        const float uk1 = u[k];
-                        c0 += fp[k] * uk1; c1 += fp[k + 1u] * uk1; c2 += fp[k + 2u] * uk1; c3 += fp[k + 3u] * uk1;
-                    }
-                }
-            }
-            float bv = 0.0f; // max_correlation = 0 (:400)
-            int bi = 0x7fffffff;
-            if constexpr (groups > 1) { // slices > 0 hand their partial sums to slice 0
-                if constexpr (kPartInF2) __syncthreads();
-                if (grp > 0) part[(grp - 1u) * tiles + tile] = make_float4(c0, c1, c2, c3);
-                __syncthreads();
-                if (grp == 0) {
-                    for (uint32_t g = 1; g < groups; g++) { const float4 o = part[(g - 1u) * tiles + tile]; c0 += o.x; c1 += o.y; c2 += o.z; c3 += o.w; }
-                }
-            }
-            if (grp == 0) {
-                const int i0 = (int)(4u * tile);
-                if (c0 > bv) { bv = c0; bi = i0; }
-                if (c1 > bv) { bv = c1; bi = i0 + 1; }
-                if (c2 > bv) { bv = c2; bi = i0 + 2; }
-                if (c3 > bv) { bv = c3; bi = i0 + 3; }
-            }
+            float bv;
+            int bi;
+            w2_sync_closed_form<SF, WAVES>(f2, pre, P.sync_a, P.sync_b, bv, bi);
             w2_block_argmax_first<WAVES>(bv, bi, W.red);
             if (t0) {
                 const int32_t consumed = (bi == 0x7fffffff) ? 0 : bi; // :771
-                S.state = kFindSfd;
-                w2_end_step(S, job, C, recs, trace, kSync, consumed, -1, 0, bv, t_start);
-                plan_from_state(next);
+                W2State L = S;
+                L.state = kFindSfd;
+                w2_end_step(L, job, C, recs, trace, kSync, consumed, -1, 0, bv, t_start);
+                W2Plan np;
+                plan_from(L, np);
+                next = np; S = L;
             }
             continue;
         }
@@ -592,23 +671,29 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             if (wvalid) w2_sfd_window<SF>(P, T, X + wpos, c, fine);
             if (lane == 0 && !is_ctl) { W.specf[wave][0] = c; W.speci[0][wave][0] = wvalid ? 1 : 0; W.speci[0][wave][1] = fine; }
             __syncthreads();
-            if (t0) {
+            if (is_ctl) { // the whole control wavefront, uniformly, on a register copy of the state (as the decode rounds do)
+                W2State L = S;
+                const float my_c = lane < kW2Workers ? W.specf[lane][0] : 0.0f;
+                const int32_t my_v = lane < kW2Workers ? W.speci[0][lane][0] : 0, my_f = lane < kW2Workers ? W.speci[0][lane][1] : 0;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 for (int w = 0; w < kW2Workers; w++) {
-                    if (w > 0 && !w2_pre_step(S, job, rec_cap, sps)) break;
-                    if (!W.speci[0][w][0]) break;
-                    const float cw = W.specf[w][0];
+                    if (w > 0 && !w2_pre_step(L, job, rec_cap, sps)) break;
+                    if (!__builtin_amdgcn_readlane(my_v, w)) break;
+                    const float cw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int32_t, my_c), w));
                     int32_t fw = 0;
                     if (cw > 0.96f) { // :792
-                        S.state = kPause;
+                        L.state = kPause;
                     } else {
-                        if (cw < -0.97f) fw = W.speci[0][w][1]; // :801-803
-                        else S.corr_fails++;
-                        if (S.corr_fails > 4u) S.state = kDetect; // :808-809
+                        if (cw < -0.97f) fw = __builtin_amdgcn_readlane(my_f, w); // :801-803
+                        else L.corr_fails++;
+                        if (L.corr_fails > 4u) L.state = kDetect; // :808-809
                     }
-                    w2_end_step(S, job, C, recs, trace, kFindSfd, (int32_t)sps + fw, -1, fw, cw, t_start);
-                    if (S.state != kFindSfd || S.done || fw != 0) break;
+                    w2_end_step(L, job, C, recs, trace, kFindSfd, (int32_t)sps + fw, -1, fw, cw, t_start, t0);
+                    if (L.state != kFindSfd || L.done || fw != 0) break;
                 }
-                plan_from_state(next);
+                W2Plan np;
+                plan_from(L, np);
+                if (t0) { next = np; S = L; }
             }
             continue;
         }
@@ -646,11 +731,31 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         // ---- kPlanDecode: DECODE_HEADER / DECODE_PAYLOAD rounds (:826-886), pipelined.  Workers demodulate the
         // 7 symbols at plan.pos into spec[plan.buf]; concurrently the control thread resolves the previous round
         // (spec[plan.buf ^ 1]) and decides whether this round's position was predicted correctly.
+        // The symbol clock moves when a window's fine sync is non-zero (:506-512, consumed = sps + fine): the windows after
+        // it in that round started at the wrong sample, and so would this round, planned while that one was still being
+        // computed.  The workers' fine values are in LDS by now, so every wavefront re-aims this round itself: it restarts
+        // right after the first such window of the previous round, shifted by its fine value.  (Whether that is the true
+        // continuation is still decided by the control wavefront's resolve, below.)
+        int64_t dpos = pos;
+        int32_t dn = plan.n_win;
+        if (plan.resolve_prev && plan.prev_n > 0) {
+            const int rb = plan.buf ^ 1;
+            const int32_t s_l = lane < plan.prev_n ? W.speci[rb][lane][0] : -1, f_l = lane < plan.prev_n ? W.speci[rb][lane][1] : 0;
+            const unsigned long long moved = __ballot(s_l >= 0 && f_l != 0);
+            if (moved) {
+                const int wq = __builtin_ctzll(moved);
+                const int32_t redo = plan.prev_n - (wq + 1); // windows of the previous round to be demodulated again
+                dpos = pos - (int64_t)redo * sps + (int64_t)__builtin_amdgcn_readlane(f_l, wq);
+                dn = plan.n_win + redo < kW2Workers ? plan.n_win + redo : kW2Workers;
+            }
+        }
         if (!is_ctl) {
+            const int64_t dwpos = dpos + (int64_t)wave * sps;
+            const bool dvalid = wave < dn && dwpos + 2 * (int64_t)sps <= n_items;
             uint32_t ws = 0;
             int32_t wfine = 0;
-            if (wvalid) wave_demod_symbol<SF, SF == 7>(P, FT, X + wpos, ws, wfine);
-            if (lane == 0) { W.speci[plan.buf][wave][0] = wvalid ? (int32_t)ws : -1; W.speci[plan.buf][wave][1] = wfine; }
+            if (dvalid) wave_demod_symbol<SF, SF == 7>(P, FT, X + dwpos, ws, wfine);
+            if (lane == 0) { W.speci[plan.buf][wave][0] = dvalid ? (int32_t)ws : -1; W.speci[plan.buf][wave][1] = wfine; }
         } else { // the whole control wavefront, uniformly (identical values in every lane); t0 does the stores
             bool predicted = true;
             const long long tr0 = clock64();
@@ -678,7 +783,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                     if (L.done || fw != 0) break; // later windows started at the wrong sample
                 }
                 // is the round the workers are computing right now the true continuation?
-                predicted = !L.done && !L.fin_pending && (L.state == kDecodeHeader || L.state == kDecodePayload) && L.pos == plan.pos &&
+                predicted = !L.done && !L.fin_pending && (L.state == kDecodeHeader || L.state == kDecodePayload) && L.pos == dpos &&
                             w2_pre_step(L, job, rec_cap, sps);
             }
             const long long tr2 = clock64();
@@ -687,10 +792,11 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 // the round in flight continues the packet; how much of the packet is left after it?
                 int32_t n_next = kW2Workers;
                 if (L.state == kDecodePayload) {
-                    const int32_t rem = L.payload_symbols - (int32_t)L.n_words - plan.n_win;
+                    const int32_t rem = L.payload_symbols - (int32_t)L.n_words - dn;
                     n_next = rem < kW2Workers ? (rem > 0 ? rem : 0) : kW2Workers; // 0: nothing left to demodulate, only resolve
                 }
-                np.mode = kPlanDecode; np.pos = plan.pos + (int64_t)plan.n_win * sps; np.buf = plan.buf ^ 1; np.resolve_prev = 1; np.n_win = n_next;
+                np.mode = kPlanDecode; np.pos = dpos + (int64_t)dn * sps; np.buf = plan.buf ^ 1; np.resolve_prev = 1; np.n_win = n_next;
+                np.prev_n = dn; np.pad = 0;
             } else {
                 plan_from(L, np); // this round's results are discarded
             }
@@ -746,11 +852,15 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             if (Q.prev_state >= 0) { Q.cyc[Q.prev_state] += (uint32_t)((clock64() - Q.prev_t) >> 6); Q.rounds[Q.prev_state]++; }
             for (int i = 0; i < 6; i++) { jr.cyc[i] = Q.cyc[i]; jr.rounds[i] = Q.rounds[i]; }
             for (int i = 0; i < 4; i++) jr.ctl[i] = Q.ctl[i];
+            jr.dbg[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4); jr.dbg[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+            jr.dbg[2] = dbg_t0; jr.dbg[3] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+            jr.dbg[4] = dbg_c0; jr.dbg[5] = (uint32_t)(clock64() >> 6);
         }
     }
     if (phase == 1) break;
     __syncthreads();
     if (!W.ph_go) break;
+    bal_rem = 0xffffffffu;
     // the probe: a job from the end state of the job proper to the next header (what decode_streams would launch)
     { // wave-uniform values: keep them in SGPRs
         const int64_t st = W.ph_start;
@@ -764,6 +874,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     }
     __syncthreads(); // everyone has read the hand-over before the control thread re-initialises the state
     } // phase
+    if (t0 && bal_mine) __hip_atomic_store(bal_mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // nothing left: the neighbour keeps the CU
 }
 
 constexpr int kW2WavesSf7 = 8, kW2WavesSf8 = 8;
@@ -776,7 +887,6 @@ static uint32_t walker2_lds_bytes(uint32_t sf)
 {
     const uint32_t sps = 8u << sf;
     const uint32_t nv = (3u * sps + 40u + 3u) & ~3u;
-    const uint32_t tiles = sps / 4u, groups = walker2_threads(sf) / tiles; // SYNC: partial sums of the k-slices > 0
     return (uint32_t)((sizeof(W2Shared) + 15) & ~(size_t)15) + (2u * sps + nv + sps) * (uint32_t)sizeof(float) +
-           wave_tables_floats(sf) * (uint32_t)sizeof(float) + ((groups > 1u && (groups - 1u) * tiles * 16u > 2u * sps * 4u) ? (groups - 1u) * tiles * 16u : 0u);
+           wave_tables_floats(sf) * (uint32_t)sizeof(float) + (2u * 256u + 8u) * (uint32_t)sizeof(double);
 }

@@ -19,6 +19,8 @@ struct SimEnv {
     uint32_t sps_, ctor_cr_, seg_symbols, slots;
     std::vector<SimFrame> frames;
     uint32_t n_jobs = 0, n_probes = 0, n_slow = 0, n_tails = 0;
+    bool burst_plan = false;  // offer the scheduler the gaps between bursts (the device's envelope pre-pass)
+    uint32_t planned = 0;
     bool tail_probes = true; // emulate Job.probe_limit (walker2); false: the generic kernels' behaviour (explicit probe jobs only)
 
     uint32_t sps() const { return sps_; }
@@ -27,6 +29,32 @@ struct SimEnv {
     uint32_t resident_slots() const { return slots; }
     bool tracing() const { return false; }
     bool implicit() const { return false; }
+    bool quiet_edges(const std::vector<StreamDesc> &streams, std::vector<std::vector<int64_t>> &edges)
+    { // same rule as envelope_kernel / edges_kernel, from every sample of the block
+        if (!burst_plan) return false;
+        edges.assign(streams.size(), {});
+        for (size_t i = 0; i < streams.size(); i++) {
+            const float *x = iq + 2 * streams[i].off;
+            const size_t nb = streams[i].len / sps_;
+            std::vector<double> E(nb);
+            double sum = 0;
+            for (size_t b = 0; b < nb; b++) {
+                double e = 0;
+                for (size_t k = 2 * b * sps_; k < 2 * (b + 1) * sps_; k++) e += (double)x[k] * x[k];
+                E[b] = e; sum += e;
+            }
+            (void)sum;
+            auto quiet = [&](size_t b) { // under half the largest energy within 8 blocks
+                double m = 0;
+                for (size_t q = b >= 8 ? b - 8 : 0; q <= b + 8 && q < nb; q++) m = std::max(m, E[q]);
+                return E[b] < 0.5 * m;
+            };
+            for (size_t b = 1; b < nb; b++)
+                if (quiet(b) && !quiet(b - 1)) edges[i].push_back((int64_t)(b * sps_));
+        }
+        return true;
+    }
+    void note_plan(bool ok, size_t) { planned += ok ? 1u : 0u; }
     int run_jobs(const std::vector<Job> &jobs, uint32_t rpj, uint32_t, RunOut &out)
     {
         out.rpj = rpj; out.cap = rpj;
@@ -92,7 +120,8 @@ extern "C" int stitch_sim_decode(const float *iq, size_t n_items, int sf, int ct
     lora_oracle_t *o = lora_oracle_create(1e6f, 125000, (uint8_t)sf, 0, (uint8_t)ctor_cr, crc, reduced_rate, 0, demod);
     if (!o) return -1;
     SimEnv env{o, iq, n_items, lora_oracle_sps(o), (uint32_t)ctor_cr, segment_symbols, resident_slots};
-    env.tail_probes = tail_probes != 0;
+    env.tail_probes = (tail_probes & 1) != 0;
+    env.burst_plan = (tail_probes & 2) != 0;
     std::vector<StreamDesc> sds(1);
     sds[0].off = 0; sds[0].len = n_items; sds[0].id = 0; sds[0].cr_in = (uint32_t)ctor_cr; sds[0].abs_base = 0;
     const int rc = decode_streams(env, sds);
@@ -105,6 +134,6 @@ extern "C" int stitch_sim_decode(const float *iq, size_t n_items, int sf, int ct
         std::memcpy(out + used, f.blob.data(), f.blob.size());
         lens[n] = (int)f.blob.size(); hdr_pos[n] = f.hdr_pos; used += f.blob.size(); n++;
     }
-    stats[0] = env.n_jobs; stats[1] = env.n_probes; stats[2] = env.n_slow; stats[3] = sds[0].incomplete ? 1u : 0u; stats[4] = env.n_tails;
+    stats[0] = env.n_jobs; stats[1] = env.n_probes; stats[2] = env.n_slow; stats[3] = sds[0].incomplete ? 1u : 0u; stats[4] = env.n_tails; stats[5] = env.planned;
     return n;
 }

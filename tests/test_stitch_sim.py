@@ -28,20 +28,20 @@ def sim(oracle_mod):
     L.stitch_sim_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int,
                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
 
-    def run(iq, sf, ctor_cr=4, demod=2, reduced=False, seg=0, slots=512, tails=True):
+    def run(iq, sf, ctor_cr=4, demod=2, reduced=False, seg=0, slots=512, tails=True, plan=False):
         a = np.ascontiguousarray(iq, dtype=np.complex64)
         out = np.zeros(1 << 20, dtype=np.uint8)
         lens = np.zeros(4096, dtype=np.int32)
         hp = np.zeros(4096, dtype=np.int64)
         st = np.zeros(8, dtype=np.uint32)
-        n = L.stitch_sim_decode(a.ctypes.data, a.size, sf, ctor_cr, 1, int(reduced), demod, seg, slots, int(tails), out.ctypes.data, out.size,
+        n = L.stitch_sim_decode(a.ctypes.data, a.size, sf, ctor_cr, 1, int(reduced), demod, seg, slots, int(tails) | (2 if plan else 0), out.ctypes.data, out.size,
                                 lens.ctypes.data, hp.ctypes.data, 4096, st.ctypes.data)
         assert n >= 0, n
         frames, off = [], 0
         for i in range(n):
             frames.append(bytes(out[off:off + lens[i]]))
             off += int(lens[i])
-        return frames, hp[:n].tolist(), dict(jobs=int(st[0]), probes=int(st[1]), slow=int(st[2]), incomplete=int(st[3]), tails=int(st[4]))
+        return frames, hp[:n].tolist(), dict(jobs=int(st[0]), probes=int(st[1]), slow=int(st[2]), incomplete=int(st[3]), tails=int(st[4]), planned=int(st[5]))
     return run
 
 
@@ -68,6 +68,30 @@ def test_segmented_equals_serial(sim, oracle_mod, seg, tails):
         assert stats["tails"] > 0 and stats["probes"] <= stats["tails"]
     else:
         assert stats["probes"] > 0 and stats["tails"] == 0
+
+
+@pytest.mark.parametrize("slots,snr_db", [(8, None), (16, None), (30, None), (100, None), (16, 10.0), (16, -8.0)])
+def test_burst_aware_plan_equals_serial(sim, oracle_mod, slots, snr_db):
+    """Auto mode with the envelope pre-pass: cuts fall in the gaps between bursts (plan_burst_segments).  Same frames
+    as the serial decoder; on clean dense traffic every job starts at a gap, so nothing falls back and the job count
+    is the slot count or less.  Below the noise (wideband) the envelope shows no gaps and the fixed grid is used."""
+    cfg = synth.TxConfig(sf=7, cr=4)
+    rng = np.random.default_rng(4100 + slots)
+    payloads = [bytes(rng.integers(0, 256, int(rng.integers(4, 40)), dtype=np.uint8)) for _ in range(64)]
+    st = synth.build_stream(payloads, cfg, rng=rng, gap_symbols=(2.0, 6.0))
+    iq = st.iq
+    if snr_db is not None:
+        sigma = synth.awgn_sigma_for_snr(snr_db, cfg)
+        iq = (iq + sigma / np.sqrt(2.0) * (rng.standard_normal(iq.size) + 1j * rng.standard_normal(iq.size))).astype(np.complex64)
+    want, wpos = _serial(oracle_mod, iq, 7)
+    got, gpos, stats = sim(iq, 7, seg=0, slots=slots, plan=True)
+    assert got == want and gpos == wpos
+    if snr_db is None:
+        assert len(want) == len(payloads)
+        assert stats["planned"] == (1 if slots <= 30 else 0)  # fewer bursts than slots: fixed grid
+        print(slots, stats)
+        if stats["planned"]:
+            assert stats["jobs"] <= slots and stats["slow"] == 0 and stats["probes"] == 0
 
 
 def test_fast_path_dominates_on_regular_traffic(sim, oracle_mod):
