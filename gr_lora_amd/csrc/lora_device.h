@@ -137,7 +137,7 @@ struct EnvStream {
     uint32_t n_blocks;
 };
 int launch_envelope(const float2 *iq, const EnvStream *d_streams, uint32_t n_streams, uint32_t total_blocks, uint32_t sps, float *d_E,
-                    unsigned long long *d_edges, uint32_t edge_cap, uint32_t *d_ctl, void *stream);
+                    unsigned long long *d_bitmap /* (total_blocks + 63) / 64 words */, void *stream);
 
 int launch_walker(const DevParams &p, const LaunchCfg &c, void *stream);
 int launch_demod_symbols(const DevParams &p, const float2 *iq, const int64_t *d_offsets, uint32_t n,

@@ -115,6 +115,7 @@ struct lora_hip_decoder {
     DevBuf<float2> d_staging;
     DevBuf<int64_t> d_offsets;
     DevBuf<uint32_t> d_bins;
+    RunOut run_out[2];                 // results of the scheduler's two launches, reused between calls
     std::vector<JobResult> h_results;
     std::vector<AttemptRec> h_recs;
     std::vector<StepRec> h_trace;
@@ -128,7 +129,7 @@ struct lora_hip_decoder {
     DevBuf<uint32_t> d_balance;             // LaunchCfg::balance, zeroed when allocated
     DevBuf<EnvStream> d_env_streams;
     DevBuf<float> d_env_E;
-    DevBuf<unsigned long long> d_env_buf;   // [0] edge count, then the edge list
+    DevBuf<unsigned long long> d_env_buf;   // gap-start bitmap, one bit per block
     PinnedBuf<EnvStream> p_env_streams;
     PinnedBuf<unsigned long long> p_env_buf;
     float envelope_ms = 0.0f;
@@ -307,6 +308,7 @@ lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vec
                          uint32_t trace_cap, hipStream_t st, RunOut &out)
 {
     const uint32_t nj = (uint32_t)jobs.size();
+    const auto hp0 = std::chrono::steady_clock::now();
     out.rpj = recs_per_job; out.cap = recs_per_job;
     out.res.assign(nj, JobResult{});
     out.recs.clear();
@@ -340,7 +342,9 @@ lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vec
     HIP_TRY(h, hipMemcpyAsync(h->p_res.p, h->d_results.p, nj * sizeof(JobResult), hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipMemcpy2DAsync(h->p_recs.p, eager * sizeof(AttemptRec), h->d_recs.p, recs_per_job * sizeof(AttemptRec), eager * sizeof(AttemptRec), nj,
                                 hipMemcpyDeviceToHost, st));
+    const auto hp1 = std::chrono::steady_clock::now();
     HIP_TRY(h, hipStreamSynchronize(st));
+    const auto hp2 = std::chrono::steady_clock::now();
     std::memcpy(out.res.data(), h->p_res.p, nj * sizeof(JobResult));
     static const bool dbg_stats = getenv("LORA_HIP_DEBUG") != nullptr;
     if (dbg_stats && h->P.use_fast) {
@@ -386,7 +390,7 @@ lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vec
     // host copy of the records: only as many per job as the busiest job wrote (a 58-deep array per job would be 10 MB to clear)
     const uint32_t stride = std::max(max_att, 1u);
     out.rpj = stride;
-    out.recs.resize((size_t)nj * stride);
+    out.recs.resize_uninit((size_t)nj * stride); // every element is written below
     for (uint32_t j = 0; j < nj; j++) // the eagerly fetched records
         std::memcpy(&out.recs[(size_t)j * stride], h->p_recs.p + (size_t)j * eager, std::min(eager, max_att) * sizeof(AttemptRec));
     bool more = false;
@@ -403,6 +407,12 @@ lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vec
     if (more) HIP_TRY(h, hipStreamSynchronize(st));
     float ms = 0.0f;
     HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    if (dbg_stats) {
+        const auto hp3 = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        fprintf(stderr, "[lora_hip] run_jobs host: enqueue %.0f us, wait %.0f us (kernel %.0f us), unpack %.0f us; results %zu B + records %zu B\n", us(hp0, hp1), us(hp1, hp2),
+                ms * 1e3, us(hp2, hp3), nj * sizeof(JobResult), (size_t)nj * eager * sizeof(AttemptRec));
+    }
     h->timing.walker_ms += ms;
     h->timing.walker_launches++;
     return LORA_HIP_OK;
@@ -425,6 +435,7 @@ lora_hip_status quiet_edges(lora_hip_decoder *h, const float2 *d_iq, const std::
                             std::vector<std::vector<int64_t>> &edges)
 {
     const uint32_t sps = h->P.sps, ns = (uint32_t)streams.size();
+    const auto hq0 = std::chrono::steady_clock::now();
     HIP_TRY(h, h->p_env_streams.reserve(ns));
     uint64_t nb = 0;
     for (uint32_t i = 0; i < ns; i++) {
@@ -433,36 +444,43 @@ lora_hip_status quiet_edges(lora_hip_decoder *h, const float2 *d_iq, const std::
         h->p_env_streams.p[i] = EnvStream{streams[i].off, (uint32_t)nb, (uint32_t)n};
         nb += n;
     }
-    const uint32_t head = 1u;                                        // the edge count, in 8-byte units
-    const uint32_t cap = (uint32_t)std::min<uint64_t>(nb / 8u + 64u, 1u << 20);
-    constexpr uint32_t kEager = 4096;                                // edges fetched together with the count
+    const size_t words = (size_t)((nb + 63u) / 64u);                 // one bit per block
     HIP_TRY(h, h->d_env_streams.reserve(ns));
     HIP_TRY(h, h->d_env_E.reserve(nb));
-    HIP_TRY(h, h->d_env_buf.reserve((size_t)head + cap));
-    HIP_TRY(h, h->p_env_buf.reserve((size_t)head + cap));
+    HIP_TRY(h, h->d_env_buf.reserve(words));
+    HIP_TRY(h, h->p_env_buf.reserve(words));
     HIP_TRY(h, hipMemcpyAsync(h->d_env_streams.p, h->p_env_streams.p, ns * sizeof(EnvStream), hipMemcpyHostToDevice, st));
-    unsigned long long *buf = h->d_env_buf.p;
     static const bool dbg = getenv("LORA_HIP_DEBUG") != nullptr;
     if (dbg) HIP_TRY(h, hipEventRecord(h->ev0, st));
-    if (launch_envelope(d_iq, h->d_env_streams.p, ns, (uint32_t)nb, sps, h->d_env_E.p, buf + head, cap, (uint32_t *)buf, st) != 0)
+    if (launch_envelope(d_iq, h->d_env_streams.p, ns, (uint32_t)nb, sps, h->d_env_E.p, h->d_env_buf.p, st) != 0)
         return fail(h, LORA_HIP_ERR_HIP, "envelope launch failed: %s", hipGetErrorString(hipGetLastError()));
     if (dbg) HIP_TRY(h, hipEventRecord(h->ev1, st));
-    const uint32_t eager = std::min(cap, kEager);
-    HIP_TRY(h, hipMemcpyAsync(h->p_env_buf.p, buf, ((size_t)head + eager) * 8u, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(h->p_env_buf.p, h->d_env_buf.p, words * 8u, hipMemcpyDeviceToHost, st));
+    const auto hq1 = std::chrono::steady_clock::now();
     HIP_TRY(h, hipStreamSynchronize(st));
+    const auto hq2 = std::chrono::steady_clock::now();
     if (dbg) { float ms = 0; if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->envelope_ms = ms; }
-    const uint32_t n_found = *(const uint32_t *)h->p_env_buf.p;
-    if (n_found > cap) return LORA_HIP_ERR_ARG;                  // more gaps than the list holds: not burst traffic
-    if (n_found > eager) {
-        HIP_TRY(h, hipMemcpyAsync(h->p_env_buf.p + head + eager, buf + head + eager, (size_t)(n_found - eager) * 8u, hipMemcpyDeviceToHost, st));
-        HIP_TRY(h, hipStreamSynchronize(st));
+    // the set bits, stream by stream, in block order
+    edges.resize(ns);
+    uint32_t n_found = 0;
+    const unsigned long long *bm = h->p_env_buf.p;
+    for (uint32_t i = 0; i < ns; i++) {
+        std::vector<int64_t> &e = edges[i];
+        e.clear();
+        const uint64_t b0 = h->p_env_streams.p[i].first_block, b1 = b0 + h->p_env_streams.p[i].n_blocks;
+        for (uint64_t w = b0 / 64u; w * 64u < b1; w++) {
+            unsigned long long bits = bm[w];
+            while (bits) {
+                const uint64_t b = w * 64u + (uint64_t)__builtin_ctzll(bits);
+                bits &= bits - 1ull;
+                if (b >= b0 && b < b1) e.push_back((int64_t)(b - b0) * (int64_t)sps);
+            }
+        }
+        n_found += (uint32_t)e.size();
     }
-    unsigned long long *e = h->p_env_buf.p + head;
-    std::sort(e, e + n_found);                                       // by stream, then position (the device appends in any order)
-    edges.assign(ns, {});
-    for (uint32_t k = 0; k < n_found; k++) {
-        const uint32_t si = (uint32_t)(e[k] >> 40);
-        if (si < ns) edges[si].push_back((int64_t)(e[k] & ((1ull << 40) - 1ull)) * (int64_t)sps);
+    if (dbg) {
+        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        fprintf(stderr, "[lora_hip] envelope host: enqueue %.0f us, wait %.0f us, sort %.0f us (%u edges)\n", us(hq0, hq1), us(hq1, hq2), us(hq2, std::chrono::steady_clock::now()), n_found);
     }
     return LORA_HIP_OK;
 }
@@ -482,6 +500,7 @@ struct DeviceEnv {
     }
     bool tracing() const { return (h->cfg.flags & LORA_HIP_FLAG_TRACE) != 0; }
     bool implicit() const { return h->P.implicit != 0; }
+    RunOut &run_out(int which) { return h->run_out[which & 1]; }
     bool quiet_edges(const std::vector<StreamDesc> &streams, std::vector<std::vector<int64_t>> &edges)
     {
         return ::quiet_edges(h, d_iq, streams, st, edges) == LORA_HIP_OK;

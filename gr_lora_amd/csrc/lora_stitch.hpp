@@ -6,6 +6,7 @@
 //
 // Env must provide:  uint32_t sps(), ctor_cr(), segment_symbols(), resident_slots();  bool tracing(), implicit();
 //   int  run_jobs(const std::vector<Job> &, uint32_t recs_per_job, uint32_t trace_cap, RunOut &);   (0 = ok)
+//   RunOut &run_out(int which);   (two reusable result holders)
 //   bool quiet_edges(const std::vector<StreamDesc> &, std::vector<std::vector<int64_t>> &);   (gap starts per stream, false = none)
 //   void publish(const AttemptRec &, StreamDesc &);   void append_trace(const RunOut &, uint32_t job, uint32_t cap, int64_t base);
 //   void count_jobs(uint32_t), count_probes(uint32_t), count_slow_path(), note_plan(bool burst_aware, size_t n_segments);   double walker_ms();
@@ -15,6 +16,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <vector>
 
 #include "lora_device.h"
@@ -55,9 +57,32 @@ struct StreamDesc {
     bool incomplete = false;
 };
 
+// Attempt records of one launch: storage that is neither cleared nor reallocated between launches (a 58-deep
+// std::vector<AttemptRec> per job would be megabytes to zero-fill and to page in on every call).
+struct RecStore {
+    std::unique_ptr<AttemptRec[]> p;
+    size_t n = 0, cap = 0;
+    AttemptRec *data() { return p.get(); }
+    const AttemptRec *data() const { return p.get(); }
+    AttemptRec &operator[](size_t i) { return p[i]; }
+    const AttemptRec &operator[](size_t i) const { return p[i]; }
+    size_t size() const { return n; }
+    void clear() { n = 0; }
+    void resize_uninit(size_t k) // contents undefined: the caller writes every element it later reads
+    {
+        if (k > cap) { p.reset(new AttemptRec[k + k / 4]); cap = k + k / 4; }
+        n = k;
+    }
+    void assign(size_t k, const AttemptRec &v)
+    {
+        resize_uninit(k);
+        for (size_t i = 0; i < k; i++) p[i] = v;
+    }
+};
+
 struct RunOut {
     std::vector<JobResult> res;
-    std::vector<AttemptRec> recs;
+    RecStore recs;
     uint32_t rpj = 0; // records stored per job (stride of `recs`): every record the jobs wrote, at most `cap`
     uint32_t cap = 0; // record capacity the jobs ran with
     const AttemptRec &rec(size_t job, uint32_t a) const { return recs[job * rpj + a]; }
@@ -203,6 +228,7 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
 {
     const uint32_t sps = env.sps();
     const bool tracing = env.tracing();
+    const auto tp_in = std::chrono::steady_clock::now();
     uint64_t total = 0;
     for (const StreamDesc &sd : streams) total += sd.len;
     // auto: as many segments as workgroups fit on the device at once (one wave of workgroups per launch;
@@ -263,7 +289,7 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
     const uint32_t rpj2 = 8;
     const uint32_t rpj1 = recs_for(max_span, sps) + (segmenting ? rpj2 : 0u);
     const uint32_t trace_cap = tracing ? (uint32_t)std::min<uint64_t>(2ull * (max_span / sps) + 64ull, 1ull << 22) : 0u;
-    RunOut R1;
+    RunOut &R1 = env.run_out(0); // (kept by the environment between calls)
     env.count_jobs((uint32_t)jobs.size());
     static const bool dbg_t = getenv("LORA_HIP_DEBUG") != nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
@@ -332,7 +358,8 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
         if (chain && pending) add_probe(e - 1, (int64_t)sd.len); // header-less tail still has to be walked
     }
     first_probe[streams.size()] = probes.size();
-    RunOut R2;
+    RunOut &R2 = env.run_out(1);
+    R2.res.clear(); R2.recs.clear();
     if (!pjobs.empty()) {
         env.count_probes((uint32_t)pjobs.size());
         s = env.run_jobs(pjobs, rpj2, 0, R2);
@@ -496,8 +523,8 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
     if (dbg_t) {
         const auto tp3 = std::chrono::steady_clock::now();
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        fprintf(stderr, "[lora_hip] round1 %.3f ms (%zu jobs, rpj %u), round2 %.3f ms (%zu probe jobs, %zu tail probes), stitch %.3f ms, walker %.3f ms\n",
-                ms(tp0, tp1), jobs.size(), rpj1, ms(tp1, tp2), pjobs.size(), probes.size() - pjobs.size(), ms(tp2, tp3), env.walker_ms());
+        fprintf(stderr, "[lora_hip] plan %.3f ms, round1 %.3f ms (%zu jobs, rpj %u), round2 %.3f ms (%zu probe jobs, %zu tail probes), stitch %.3f ms, walker %.3f ms\n",
+                ms(tp_in, tp0), ms(tp0, tp1), jobs.size(), rpj1, ms(tp1, tp2), pjobs.size(), probes.size() - pjobs.size(), ms(tp2, tp3), env.walker_ms());
     }
     return 0;
 }

@@ -19,6 +19,8 @@ struct SimEnv {
     uint32_t sps_, ctor_cr_, seg_symbols, slots;
     std::vector<SimFrame> frames;
     uint32_t n_jobs = 0, n_probes = 0, n_slow = 0, n_tails = 0;
+    RunOut outs[2];
+    RunOut &run_out(int which) { return outs[which & 1]; }
     bool burst_plan = false;  // offer the scheduler the gaps between bursts (the device's envelope pre-pass)
     uint32_t planned = 0;
     bool tail_probes = true; // emulate Job.probe_limit (walker2); false: the generic kernels' behaviour (explicit probe jobs only)
