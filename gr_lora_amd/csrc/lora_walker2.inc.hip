@@ -219,21 +219,38 @@ __device__ __forceinline__ bool w2_post_symbol(const DevParams &P, W2State &S, S
 
 // ---- wave-level window evaluations ---------------------------------------------------------------------
 // DETECT (:340-366): sums of c1*conj(c2), |c1|^2, |c2|^2 over one symbol pair
+#ifndef LORA_W2_GLOBAL
+#define LORA_W2_GLOBAL __attribute__((address_space(1)))
+#endif
+#ifndef LORA_W2_WINDOW_ATTR
+#define LORA_W2_WINDOW_ATTR __forceinline__ // (as out-of-line functions they fault on the device: left inline)
+#endif
 template <int SF>
-__device__ __forceinline__ void w2_detect_window(const float2 *__restrict__ p, float (&out)[4])
+__device__ LORA_W2_WINDOW_ATTR float4 w2_detect_window(const float2 *p_)
 {
+    const auto p = (const LORA_W2_GLOBAL v2f *)p_; // global, not flat, loads
     constexpr int SPS = 8 << SF, J = SPS / 64;
     const int lane = threadIdx.x & 63;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    constexpr int B = J < 16 ? J : 16; // loads are issued B + B at a time (left to itself the compiler waits for every pair)
 #pragma unroll
-    for (int j = 0; j < J; j++) {
-        const float2 c1 = p[j * 64 + lane], c2 = p[SPS + j * 64 + lane];
-        a0 += c1.x * c2.x + c1.y * c2.y;
-        a1 += c1.y * c2.x - c1.x * c2.y;
-        a2 += c1.x * c1.x + c1.y * c1.y;
-        a3 += c2.x * c2.x + c2.y * c2.y;
+    for (int jb = 0; jb < J; jb += B) {
+        v2f u[B], w[B];
+#pragma unroll
+        for (int j = 0; j < B; j++) u[j] = p[(jb + j) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < B; j++) w[j] = p[SPS + (jb + j) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0); // keeps the scheduler from sinking the loads into the sums below, one wait each
+#pragma unroll
+        for (int j = 0; j < B; j++) {
+            const v2f c1 = u[j], c2 = w[j];
+            a0 += c1.x * c2.x + c1.y * c2.y;
+            a1 += c1.y * c2.x - c1.x * c2.y;
+            a2 += c1.x * c1.x + c1.y * c1.y;
+            a3 += c2.x * c2.x + c2.y * c2.y;
+        }
     }
-    out[0] = wave_sum_rows(a0); out[1] = wave_sum_rows(a1); out[2] = wave_sum_rows(a2); out[3] = wave_sum_rows(a3);
+    return make_float4(wave_sum_rows(a0), wave_sum_rows(a1), wave_sum_rows(a2), wave_sum_rows(a3));
 }
 
 // K consecutive DETECT windows (pos, pos + sps, ...) by one wavefront: the K + 1 symbols are read once,
@@ -269,20 +286,31 @@ __device__ __forceinline__ void w2_detect_windows(const float2 *__restrict__ p, 
 
 // FIND_SFD (:385-390, :283-298, :801-803): Pearson correlation of the window's ifreq with the ideal
 // downchirp ifreq, and -- for an upchirp (c < -0.97) -- fine_sync(-1, 4*D) over the 63 lags.
+struct W2SfdOut { float c; int32_t fine; };
 template <int SF>
-__device__ __forceinline__ void w2_sfd_window(const DevParams &P, const W2Tabs &T, const float2 *__restrict__ p, float &c_out, int32_t &fine_out)
+__device__ LORA_W2_WINDOW_ATTR W2SfdOut w2_sfd_window(const float2 *p, const float *Tv, const float *Tdd, float *scr /* this wavefront's 72 floats */,
+                                                          float down_ifreq_sd, float down_ifreq_dsum, double sync_a, double sync_b)
 {
     constexpr int SPS = 8 << SF, J = SPS / 64;
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));
     float f[J];
-    const v2f *__restrict__ pv = reinterpret_cast<const v2f *>(p);
+    {
+        const auto pv = (const LORA_W2_GLOBAL v2f *)p; // global, not flat, loads
+        v2f a[J]; // the whole window in one round of loads (lane owns n = 64 j + lane)
 #pragma unroll
-    for (int j = 0; j < J; j += 2) { // two samples per packed evaluation (same arithmetic as the demodulator's)
-        const int n0 = j * 64 + lane, n1 = n0 + 64;
-        const v2f fp = ifreq_prod_pk(pv[n0 >= 1 ? n0 - 1 : 0], pv[n0], pv[n1 - 1], pv[n1]); // ifreq[n-1]; the n-1 loads hit the lines just fetched
-        f[j] = (n0 >= 1) ? fp.x : 0.0f;
-        f[j + 1] = fp.y;
+        for (int j = 0; j < J; j++) a[j] = pv[j * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0); // (all loads issued before the first use)
+        v2f bprev = (v2f){0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < J; j += 2) { // ifreq[n-1] = arg(x[n] conj(x[n-1])), two per packed evaluation; x[n-1] by wave rotate
+            const v2f b0 = dpp2<kDppWaveRor1>(a[j]), b1 = dpp2<kDppWaveRor1>(a[j + 1]);
+            const v2f p0 = (lane == 0) ? bprev : b0, p1 = (lane == 0) ? b0 : b1;
+            bprev = b1;
+            const v2f fp = ifreq_prod_pk(p0, a[j], p1, a[j + 1]);
+            f[j] = (j == 0 && lane == 0) ? 0.0f : fp.x;
+            f[j + 1] = fp.y;
+        }
     }
     // one-pass Pearson over the n = sps-1 points k = 0 .. sps-2
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
@@ -290,18 +318,16 @@ __device__ __forceinline__ void w2_sfd_window(const DevParams &P, const W2Tabs &
     for (int j = 0; j < J; j++) {
         const int k = j * 64 + lane - 1;
         const float fk = f[j];
-        const float d = T.dd[k < 0 ? 0 : k];
+        const float d = Tdd[k < 0 ? 0 : k];
         a0 += fk; a1 += fk * fk; a2 += fk * d; // f[j] is 0 for the non-existent k = -1
     }
     a0 = wave_sum_rows(a0); a1 = wave_sum_rows(a1); a2 = wave_sum_rows(a2);
     const float n = (float)(SPS - 1);
     const float average = a0 / n;
     const float var = fmaxf(a1 / n - average * average, 0.0f);
-    const float sd = sqrtf(var) * P.down_ifreq_sd;
-    const float c = (a2 - average * P.down_ifreq_dsum) / sd / n;
-    c_out = c;
-    fine_out = 0;
-    if (!(c < -0.97f) || c > 0.96f) return;
+    const float sd = sqrtf(var) * down_ifreq_sd;
+    const float c = (a2 - average * down_ifreq_dsum) / sd / n;
+    if (!(c < -0.97f) || c > 0.96f) return W2SfdOut{c, 0};
     // fine_sync(-1, 32) (:300-321): c_i = sum_{k<sps} fe[k] * v[sps + i + k], i = -31 .. 31, with fe[sps-1] = fe[sps-2].
     // v is the ifreq of concatenated upchirps: v[m] = a + b*(m mod sps) except the one wrap sample per period
     // (m mod sps == sps-1), up to float noise ~1e-5 of the sums.  With t = (i+k) mod sps that gives, exactly in
@@ -323,7 +349,6 @@ __device__ __forceinline__ void w2_sfd_window(const DevParams &P, const W2Tabs &
         for (int o = 32; o > 0; o >>= 1) { g0 += __shfl_xor(g0, o, 64); g1 += __shfl_xor(g1, o, 64); }
     }
     // the first 32 and last 33 samples go to this wavefront's scratch: head[k] = fe[k], tail[q] = fe[sps-1-q]
-    float *scr = T.scratch + (threadIdx.x >> 6) * 72;
     if (lane >= 1 && lane <= 32) scr[lane - 1] = f[0];                 // fe[0..31]
     if (lane >= 31) scr[32 + 1 + (63 - lane)] = f[J - 1];              // fe[sps-2-(63-lane)] -> tail[1 + (63-lane)]
     if (lane == 63) scr[32] = f[J - 1];                                // tail[0] = fe[sps-1] = fe[sps-2]
@@ -341,8 +366,8 @@ __device__ __forceinline__ void w2_sfd_window(const DevParams &P, const W2Tabs &
     const float hsum = __shfl(ps, lane < 31 ? 30 - lane : 0, 64); // H_{-i} for the negative lags
     float c_i = -3.0e38f;
     if (lane <= 62) {
-        const double a = P.sync_a, b = P.sync_b;
-        const double wd = (double)T.v[2 * SPS - 1] - (a + b * (double)(SPS - 1));
+        const double a = sync_a, b = sync_b;
+        const double wd = (double)Tv[2 * SPS - 1] - (a + b * (double)(SPS - 1));
         double edge;
         float wrap_f;
         if (i >= 0) {
@@ -362,7 +387,7 @@ __device__ __forceinline__ void w2_sfd_window(const DevParams &P, const W2Tabs &
         if (ov > c_i || (ov == c_i && oi < li)) { c_i = ov; li = oi; }
     }
     const int32_t lag = (c_i > 0.0f) ? li - 31 : 0;
-    fine_out = -lag;
+    return W2SfdOut{c, -lag};
 }
 
 // SYNC (:770-783, detect_upchirp :392-413): this thread's best shift of the sliding correlation of f[0 .. 2 sps) with the
@@ -561,7 +586,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 }
                 float a[kW2DetectK][4];
                 if (nvalid > 0) {
-                    if (kd == 1) w2_detect_window<SF>(X + dpos, a[0]);
+                    if (kd == 1) { const float4 r = w2_detect_window<SF>(X + dpos); a[0][0] = r.x; a[0][1] = r.y; a[0][2] = r.z; a[0][3] = r.w; }
                     else w2_detect_windows<SF, kW2DetectK>(X + dpos, nvalid, a);
                 }
                 if (lane == 0) {
@@ -571,6 +596,10 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 }
             }
             __syncthreads();
+#ifdef LORA_W2_STAMP_ACQ
+            const long long ts_b = clock64();
+            if (t0) W.stats.ctl[0] += (uint32_t)((ts_b - t_start) >> 6);
+#endif
             if (is_ctl) {
                 // the control wavefront evaluates all windows at once (lane q = window q); what the serial replay
                 // of :740-768 would do with them -- stop at the first trigger, at the scan limit or at the end of
@@ -638,6 +667,10 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                     W2Plan np;
                     plan_from(L, np);
                     next = np; S = L;
+#ifdef LORA_W2_STAMP_ACQ
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    W.stats.ctl[1] += (uint32_t)((clock64() - ts_b) >> 6);
+#endif
                 }
             }
             continue;
@@ -668,9 +701,16 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         if (plan.mode == kPlanSfd) {
             float c = 0.0f;
             int32_t fine = 0;
-            if (wvalid) w2_sfd_window<SF>(P, T, X + wpos, c, fine);
+            if (wvalid) {
+                const W2SfdOut r = w2_sfd_window<SF>(X + wpos, T.v, T.dd, T.scratch + wave * 72, P.down_ifreq_sd, P.down_ifreq_dsum, P.sync_a, P.sync_b);
+                c = r.c; fine = r.fine;
+            }
             if (lane == 0 && !is_ctl) { W.specf[wave][0] = c; W.speci[0][wave][0] = wvalid ? 1 : 0; W.speci[0][wave][1] = fine; }
             __syncthreads();
+#ifdef LORA_W2_STAMP_ACQ
+            const long long ts_b = clock64();
+            if (t0) W.stats.ctl[2] += (uint32_t)((ts_b - t_start) >> 6);
+#endif
             if (is_ctl) { // the whole control wavefront, uniformly, on a register copy of the state (as the decode rounds do)
                 W2State L = S;
                 const float my_c = lane < kW2Workers ? W.specf[lane][0] : 0.0f;
@@ -694,6 +734,10 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 W2Plan np;
                 plan_from(L, np);
                 if (t0) { next = np; S = L; }
+#ifdef LORA_W2_STAMP_ACQ
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (t0) W.stats.ctl[3] += (uint32_t)((clock64() - ts_b) >> 6);
+#endif
             }
             continue;
         }
@@ -806,8 +850,10 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 S = L;
                 W.words_pk[0] = wpk[0]; W.words_pk[1] = wpk[1];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef LORA_W2_STAMP_ACQ
                 W.stats.ctl[0] += (uint32_t)((tr1 - tr0) >> 6); W.stats.ctl[1] += (uint32_t)((tr2 - tr1) >> 6); W.stats.ctl[2] += (uint32_t)((tr3 - tr2) >> 6);
                 W.stats.ctl[3] += (uint32_t)((clock64() - tr3) >> 6);
+#endif
                 W.stats.cyc[4] += (uint32_t)((clock64() - tr0) >> 6); W.stats.rounds[4]++; // control wavefront's share of a decode round
             }
         }

@@ -34,7 +34,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int kDppQuadXor1 = 0xB1, kDppQuadXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140, kDppRor8 = 0x128,
-              kDppBcast15 = 0x142, kDppBcast31 = 0x143;
+              kDppBcast15 = 0x142, kDppBcast31 = 0x143,
+              kDppWaveRor1 = 0x13C; // lane i reads lane i - 1, lane 0 reads lane 63 (GFX9 wavefront rotate)
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v)
@@ -228,11 +229,16 @@ __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const Wave
     for (int j = 0; j < J; j++) a[j] = xv[j * 64 + nl];
 #endif
     if (EARLY_F && want_fine) {
+        // sample n - 1 of this lane's n = 64 j + lane sits in the neighbouring lane (lane 0: lane 63 of the previous
+        // register): one wave rotate per register instead of a second, dependent round of loads
+        v2f bprev = (v2f){0.0f, 0.0f};
 #pragma unroll
         for (int j = 0; j < J; j += 2) {
-            const int n0 = j * 64 + nl, n1 = n0 + 64;
-            const v2f fp = ifreq_prod_pk(xv[n0 >= 1 ? n0 - 1 : 0], a[j], xv[n1 - 1], a[j + 1]);
-            f[j] = (n0 >= 1) ? fp.x : 0.0f;
+            const v2f b0 = dpp2<kDppWaveRor1>(a[j]), b1 = dpp2<kDppWaveRor1>(a[j + 1]);
+            const v2f p0 = (lane == 0) ? bprev : b0, p1 = (lane == 0) ? b0 : b1;
+            bprev = b1;
+            const v2f fp = ifreq_prod_pk(p0, a[j], p1, a[j + 1]);
+            f[j] = (j == 0 && lane == 0) ? 0.0f : fp.x; // n = 0 has no predecessor in the window
             f[j + 1] = fp.y;
         }
     }
