@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -143,6 +144,7 @@ struct lora_hip_decoder {
     PwrState stream_pwr;
     size_t batch_items = 0, batch_need = 0;
     uint32_t resident_slots = 0;
+    uint32_t eager_recs = 4;
 };
 
 namespace {
@@ -310,7 +312,7 @@ lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vec
     const uint32_t nj = (uint32_t)jobs.size();
     const auto hp0 = std::chrono::steady_clock::now();
     out.rpj = recs_per_job; out.cap = recs_per_job;
-    out.res.assign(nj, JobResult{});
+    out.res.resize(nj); // (overwritten from the landing buffer below)
     out.recs.clear();
     if (nj == 0) return LORA_HIP_OK;
     HIP_TRY(h, h->d_jobs.reserve(nj));
@@ -319,8 +321,8 @@ lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vec
     const bool need_scratch = !h->P.ifreq_in_lds_2;
     if (need_scratch) HIP_TRY(h, h->d_scratch.reserve((size_t)nj * 2u * h->P.sps));
     if (trace_cap) HIP_TRY(h, h->d_trace.reserve((size_t)nj * trace_cap));
-    constexpr uint32_t kEagerRecs = 4; // attempt records per job fetched together with the results (most jobs have <= 4)
-    const uint32_t eager = std::min(kEagerRecs, recs_per_job);
+    // attempt records per job fetched together with the results: what the busiest job of the previous launch needed
+    const uint32_t eager = std::min(std::max(h->eager_recs, 2u), recs_per_job);
     HIP_TRY(h, h->p_jobs.reserve(nj));
     HIP_TRY(h, h->p_res.reserve(nj));
     HIP_TRY(h, h->p_recs.reserve((size_t)nj * eager));
@@ -391,8 +393,17 @@ lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vec
     const uint32_t stride = std::max(max_att, 1u);
     out.rpj = stride;
     out.recs.resize_uninit((size_t)nj * stride); // every element is written below
-    for (uint32_t j = 0; j < nj; j++) // the eagerly fetched records
-        std::memcpy(&out.recs[(size_t)j * stride], h->p_recs.p + (size_t)j * eager, std::min(eager, max_att) * sizeof(AttemptRec));
+    // the eagerly fetched records: only the ones a job wrote, and of each only the header and the frame bytes it holds
+    // (the landing buffer has just been written by DMA: every byte read from it comes from DRAM)
+    for (uint32_t j = 0; j < nj; j++) {
+        const uint32_t used = std::min(std::min(eager, max_att), out.res[j].n_attempts + (out.res[j].tail_valid ? out.res[j].tail_n_attempts : 0u));
+        for (uint32_t a = 0; a < used; a++) {
+            const AttemptRec *src = h->p_recs.p + (size_t)j * eager + a;
+            const size_t n = offsetof(AttemptRec, frame) + std::min<size_t>(src->frame_len, sizeof src->frame);
+            std::memcpy(&out.recs[(size_t)j * stride + a], src, n);
+        }
+    }
+    h->eager_recs = std::min(std::max(max_att, 2u), 8u);
     bool more = false;
     if (max_att > eager) { // rare: some job made more attempts than were fetched with the results
         HIP_TRY(h, hipMemcpy2DAsync(out.recs.data() + eager, stride * sizeof(AttemptRec), h->d_recs.p + eager,

@@ -240,7 +240,8 @@ __device__ LORA_W2_WINDOW_ATTR float4 w2_detect_window(const float2 *p_)
         for (int j = 0; j < B; j++) u[j] = p[(jb + j) * 64 + lane];
 #pragma unroll
         for (int j = 0; j < B; j++) w[j] = p[SPS + (jb + j) * 64 + lane];
-        __builtin_amdgcn_sched_barrier(0); // keeps the scheduler from sinking the loads into the sums below, one wait each
+        __builtin_amdgcn_sched_group_barrier(0x020, 2 * B, 0); // all VMEM reads of the batch first (left alone the scheduler sinks them into the sums, one wait each)
+        __builtin_amdgcn_sched_group_barrier(0x002, 16 * B, 0);
 #pragma unroll
         for (int j = 0; j < B; j++) {
             const v2f c1 = u[j], c2 = w[j];
@@ -550,14 +551,21 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
 
     for (uint32_t it = 0;; it++) {
         __syncthreads(); // plan[it & 1] and everything the control thread wrote are visible; plan[(it+1) & 1] is free
-        const W2Plan plan = W.plan[it & 1u];
+        // the plan is the same in every lane: its fields go to scalar registers one by one (a struct copy would be
+        // parked in scratch and reloaded piecemeal, each reload a full s_waitcnt)
+        const W2Plan &pl_in = W.plan[it & 1u];
+        const uint64_t pl_pp = (uint64_t)pl_in.pos;
+        const int64_t plan_pos = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(pl_pp >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)pl_pp));
+        const int32_t plan_mode = __builtin_amdgcn_readfirstlane(pl_in.mode), plan_buf = __builtin_amdgcn_readfirstlane(pl_in.buf);
+        const int32_t plan_resolve_prev = __builtin_amdgcn_readfirstlane(pl_in.resolve_prev), plan_n_win = __builtin_amdgcn_readfirstlane(pl_in.n_win);
+        const int32_t plan_prev_n = __builtin_amdgcn_readfirstlane(pl_in.prev_n);
         W2Plan &next = W.plan[(it + 1u) & 1u];
-        if (plan.mode == kPlanExit) break;
-        const int64_t pos = plan.pos;
+        if (plan_mode == kPlanExit) break;
+        const int64_t pos = plan_pos;
         const long long t_start = clock64();
         if (t0) {
             W2Stats &Q = W.stats;
-            const int sidx = plan.mode == kPlanDetect ? 0 : plan.mode == kPlanSync ? 1 : plan.mode == kPlanSfd ? 2 : plan.mode == kPlanPause ? 3 : 5;
+            const int sidx = plan_mode == kPlanDetect ? 0 : plan_mode == kPlanSync ? 1 : plan_mode == kPlanSfd ? 2 : plan_mode == kPlanPause ? 3 : 5;
             if (Q.prev_state >= 0) { Q.cyc[Q.prev_state] += (uint32_t)((t_start - Q.prev_t) >> 6); Q.rounds[Q.prev_state]++; }
             Q.prev_state = sidx; Q.prev_t = t_start;
         }
@@ -573,10 +581,10 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             if (W.prio) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
         }
         const int64_t wpos = pos + (int64_t)wave * sps;
-        const bool wvalid = !is_ctl && wave < plan.n_win && wpos + 2 * (int64_t)sps <= n_items;
+        const bool wvalid = !is_ctl && wave < plan_n_win && wpos + 2 * (int64_t)sps <= n_items;
 
-        if (plan.mode == kPlanDetect) { // every worker evaluates kd (1 or kW2DetectK) consecutive windows
-            const int kd = plan.n_win;
+        if (plan_mode == kPlanDetect) { // every worker evaluates kd (1 or kW2DetectK) consecutive windows
+            const int kd = plan_n_win;
             if (!is_ctl) {
                 const int64_t dpos = pos + (int64_t)wave * kd * sps;
                 int nvalid = 0; // windows of this worker that lie inside the data (:91)
@@ -676,9 +684,24 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             continue;
         }
 
-        if (plan.mode == kPlanSync) { // :770-783, detect_upchirp :392-413 -- all wavefronts together
+        if (plan_mode == kPlanSync) { // :770-783, detect_upchirp :392-413 -- all wavefronts together
             const float2 *__restrict__ x = X + pos;
-            for (uint32_t i = 1u + threadIdx.x; i < 2u * sps; i += kW2) f2[i - 1] = ifreq_prod(x[i - 1], x[i]);
+            {
+                constexpr int NI = (2 * SPS + kW2 - 1) / kW2; // samples per thread: all loads first, then the arithmetic
+                float2 xb[NI], xa[NI];
+#pragma unroll
+                for (int k = 0; k < NI; k++) {
+                    const uint32_t i = 1u + threadIdx.x + (uint32_t)k * kW2;
+                    if (i < 2u * sps) { xb[k] = x[i - 1]; xa[k] = x[i]; }
+                }
+                __builtin_amdgcn_sched_group_barrier(0x020, 2 * NI, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 64 * NI, 0);
+#pragma unroll
+                for (int k = 0; k < NI; k++) {
+                    const uint32_t i = 1u + threadIdx.x + (uint32_t)k * kW2;
+                    if (i < 2u * sps) f2[i - 1] = ifreq_prod(xb[k], xa[k]);
+                }
+            }
             __syncthreads();
             if (t0) f2[2u * sps - 1u] = f2[2u * sps - 2u]; // :243
             __syncthreads();
@@ -698,7 +721,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             continue;
         }
 
-        if (plan.mode == kPlanSfd) {
+        if (plan_mode == kPlanSfd) {
             float c = 0.0f;
             int32_t fine = 0;
             if (wvalid) {
@@ -742,7 +765,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             continue;
         }
 
-        if (plan.mode == kPlanPause) { // :820-824
+        if (plan_mode == kPlanPause) { // :820-824
             if (t0) {
                 S.state = kDecodeHeader;
                 const int32_t consumed = (int32_t)(sps + sps / 4u);
@@ -753,7 +776,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             continue;
         }
 
-        if (plan.mode == kPlanFinalize) { // decode(false) + frame bytes (:870-881), all threads
+        if (plan_mode == kPlanFinalize) { // decode(false) + frame bytes (:870-881), all threads
             const uint32_t n_cw = S.n_cw, cr = S.cr, n_bytes = S.fin_n_bytes, plen = S.fin_plen;
             decode_payload_bytes(sh, n_cw, cr, n_bytes);
             AttemptRec &r = recs[S.n_att];
@@ -773,24 +796,24 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         }
 
         // ---- kPlanDecode: DECODE_HEADER / DECODE_PAYLOAD rounds (:826-886), pipelined.  Workers demodulate the
-        // 7 symbols at plan.pos into spec[plan.buf]; concurrently the control thread resolves the previous round
-        // (spec[plan.buf ^ 1]) and decides whether this round's position was predicted correctly.
+        // 7 symbols at plan_pos into spec[plan_buf]; concurrently the control thread resolves the previous round
+        // (spec[plan_buf ^ 1]) and decides whether this round's position was predicted correctly.
         // The symbol clock moves when a window's fine sync is non-zero (:506-512, consumed = sps + fine): the windows after
         // it in that round started at the wrong sample, and so would this round, planned while that one was still being
         // computed.  The workers' fine values are in LDS by now, so every wavefront re-aims this round itself: it restarts
         // right after the first such window of the previous round, shifted by its fine value.  (Whether that is the true
         // continuation is still decided by the control wavefront's resolve, below.)
         int64_t dpos = pos;
-        int32_t dn = plan.n_win;
-        if (plan.resolve_prev && plan.prev_n > 0) {
-            const int rb = plan.buf ^ 1;
-            const int32_t s_l = lane < plan.prev_n ? W.speci[rb][lane][0] : -1, f_l = lane < plan.prev_n ? W.speci[rb][lane][1] : 0;
+        int32_t dn = plan_n_win;
+        if (plan_resolve_prev && plan_prev_n > 0) {
+            const int rb = plan_buf ^ 1;
+            const int32_t s_l = lane < plan_prev_n ? W.speci[rb][lane][0] : -1, f_l = lane < plan_prev_n ? W.speci[rb][lane][1] : 0;
             const unsigned long long moved = __ballot(s_l >= 0 && f_l != 0);
             if (moved) {
                 const int wq = __builtin_ctzll(moved);
-                const int32_t redo = plan.prev_n - (wq + 1); // windows of the previous round to be demodulated again
+                const int32_t redo = plan_prev_n - (wq + 1); // windows of the previous round to be demodulated again
                 dpos = pos - (int64_t)redo * sps + (int64_t)__builtin_amdgcn_readlane(f_l, wq);
-                dn = plan.n_win + redo < kW2Workers ? plan.n_win + redo : kW2Workers;
+                dn = plan_n_win + redo < kW2Workers ? plan_n_win + redo : kW2Workers;
             }
         }
         if (!is_ctl) {
@@ -799,7 +822,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             uint32_t ws = 0;
             int32_t wfine = 0;
             if (dvalid) wave_demod_symbol<SF, SF == 7>(P, FT, X + dwpos, ws, wfine);
-            if (lane == 0) { W.speci[plan.buf][wave][0] = dvalid ? (int32_t)ws : -1; W.speci[plan.buf][wave][1] = wfine; }
+            if (lane == 0) { W.speci[plan_buf][wave][0] = dvalid ? (int32_t)ws : -1; W.speci[plan_buf][wave][1] = wfine; }
         } else { // the whole control wavefront, uniformly (identical values in every lane); t0 does the stores
             bool predicted = true;
             const long long tr0 = clock64();
@@ -807,8 +830,8 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             W2State L = S; // the resolve works on a register copy: every field access in LDS is a ~130-cycle round trip
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const long long tr1 = clock64();
-            if (plan.resolve_prev) {
-                const int rb = plan.buf ^ 1;
+            if (plan_resolve_prev) {
+                const int rb = plan_buf ^ 1;
                 // lane w fetches worker w's result: one LDS round trip for the round instead of two per symbol
                 const int32_t my_s = lane < kW2Workers ? W.speci[rb][lane][0] : -1, my_f = lane < kW2Workers ? W.speci[rb][lane][1] : 0;
                 for (int w = 0; w < kW2Workers; w++) {
@@ -839,7 +862,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                     const int32_t rem = L.payload_symbols - (int32_t)L.n_words - dn;
                     n_next = rem < kW2Workers ? (rem > 0 ? rem : 0) : kW2Workers; // 0: nothing left to demodulate, only resolve
                 }
-                np.mode = kPlanDecode; np.pos = dpos + (int64_t)dn * sps; np.buf = plan.buf ^ 1; np.resolve_prev = 1; np.n_win = n_next;
+                np.mode = kPlanDecode; np.pos = dpos + (int64_t)dn * sps; np.buf = plan_buf ^ 1; np.resolve_prev = 1; np.n_win = n_next;
                 np.prev_n = dn; np.pad = 0;
             } else {
                 plan_from(L, np); // this round's results are discarded
