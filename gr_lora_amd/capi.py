@@ -21,7 +21,7 @@ EXPORTS = [
     "lora_hip_abi_version", "lora_hip_strerror", "lora_hip_last_error", "lora_hip_create", "lora_hip_destroy",
     "lora_hip_get_geometry", "lora_hip_set_sf", "lora_hip_set_samp_rate", "lora_hip_work", "lora_hip_flush",
     "lora_hip_decode_device", "lora_hip_frames_available", "lora_hip_poll_frame", "lora_hip_drain_frames", "lora_hip_drain_slots", "lora_hip_demod_symbols_device", "lora_hip_demod_symbols_ex_device",
-    "lora_hip_last_timing", "lora_hip_trace", "lora_hip_trace_clear",
+    "lora_hip_last_timing", "lora_hip_last_plan", "lora_hip_trace", "lora_hip_trace_clear",
 ]
 
 
@@ -110,6 +110,7 @@ def load():
     L.lora_hip_demod_symbols_device.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int, vp, vp]
     L.lora_hip_demod_symbols_ex_device.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int, vp, vp, vp]
     L.lora_hip_last_timing.argtypes = [vp, C.POINTER(Timing)]
+    L.lora_hip_last_plan.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.lora_hip_trace.restype = C.c_size_t
     L.lora_hip_trace.argtypes = [vp, C.POINTER(C.POINTER(Step))]
     L.lora_hip_trace_clear.argtypes = [vp]
@@ -263,6 +264,12 @@ class Handle:
         t = Timing()
         self._check(self.L.lora_hip_last_timing(self.h, C.byref(t)))
         return t
+
+    def plan(self):
+        """(burst_aware, segments) of the last pass: lora_hip_last_plan."""
+        b, n = C.c_uint32(0), C.c_uint32(0)
+        self._check(self.L.lora_hip_last_plan(self.h, C.byref(b), C.byref(n)))
+        return bool(b.value), int(n.value)
 
     def trace(self):
         p = C.POINTER(Step)()

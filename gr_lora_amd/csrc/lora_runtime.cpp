@@ -145,6 +145,7 @@ struct lora_hip_decoder {
     size_t batch_items = 0, batch_need = 0;
     uint32_t resident_slots = 0;
     uint32_t eager_recs = 4;
+    uint32_t last_plan_burst = 0, last_plan_segments = 0;
 };
 
 namespace {
@@ -527,6 +528,7 @@ struct DeviceEnv {
     void count_slow_path() { h->timing.slow_path_relaunches++; }
     void note_plan(bool burst_aware, size_t n_segs)
     {
+        h->last_plan_burst = burst_aware ? 1u : 0u; h->last_plan_segments = (uint32_t)n_segs;
         static const bool dbg = getenv("LORA_HIP_DEBUG") != nullptr;
         if (dbg) fprintf(stderr, "[lora_hip] segment plan: %s, %zu segments (envelope kernels %.3f ms)\n", burst_aware ? "burst-aware" : "fixed grid", n_segs, burst_aware ? h->envelope_ms : 0.0f);
     }
@@ -785,6 +787,14 @@ lora_hip_status lora_hip_demod_symbols_device(lora_hip_decoder_t *h, const void 
                                               void *hip_stream)
 {
     return lora_hip_demod_symbols_ex_device(h, d_iq, total_items, offsets, n, demod, bins_out, nullptr, hip_stream);
+}
+
+lora_hip_status lora_hip_last_plan(const lora_hip_decoder_t *h, uint32_t *burst_aware, uint32_t *segments)
+{
+    if (!h) return LORA_HIP_ERR_ARG;
+    if (burst_aware) *burst_aware = h->last_plan_burst;
+    if (segments) *segments = h->last_plan_segments;
+    return LORA_HIP_OK;
 }
 
 lora_hip_status lora_hip_last_timing(const lora_hip_decoder_t *h, lora_hip_timing_t *t)

@@ -167,6 +167,11 @@ lora_hip_status lora_hip_demod_symbols_ex_device(lora_hip_decoder_t *h, const vo
 
 /* ---- introspection --------------------------------------------------------------------------------------- */
 lora_hip_status lora_hip_last_timing(const lora_hip_decoder_t *h, lora_hip_timing_t *t);
+
+/* How the last pass cut its streams into speculation segments (diagnostics): *burst_aware = 1 when the cuts were placed
+ * in the gaps between bursts found by the energy-envelope pre-pass, 0 for the fixed grid (configured segment length,
+ * sparse or weak traffic, tracing); *segments = segments = workgroups of the main launch.                      */
+lora_hip_status lora_hip_last_plan(const lora_hip_decoder_t *h, uint32_t *burst_aware, uint32_t *segments);
 size_t          lora_hip_trace(const lora_hip_decoder_t *h, const lora_hip_step_t **steps);
 void            lora_hip_trace_clear(lora_hip_decoder_t *h);
 

@@ -291,3 +291,45 @@ def test_segment_speculation_noisy_and_cr_mix(torch_cuda, oracle_mod):
         assert [g[15:] for g, _ in got] == [w[15:] for w in want]
         assert [g for g, _ in got] == want
         h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("snr_db", [None, 12.0, -3.0])
+def test_burst_aware_plan_equals_oracle(torch_cuda, oracle_mod, snr_db):
+    """Dense traffic in auto mode: the envelope pre-pass finds the gaps and the scheduler cuts there (lora_hip_last_plan
+    says so); the frames are the oracle's, stream by stream.  With the bursts under the wideband noise the envelope
+    shows nothing and the fixed grid is used -- same frames again.  Gaps go down to zero (back-to-back packets)."""
+    from gr_lora_amd import capi
+    cfg = synth.TxConfig(sf=7, cr=4)
+    rng = np.random.default_rng(77)
+    n_streams, per = 6, 120
+    pieces, offs, lens = [], [], []
+    off = 0
+    for s in range(n_streams):
+        payloads = [bytes(rng.integers(0, 256, int(rng.integers(2, 40)), dtype=np.uint8)) for _ in range(per)]
+        gaps = [int(g) for g in rng.integers(0, 8 * cfg.sps, per)]
+        gaps[3] = 0; gaps[4] = 1; gaps[10] = cfg.sps // 3
+        iq = synth.build_stream(payloads, cfg, gaps=gaps).iq
+        if snr_db is not None:
+            sigma = synth.awgn_sigma_for_snr(snr_db, cfg)
+            iq = (iq + sigma / np.sqrt(2.0) * (rng.standard_normal(iq.size) + 1j * rng.standard_normal(iq.size))).astype(np.complex64)
+        pieces.append(iq); offs.append(off); lens.append(iq.size); off += iq.size
+    allq = np.concatenate(pieces)
+    dev = _to_dev(torch_cuda, allq)
+    h = capi.Handle(sf=7, cr=4, demod=capi.DEMOD_FFT_COMPAT)
+    h.decode_device(dev.data_ptr(), allq.size, offs, lens, 0)
+    got = h.drain()
+    burst, segs = h.plan()
+    h.close()
+    if snr_db is None or snr_db > 5.0:
+        assert burst and 2 <= segs <= 512
+    elif snr_db < 0.0:
+        assert not burst
+    for s in range(n_streams):
+        o = oracle_mod.Oracle(sf=7, cr=4, demod=oracle_mod.DEMOD_FFT_COMPAT)
+        o.run(allq[offs[s]:offs[s] + lens[s]])
+        mine = [(g, i.header_pos) for g, i in got if i.stream == s]
+        assert [g for g, _ in mine] == o.frames()
+        assert [p for _, p in mine] == o.frame_positions()
+        if snr_db is None:
+            assert len(mine) >= per - 4
