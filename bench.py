@@ -178,7 +178,7 @@ def main():
         # WRITE_SIZE passes, gfx950 FETCH x2 correction as MI355X_MICROARCH.md prescribes); null otherwise
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_e_pmc_traffic.json")))
             if pmc.get("workload_items") == n_items and args.demod != 0:
                 traffic = int(pmc["hbm_bytes_per_pass_corrected"])
         except (OSError, ValueError, KeyError):
@@ -196,7 +196,7 @@ def main():
                        "bit_exact_vs_expected": verified, "parallelism": "streams sharded, dp%d" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "traffic_unit": "HBM bytes per pass (PMC, profiles/r01_d_pmc_traffic.json)",
+                         "traffic_unit": "HBM bytes per pass (PMC, profiles/r01_e_pmc_traffic.json)",
                          "kernel": kname, "kernel_ms_per_pass": round(kernel_ms, 4),
                          "launches_per_pass": launches / max(1, args.steps),
                          "algorithmic_bytes_per_pass": 8 * n_items},

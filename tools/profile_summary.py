@@ -16,7 +16,7 @@ def per_dispatch(kind, counter):
     for path in glob.glob(os.path.join(src, kind, "**", "*counter_collection.csv"), recursive=True):
         acc, meta = collections.defaultdict(float), {}
         for row in csv.DictReader(open(path)):
-            if row["Counter_Name"] != counter or "walker" not in row["Kernel_Name"]:
+            if row["Counter_Name"] != counter or not any(k in row["Kernel_Name"] for k in ("walker", "envelope_kernel", "edges_kernel")):
                 continue
             acc[row["Dispatch_Id"]] += float(row["Counter_Value"])
             meta[row["Dispatch_Id"]] = (row["Kernel_Name"].split("(")[0], row["Grid_Size"])
@@ -27,13 +27,17 @@ def per_dispatch(kind, counter):
 fetch, write = per_dispatch("fetch", "FETCH_SIZE"), per_dispatch("write", "WRITE_SIZE")
 line = json.loads([l for l in open(os.path.join(src, "stats.log")).read().splitlines() if l.startswith("{\"metric\"")][-1])
 disp = {}
-fetch_raw = write_raw = 0.0
+fetch_raw = write_raw = pre_fetch = pre_write = 0.0
 for key in sorted(set(fetch) | set(write)):
     f = sum(fetch.get(key, [0])) / max(1, len(fetch.get(key, [])))
     w = sum(write.get(key, [0])) / max(1, len(write.get(key, [])))
     disp["%s grid %s" % key] = {"fetch_kb_avg": f, "write_kb_avg": w, "dispatches_fetch_pass": len(fetch.get(key, []))}
-    fetch_raw += f * 1024.0
-    write_raw += w * 1024.0
+    if "walker" in key[0]:
+        fetch_raw += f * 1024.0
+        write_raw += w * 1024.0
+    else: # the segment-planning pre-pass (envelope_kernel, edges_kernel)
+        pre_fetch += f * 1024.0
+        pre_write += w * 1024.0
 res = {
     "command": "tools/profile_round.sh %s: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline" % tag,
     "workload_items": line["config"]["items_per_gpu"],
@@ -45,6 +49,7 @@ res = {
                                "pattern (8 B per lane, 512 contiguous bytes per wave instruction) with tools/calib_fetch.hip: FETCH_SIZE = 0.500 x bytes read; "
                                "WRITE_SIZE is uncalibrated",
     "hbm_bytes_per_pass_corrected": 2.0 * fetch_raw + write_raw,
+    "prepass_hbm_bytes_per_pass_corrected": 2.0 * pre_fetch + pre_write,
     "algorithmic_bytes_per_pass": 8 * line["config"]["items_per_gpu"],
 }
 json.dump(res, open(os.path.join("profiles", "%s_%s_pmc_traffic.json" % (rnd, tag)), "w"), indent=1)
