@@ -316,21 +316,30 @@ lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vec
     out.res.resize(nj); // (overwritten from the landing buffer below)
     out.recs.clear();
     if (nj == 0) return LORA_HIP_OK;
-    HIP_TRY(h, h->d_jobs.reserve(nj));
-    HIP_TRY(h, h->d_results.reserve(nj));
-    HIP_TRY(h, h->d_recs.reserve((size_t)nj * recs_per_job));
+    static const bool staged_bufs = getenv("LORA_HIP_STAGED") != nullptr;
+    if (staged_bufs) {
+        HIP_TRY(h, h->d_jobs.reserve(nj));
+        HIP_TRY(h, h->d_results.reserve(nj));
+        HIP_TRY(h, h->d_recs.reserve((size_t)nj * recs_per_job));
+    }
     const bool need_scratch = !h->P.ifreq_in_lds_2;
     if (need_scratch) HIP_TRY(h, h->d_scratch.reserve((size_t)nj * 2u * h->P.sps));
     if (trace_cap) HIP_TRY(h, h->d_trace.reserve((size_t)nj * trace_cap));
-    // attempt records per job fetched together with the results: what the busiest job of the previous launch needed
-    const uint32_t eager = std::min(std::max(h->eager_recs, 2u), recs_per_job);
+    // Jobs, results and attempt records live in page-locked host memory that the kernel reads and writes directly:
+    // 32 KB of jobs are read over PCIe once per workgroup, the records trickle out as they are produced, and nothing is
+    // left to copy when the kernel ends (staged copies: one H2D before and two D2H after the launch, ~40 us of a 0.6 ms
+    // pass).  LORA_HIP_STAGED=1 keeps the staged path (diagnostics).
+    static const bool direct = getenv("LORA_HIP_STAGED") == nullptr;
+    // staged only: attempt records per job fetched together with the results (what the busiest job of the previous launch needed)
+    const uint32_t eager = direct ? recs_per_job : std::min(std::max(h->eager_recs, 2u), recs_per_job);
     HIP_TRY(h, h->p_jobs.reserve(nj));
     HIP_TRY(h, h->p_res.reserve(nj));
     HIP_TRY(h, h->p_recs.reserve((size_t)nj * eager));
     std::memcpy(h->p_jobs.p, jobs.data(), nj * sizeof(Job));
-    HIP_TRY(h, hipMemcpyAsync(h->d_jobs.p, h->p_jobs.p, nj * sizeof(Job), hipMemcpyHostToDevice, st));
+    if (!direct) HIP_TRY(h, hipMemcpyAsync(h->d_jobs.p, h->p_jobs.p, nj * sizeof(Job), hipMemcpyHostToDevice, st));
     LaunchCfg c{};
-    c.iq = d_iq; c.jobs = h->d_jobs.p; c.results = h->d_results.p; c.recs = h->d_recs.p; c.recs_per_job = recs_per_job;
+    c.iq = d_iq; c.recs_per_job = recs_per_job;
+    c.jobs = direct ? h->p_jobs.p : h->d_jobs.p; c.results = direct ? h->p_res.p : h->d_results.p; c.recs = direct ? h->p_recs.p : h->d_recs.p;
     c.scratch = need_scratch ? h->d_scratch.p : nullptr;
     c.trace = trace_cap ? h->d_trace.p : nullptr; c.trace_cap = trace_cap; c.n_jobs = nj;
     static const bool no_balance = getenv("LORA_HIP_NO_BALANCE") != nullptr;
@@ -342,9 +351,11 @@ lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vec
     HIP_TRY(h, hipEventRecord(h->ev0, st));
     if (launch_walker(h->P, c, st) != 0) return fail(h, LORA_HIP_ERR_HIP, "walker launch failed: %s", hipGetErrorString(hipGetLastError()));
     HIP_TRY(h, hipEventRecord(h->ev1, st));
-    HIP_TRY(h, hipMemcpyAsync(h->p_res.p, h->d_results.p, nj * sizeof(JobResult), hipMemcpyDeviceToHost, st));
-    HIP_TRY(h, hipMemcpy2DAsync(h->p_recs.p, eager * sizeof(AttemptRec), h->d_recs.p, recs_per_job * sizeof(AttemptRec), eager * sizeof(AttemptRec), nj,
-                                hipMemcpyDeviceToHost, st));
+    if (!direct) {
+        HIP_TRY(h, hipMemcpyAsync(h->p_res.p, h->d_results.p, nj * sizeof(JobResult), hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipMemcpy2DAsync(h->p_recs.p, eager * sizeof(AttemptRec), h->d_recs.p, recs_per_job * sizeof(AttemptRec), eager * sizeof(AttemptRec), nj,
+                                    hipMemcpyDeviceToHost, st));
+    }
     const auto hp1 = std::chrono::steady_clock::now();
     HIP_TRY(h, hipStreamSynchronize(st));
     const auto hp2 = std::chrono::steady_clock::now();
@@ -394,7 +405,7 @@ lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vec
     const uint32_t stride = std::max(max_att, 1u);
     out.rpj = stride;
     out.recs.resize_uninit((size_t)nj * stride); // every element is written below
-    // the eagerly fetched records: only the ones a job wrote, and of each only the header and the frame bytes it holds
+    // the landed records: only the ones a job wrote, and of each only the header and the frame bytes it holds
     // (the landing buffer has just been written by DMA: every byte read from it comes from DRAM)
     for (uint32_t j = 0; j < nj; j++) {
         const uint32_t used = std::min(std::min(eager, max_att), out.res[j].n_attempts + (out.res[j].tail_valid ? out.res[j].tail_n_attempts : 0u));
@@ -464,10 +475,11 @@ lora_hip_status quiet_edges(lora_hip_decoder *h, const float2 *d_iq, const std::
     HIP_TRY(h, hipMemcpyAsync(h->d_env_streams.p, h->p_env_streams.p, ns * sizeof(EnvStream), hipMemcpyHostToDevice, st));
     static const bool dbg = getenv("LORA_HIP_DEBUG") != nullptr;
     if (dbg) HIP_TRY(h, hipEventRecord(h->ev0, st));
-    if (launch_envelope(d_iq, h->d_env_streams.p, ns, (uint32_t)nb, sps, h->d_env_E.p, h->d_env_buf.p, st) != 0)
+    static const bool direct = getenv("LORA_HIP_STAGED") == nullptr; // the bitmap is written straight into page-locked host memory
+    if (launch_envelope(d_iq, h->d_env_streams.p, ns, (uint32_t)nb, sps, h->d_env_E.p, direct ? h->p_env_buf.p : h->d_env_buf.p, st) != 0)
         return fail(h, LORA_HIP_ERR_HIP, "envelope launch failed: %s", hipGetErrorString(hipGetLastError()));
     if (dbg) HIP_TRY(h, hipEventRecord(h->ev1, st));
-    HIP_TRY(h, hipMemcpyAsync(h->p_env_buf.p, h->d_env_buf.p, words * 8u, hipMemcpyDeviceToHost, st));
+    if (!direct) HIP_TRY(h, hipMemcpyAsync(h->p_env_buf.p, h->d_env_buf.p, words * 8u, hipMemcpyDeviceToHost, st));
     const auto hq1 = std::chrono::steady_clock::now();
     HIP_TRY(h, hipStreamSynchronize(st));
     const auto hq2 = std::chrono::steady_clock::now();
