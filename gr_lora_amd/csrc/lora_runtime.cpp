@@ -672,6 +672,31 @@ lora_hip_status lora_hip_decode_device(lora_hip_decoder_t *h, const void *d_iq, 
     return decode_streams(h, (const float2 *)d_iq, sds, (hipStream_t)hip_stream);
 }
 
+lora_hip_status lora_hip_gap_starts_device(lora_hip_decoder_t *h, const void *d_iq, size_t total_items, const uint64_t *stream_off,
+                                           const uint64_t *stream_len, uint32_t n_streams, int64_t *pos, size_t cap, uint32_t *counts,
+                                           void *hip_stream)
+{
+    if (!h || !d_iq || !n_streams || !stream_off || !stream_len || !counts || (!pos && cap)) return LORA_HIP_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    std::vector<StreamDesc> sds(n_streams);
+    for (uint32_t i = 0; i < n_streams; i++) {
+        if (stream_off[i] + stream_len[i] > total_items) return fail(h, LORA_HIP_ERR_ARG, "stream %u exceeds the buffer", i);
+        sds[i].off = stream_off[i]; sds[i].len = stream_len[i]; sds[i].id = i;
+    }
+    std::vector<std::vector<int64_t>> edges;
+    h->err.clear();
+    const lora_hip_status s = quiet_edges(h, (const float2 *)d_iq, sds, (hipStream_t)hip_stream, edges);
+    if (s != LORA_HIP_OK) return h->err.empty() ? fail(h, LORA_HIP_ERR_BAD_CONFIG, "no envelope for these streams (shorter than a symbol, or fewer than 128 samples per symbol)") : s;
+    size_t used = 0;
+    for (uint32_t i = 0; i < n_streams; i++) {
+        counts[i] = (uint32_t)edges[i].size();
+        if (used + edges[i].size() > cap) return LORA_HIP_ERR_OVERFLOW;
+        std::copy(edges[i].begin(), edges[i].end(), pos + used);
+        used += edges[i].size();
+    }
+    return LORA_HIP_OK;
+}
+
 static lora_hip_status stream_pass(lora_hip_decoder_t *h, bool flushing)
 {
     const size_t items = h->hostbuf.size() / 2u;

@@ -134,6 +134,15 @@ lora_hip_status lora_hip_decode_device(lora_hip_decoder_t *h, const void *d_iq, 
                                        const uint64_t *stream_off, const uint64_t *stream_len,
                                        uint32_t n_streams, void *hip_stream);
 
+/* Diagnostics: where the segment planner's energy-envelope pre-pass sees the streams go quiet (the start of every gap
+ * between bursts; lora_hip_decode_device cuts its speculation segments there when the traffic is dense enough).
+ * counts[i] = gap starts found in stream i; their item positions, relative to the stream and ascending, are packed stream
+ * after stream into pos[0 .. sum(counts)) (LORA_HIP_ERR_OVERFLOW when cap is too small).  Streams shorter than one
+ * symbol or a samples/symbol below 128 give LORA_HIP_ERR_BAD_CONFIG.  Not part of the reference: it has no scheduler. */
+lora_hip_status lora_hip_gap_starts_device(lora_hip_decoder_t *h, const void *d_iq, size_t total_items,
+                                           const uint64_t *stream_off, const uint64_t *stream_len, uint32_t n_streams,
+                                           int64_t *pos, size_t cap, uint32_t *counts, void *hip_stream);
+
 /* ---- "frames" message port (decoder_impl.cc:120, 588-609) ----------------------------------------------- */
 size_t          lora_hip_frames_available(const lora_hip_decoder_t *h);
 /* Pops the oldest frame: blob = loratap_header_t (15 B, include/lora/loratap.h:35-55) | loraphy_header_t

@@ -333,3 +333,39 @@ def test_burst_aware_plan_equals_oracle(torch_cuda, oracle_mod, snr_db):
         assert [p for _, p in mine] == o.frame_positions()
         if snr_db is None:
             assert len(mine) >= per - 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sf,snr_db", [(7, None), (7, 14.0), (8, None)])
+def test_envelope_gap_starts_vs_numpy(torch_cuda, sf, snr_db):
+    """envelope_kernel + edges_kernel against their numpy restatement (oracle/envelope_oracle.py): same gap starts,
+    stream by stream, including a stream at an odd item offset, back-to-back packets and a ragged tail."""
+    from gr_lora_amd import capi
+    from oracle import envelope_oracle as EO
+    cfg = synth.TxConfig(sf=sf, cr=4)
+    rng = np.random.default_rng(500 + sf)
+    pieces, offs, lens = [np.zeros(3, dtype=np.complex64)], [], []   # first stream starts at an odd item
+    off = 3
+    for s in range(3):
+        payloads = [bytes(rng.integers(0, 256, int(rng.integers(2, 30)), dtype=np.uint8)) for _ in range(12)]
+        gaps = [int(g) for g in rng.integers(0, 9 * cfg.sps, len(payloads))]
+        gaps[2] = 0; gaps[3] = cfg.sps // 2
+        iq = synth.build_stream(payloads, cfg, gaps=gaps).iq
+        iq = iq[: iq.size - int(rng.integers(0, cfg.sps))]          # ragged end
+        if snr_db is not None:
+            sigma = synth.awgn_sigma_for_snr(snr_db, cfg)
+            iq = (iq + sigma / np.sqrt(2.0) * (rng.standard_normal(iq.size) + 1j * rng.standard_normal(iq.size))).astype(np.complex64)
+        pieces.append(iq); offs.append(off); lens.append(iq.size); off += iq.size
+    allq = np.concatenate(pieces)
+    dev = _to_dev(torch_cuda, allq)
+    h = capi.Handle(sf=sf, cr=4, demod=capi.DEMOD_FFT_COMPAT)
+    got = h.gap_starts_device(dev.data_ptr(), allq.size, offs, lens, 0)
+    h.close()
+    total = 0
+    for s in range(3):
+        certain, possible = EO.gap_starts(allq, offs[s], lens[s], cfg.sps, rel_tol=1e-4)   # float32 sums on the device
+        g = set(got[s].tolist())
+        assert set(certain.tolist()) <= g <= set(possible.tolist()), s
+        assert got[s].tolist() == sorted(g)
+        total += certain.size
+    assert total >= 12   # gaps of about two symbols and more are found (shorter ones need not leave a quiet block)
