@@ -219,16 +219,10 @@ __device__ __forceinline__ bool w2_post_symbol(const DevParams &P, W2State &S, S
 
 // ---- wave-level window evaluations ---------------------------------------------------------------------
 // DETECT (:340-366): sums of c1*conj(c2), |c1|^2, |c2|^2 over one symbol pair
-#ifndef LORA_W2_GLOBAL
-#define LORA_W2_GLOBAL __attribute__((address_space(1)))
-#endif
-#ifndef LORA_W2_WINDOW_ATTR
-#define LORA_W2_WINDOW_ATTR __forceinline__ // (as out-of-line functions they fault on the device: left inline)
-#endif
 template <int SF>
-__device__ LORA_W2_WINDOW_ATTR float4 w2_detect_window(const float2 *p_)
+__device__ __forceinline__ float4 w2_detect_window(const float2 *p_)
 {
-    const auto p = (const LORA_W2_GLOBAL v2f *)p_; // global, not flat, loads
+    const auto p = (const __attribute__((address_space(1))) v2f *)p_; // global, not flat, loads
     constexpr int SPS = 8 << SF, J = SPS / 64;
     const int lane = threadIdx.x & 63;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -289,7 +283,7 @@ __device__ __forceinline__ void w2_detect_windows(const float2 *__restrict__ p, 
 // downchirp ifreq, and -- for an upchirp (c < -0.97) -- fine_sync(-1, 4*D) over the 63 lags.
 struct W2SfdOut { float c; int32_t fine; };
 template <int SF>
-__device__ LORA_W2_WINDOW_ATTR W2SfdOut w2_sfd_window(const float2 *p, const float *Tv, const float *Tdd, float *scr /* this wavefront's 72 floats */,
+__device__ __forceinline__ W2SfdOut w2_sfd_window(const float2 *p, const float *Tv, const float *Tdd, float *scr /* this wavefront's 72 floats */,
                                                           float down_ifreq_sd, float down_ifreq_dsum, double sync_a, double sync_b)
 {
     constexpr int SPS = 8 << SF, J = SPS / 64;
@@ -297,7 +291,7 @@ __device__ LORA_W2_WINDOW_ATTR W2SfdOut w2_sfd_window(const float2 *p, const flo
     asm volatile("" : "+v"(lane));
     float f[J];
     {
-        const auto pv = (const LORA_W2_GLOBAL v2f *)p; // global, not flat, loads
+        const auto pv = (const __attribute__((address_space(1))) v2f *)p; // global, not flat, loads
         v2f a[J]; // the whole window in one round of loads (lane owns n = 64 j + lane)
 #pragma unroll
         for (int j = 0; j < J; j++) a[j] = pv[j * 64 + lane];
@@ -604,10 +598,6 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 }
             }
             __syncthreads();
-#ifdef LORA_W2_STAMP_ACQ
-            const long long ts_b = clock64();
-            if (t0) W.stats.ctl[0] += (uint32_t)((ts_b - t_start) >> 6);
-#endif
             if (is_ctl) {
                 // the control wavefront evaluates all windows at once (lane q = window q); what the serial replay
                 // of :740-768 would do with them -- stop at the first trigger, at the scan limit or at the end of
@@ -675,10 +665,6 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                     W2Plan np;
                     plan_from(L, np);
                     next = np; S = L;
-#ifdef LORA_W2_STAMP_ACQ
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    W.stats.ctl[1] += (uint32_t)((clock64() - ts_b) >> 6);
-#endif
                 }
             }
             continue;
@@ -730,10 +716,6 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             }
             if (lane == 0 && !is_ctl) { W.specf[wave][0] = c; W.speci[0][wave][0] = wvalid ? 1 : 0; W.speci[0][wave][1] = fine; }
             __syncthreads();
-#ifdef LORA_W2_STAMP_ACQ
-            const long long ts_b = clock64();
-            if (t0) W.stats.ctl[2] += (uint32_t)((ts_b - t_start) >> 6);
-#endif
             if (is_ctl) { // the whole control wavefront, uniformly, on a register copy of the state (as the decode rounds do)
                 W2State L = S;
                 const float my_c = lane < kW2Workers ? W.specf[lane][0] : 0.0f;
@@ -757,10 +739,6 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 W2Plan np;
                 plan_from(L, np);
                 if (t0) { next = np; S = L; }
-#ifdef LORA_W2_STAMP_ACQ
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (t0) W.stats.ctl[3] += (uint32_t)((clock64() - ts_b) >> 6);
-#endif
             }
             continue;
         }
@@ -873,10 +851,8 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 S = L;
                 W.words_pk[0] = wpk[0]; W.words_pk[1] = wpk[1];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifndef LORA_W2_STAMP_ACQ
                 W.stats.ctl[0] += (uint32_t)((tr1 - tr0) >> 6); W.stats.ctl[1] += (uint32_t)((tr2 - tr1) >> 6); W.stats.ctl[2] += (uint32_t)((tr3 - tr2) >> 6);
                 W.stats.ctl[3] += (uint32_t)((clock64() - tr3) >> 6);
-#endif
                 W.stats.cyc[4] += (uint32_t)((clock64() - tr0) >> 6); W.stats.rounds[4]++; // control wavefront's share of a decode round
             }
         }
