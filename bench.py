@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--payload", type=int, default=32)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("LORA_BENCH_STREAMS", "8")))
     ap.add_argument("--demod", type=int, default=2, help="0 grad, 1 fft, 2 fft_compat")
+    ap.add_argument("--depth", type=int, default=2, help="passes in flight: 2 = while the device runs step k+1 the host stitches step k "
+                    "(two decoder handles alternating on one stream; kernels never overlap), 1 = strictly one after the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -121,37 +123,57 @@ def main():
     cfg, iq, offs, lens, expect = make_workload(args.sf, args.cr, args.packets, args.payload, args.streams, seed=2 + 1000 * rank)
     n_items = int(iq.size)
     d_iq = torch.from_numpy(iq.view(np.float32)).to(dev)
-    h = capi.Handle(samp_rate=cfg.samp_rate, bandwidth=cfg.bw, sf=cfg.sf, cr=4, crc=True, reduced_rate=cfg.reduced_rate,
-                    device=local_rank, demod=args.demod)
+    depth = max(1, min(2, args.depth))
+    hs = [capi.Handle(samp_rate=cfg.samp_rate, bandwidth=cfg.bw, sf=cfg.sf, cr=4, crc=True, reduced_rate=cfg.reduced_rate,
+                      device=local_rank, demod=args.demod) for _ in range(depth)]
+    h = hs[0]
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step():
-        h.decode_device(d_iq.data_ptr(), n_items, offs, lens, stream)
-        mine = h.drain_slots(gather.SLOT_BYTES)              # frames straight into the exchange layout
+    # One step = one full pass over the batch.  With depth 2 the passes are software-pipelined the way a streaming receiver
+    # runs them: the plan + launch of step k+1 (begin) is issued before the results of step k are collected (finish), on
+    # the same HIP stream, so the device goes from one walker kernel straight to the next while the host stitches.
+    def begin(k):   # the IQ is resident and unchanged: the envelope pre-pass need not wait for the stream (IQ_READY)
+        hs[k % depth].decode_device_begin(d_iq.data_ptr(), n_items, offs, lens, stream, iq_ready=True)
+
+    def finish(k):
+        hk = hs[k % depth]
+        hk.decode_device_end()
+        mine = hk.drain_slots(gather.SLOT_BYTES)             # frames straight into the exchange layout
         slots, counts = gather.gather_slots(mine, dev)       # RCCL all_gather of the frames when N > 1
-        return slots, counts
+        return slots, counts, hk.timing()
 
-    # correctness of what is being timed (outside the timed region): frames as gathered, this rank's share
-    slots, counts = step()
-    mine = gather.unpack_frames(slots[rank if len(counts) > 1 else 0], counts[rank if len(counts) > 1 else 0])
-    got = {}
-    for b, sid, _hp in mine:
-        got.setdefault(sid, []).append(b[15:])
-    verified = all(got.get(s, []) == expect[s] for s in range(len(offs)))
+    def run(n_steps):
+        wk, ln = 0.0, 0
+        if n_steps <= 0:
+            return wk, ln
+        begin(0)
+        for k in range(n_steps):
+            if depth > 1 and k + 1 < n_steps:
+                begin(k + 1)
+            _s, _c, tm = finish(k)
+            wk += tm.walker_ms
+            ln += tm.walker_launches
+            if depth == 1 and k + 1 < n_steps:
+                begin(k + 1)
+        return wk, ln
 
-    for _ in range(args.warmup):
-        step()
-    walker_ms = 0.0
-    launches = 0
+    # correctness of what is being timed (outside the timed region): frames as gathered, this rank's share, every handle
+    verified = True
+    for j in range(depth):
+        begin(j)
+        slots, counts, _tm = finish(j)
+        mine = gather.unpack_frames(slots[rank if len(counts) > 1 else 0], counts[rank if len(counts) > 1 else 0])
+        got = {}
+        for b, sid, _hp in mine:
+            got.setdefault(sid, []).append(b[15:])
+        verified = verified and all(got.get(s, []) == expect[s] for s in range(len(offs)))
+
+    run(args.warmup)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        tm = h.timing()
-        walker_ms += tm.walker_ms
-        launches += tm.walker_launches
+    walker_ms, launches = run(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -193,7 +215,8 @@ def main():
             "config": {"workload": "SF%d CR4/%d BW125k fs1M, %d packets x %d B payload per GPU, %d stream(s)" %
                                    (args.sf, 4 + args.cr, args.packets, args.payload, args.streams),
                        "items_per_gpu": n_items, "demod": ["grad", "fft", "fft_compat"][args.demod],
-                       "bit_exact_vs_expected": verified, "parallelism": "streams sharded, dp%d" % world},
+                       "bit_exact_vs_expected": verified, "parallelism": "streams sharded, dp%d" % world,
+                       "pipeline_depth": depth},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "traffic_unit": "HBM bytes per pass (PMC, profiles/r01_e_pmc_traffic.json)",
@@ -209,7 +232,8 @@ def main():
                                    "all_cores": {"value": round(cb["all_cores"][0], 3), "unit": "Msamples/s", "threads": cb["all_cores"][1],
                                                  "host_cores": cb["all_cores"][2], "sample": "one decoder per stream, gradient demod, 12e6 items each"}}
         print(json.dumps(res))
-    h.close()
+    for hk in hs:
+        hk.close()
     if world > 1:
         dist.destroy_process_group()
 

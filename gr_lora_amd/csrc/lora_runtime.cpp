@@ -120,7 +120,18 @@ struct lora_hip_decoder {
     std::vector<JobResult> h_results;
     std::vector<AttemptRec> h_recs;
     std::vector<StepRec> h_trace;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
+    hipEvent_t ev_pre0 = nullptr, ev_pre1 = nullptr, ev_dep = nullptr; // envelope pre-pass timing; dependency of the pre-pass stream on the caller's
+    hipStream_t pre_stream = nullptr;  // the envelope pre-pass runs here, beside whatever the caller's stream is busy with
+    // the main launch of a pass between run_jobs_begin and run_jobs_end
+    struct Pending { uint32_t nj = 0, recs_per_job = 0, eager = 0, trace_cap = 0; bool direct = true, open = false; hipStream_t st = nullptr;
+                     std::chrono::steady_clock::time_point hp0, hp1; } pending;
+    // a pass between lora_hip_decode_device_begin and _end
+    PassCtx pass;
+    std::vector<StreamDesc> pass_streams;
+    const float2 *pass_iq = nullptr;
+    hipStream_t pass_st = nullptr;
+    bool pass_open = false, iq_ready = false;
     // outputs
     FrameQueue frames;
     PinnedBuf<Job> p_jobs;             // staging for run_jobs: jobs up, results and the first attempt records down
@@ -306,12 +317,15 @@ void publish(lora_hip_decoder *h, const AttemptRec &r, StreamDesc &sd)
     std::memcpy(blob + kLoratapLen, r.frame, r.frame_len);
 }
 
-// Runs the walker over a set of jobs and brings results back to the host.
-lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vector<Job> &jobs, uint32_t recs_per_job,
-                         uint32_t trace_cap, hipStream_t st, RunOut &out)
+// Launches the walker over a set of jobs (run_jobs_begin) and brings the results back to the host (run_jobs_end).
+lora_hip_status run_jobs_begin(lora_hip_decoder *h, const float2 *d_iq, const std::vector<Job> &jobs, uint32_t recs_per_job,
+                               uint32_t trace_cap, hipStream_t st, RunOut &out)
 {
     const uint32_t nj = (uint32_t)jobs.size();
     const auto hp0 = std::chrono::steady_clock::now();
+    if (h->pending.open) return fail(h, LORA_HIP_ERR_INTERNAL, "a launch is already in flight on this handle");
+    h->pending = lora_hip_decoder::Pending{};
+    h->pending.nj = nj; h->pending.recs_per_job = recs_per_job; h->pending.trace_cap = trace_cap; h->pending.st = st; h->pending.hp0 = hp0;
     out.rpj = recs_per_job; out.cap = recs_per_job;
     out.res.resize(nj); // (overwritten from the landing buffer below)
     out.recs.clear();
@@ -356,8 +370,21 @@ lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vec
         HIP_TRY(h, hipMemcpy2DAsync(h->p_recs.p, eager * sizeof(AttemptRec), h->d_recs.p, recs_per_job * sizeof(AttemptRec), eager * sizeof(AttemptRec), nj,
                                     hipMemcpyDeviceToHost, st));
     }
-    const auto hp1 = std::chrono::steady_clock::now();
-    HIP_TRY(h, hipStreamSynchronize(st));
+    HIP_TRY(h, hipEventRecord(h->ev_done, st)); // (waited for instead of the stream: the caller may have queued another pass behind this one)
+    h->pending.eager = eager; h->pending.direct = direct; h->pending.open = true;
+    h->pending.hp1 = std::chrono::steady_clock::now();
+    return LORA_HIP_OK;
+}
+
+lora_hip_status run_jobs_end(lora_hip_decoder *h, RunOut &out)
+{
+    if (!h->pending.open) return LORA_HIP_OK; // nothing was launched (no jobs)
+    h->pending.open = false;
+    const uint32_t nj = h->pending.nj, recs_per_job = h->pending.recs_per_job, eager = h->pending.eager, trace_cap = h->pending.trace_cap;
+    const hipStream_t st = h->pending.st;
+    const auto hp0 = h->pending.hp0, hp1 = h->pending.hp1;
+    const Job *jobs = h->p_jobs.p;
+    HIP_TRY(h, hipEventSynchronize(h->ev_done));
     const auto hp2 = std::chrono::steady_clock::now();
     std::memcpy(out.res.data(), h->p_res.p, nj * sizeof(JobResult));
     static const bool dbg_stats = getenv("LORA_HIP_DEBUG") != nullptr;
@@ -441,6 +468,13 @@ lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vec
     return LORA_HIP_OK;
 }
 
+lora_hip_status run_jobs(lora_hip_decoder *h, const float2 *d_iq, const std::vector<Job> &jobs, uint32_t recs_per_job, uint32_t trace_cap,
+                         hipStream_t st, RunOut &out)
+{
+    const lora_hip_status s = run_jobs_begin(h, d_iq, jobs, recs_per_job, trace_cap, st, out);
+    return s == LORA_HIP_OK ? run_jobs_end(h, out) : s;
+}
+
 void append_trace(lora_hip_decoder *h, const RunOut &out, uint32_t job_index, uint32_t trace_cap, int64_t abs_base)
 {
     const JobResult &jr = out.res[job_index];
@@ -472,18 +506,26 @@ lora_hip_status quiet_edges(lora_hip_decoder *h, const float2 *d_iq, const std::
     HIP_TRY(h, h->d_env_E.reserve(nb));
     HIP_TRY(h, h->d_env_buf.reserve(words));
     HIP_TRY(h, h->p_env_buf.reserve(words));
-    HIP_TRY(h, hipMemcpyAsync(h->d_env_streams.p, h->p_env_streams.p, ns * sizeof(EnvStream), hipMemcpyHostToDevice, st));
+    // The pre-pass runs on the handle's own stream, ordered after what the caller's stream holds so far (whoever
+    // produced the IQ) unless the caller has declared the IQ ready (LORA_HIP_FLAG... see lora_hip_decode_device_begin):
+    // then it runs beside whatever that stream is busy with - the previous pass's walker, when passes are pipelined.
+    const hipStream_t ps = h->pre_stream;
+    if (!h->iq_ready) {
+        HIP_TRY(h, hipEventRecord(h->ev_dep, st));
+        HIP_TRY(h, hipStreamWaitEvent(ps, h->ev_dep, 0));
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->d_env_streams.p, h->p_env_streams.p, ns * sizeof(EnvStream), hipMemcpyHostToDevice, ps));
     static const bool dbg = getenv("LORA_HIP_DEBUG") != nullptr;
-    if (dbg) HIP_TRY(h, hipEventRecord(h->ev0, st));
+    if (dbg) HIP_TRY(h, hipEventRecord(h->ev_pre0, ps));
     static const bool direct = getenv("LORA_HIP_STAGED") == nullptr; // the bitmap is written straight into page-locked host memory
-    if (launch_envelope(d_iq, h->d_env_streams.p, ns, (uint32_t)nb, sps, h->d_env_E.p, direct ? h->p_env_buf.p : h->d_env_buf.p, st) != 0)
+    if (launch_envelope(d_iq, h->d_env_streams.p, ns, (uint32_t)nb, sps, h->d_env_E.p, direct ? h->p_env_buf.p : h->d_env_buf.p, ps) != 0)
         return fail(h, LORA_HIP_ERR_HIP, "envelope launch failed: %s", hipGetErrorString(hipGetLastError()));
-    if (dbg) HIP_TRY(h, hipEventRecord(h->ev1, st));
-    if (!direct) HIP_TRY(h, hipMemcpyAsync(h->p_env_buf.p, h->d_env_buf.p, words * 8u, hipMemcpyDeviceToHost, st));
+    if (dbg) HIP_TRY(h, hipEventRecord(h->ev_pre1, ps));
+    if (!direct) HIP_TRY(h, hipMemcpyAsync(h->p_env_buf.p, h->d_env_buf.p, words * 8u, hipMemcpyDeviceToHost, ps));
     const auto hq1 = std::chrono::steady_clock::now();
-    HIP_TRY(h, hipStreamSynchronize(st));
+    HIP_TRY(h, hipStreamSynchronize(ps));
     const auto hq2 = std::chrono::steady_clock::now();
-    if (dbg) { float ms = 0; if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->envelope_ms = ms; }
+    if (dbg) { float ms = 0; if (hipEventElapsedTime(&ms, h->ev_pre0, h->ev_pre1) == hipSuccess) h->envelope_ms = ms; }
     // the set bits, stream by stream, in block order
     edges.resize(ns);
     uint32_t n_found = 0;
@@ -533,6 +575,11 @@ struct DeviceEnv {
     {
         return ::run_jobs(h, d_iq, jobs, rpj, trace_cap, st, out) == LORA_HIP_OK ? 0 : -1;
     }
+    int run_jobs_begin(const std::vector<Job> &jobs, uint32_t rpj, uint32_t trace_cap, RunOut &out)
+    {
+        return ::run_jobs_begin(h, d_iq, jobs, rpj, trace_cap, st, out) == LORA_HIP_OK ? 0 : -1;
+    }
+    int run_jobs_end(RunOut &out) { return ::run_jobs_end(h, out) == LORA_HIP_OK ? 0 : -1; }
     void publish(const AttemptRec &r, StreamDesc &sd) { ::publish(h, r, sd); }
     void append_trace(const RunOut &out, uint32_t job, uint32_t cap, int64_t base) { ::append_trace(h, out, job, cap, base); }
     void count_jobs(uint32_t n) { h->timing.jobs += n; }
@@ -599,7 +646,11 @@ lora_hip_status lora_hip_create(const lora_hip_config_t *cfg, lora_hip_decoder_t
     const hipError_t es = hipSetDevice(h->device);
     if (es != hipSuccess) s = fail(nullptr, LORA_HIP_ERR_NO_DEVICE, "hipSetDevice(%d): %s", h->device, hipGetErrorString(es));
     if (s == LORA_HIP_OK) s = build_tables(h);
-    if (s == LORA_HIP_OK && (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess)) s = LORA_HIP_ERR_HIP;
+    if (s == LORA_HIP_OK && (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess || hipEventCreate(&h->ev_done) != hipSuccess ||
+                             hipEventCreate(&h->ev_pre0) != hipSuccess || hipEventCreate(&h->ev_pre1) != hipSuccess ||
+                             hipEventCreateWithFlags(&h->ev_dep, hipEventDisableTiming) != hipSuccess ||
+                             hipStreamCreateWithFlags(&h->pre_stream, hipStreamNonBlocking) != hipSuccess))
+        s = LORA_HIP_ERR_HIP;
     if (s != LORA_HIP_OK) { lora_hip_destroy(h); return s; }
     h->stream_cr = h->P.ctor_cr;
     h->batch_items = cfg->batch_items ? cfg->batch_items : std::max<size_t>(1u << 20, 64ull * h->P.sps);
@@ -623,8 +674,9 @@ void lora_hip_destroy(lora_hip_decoder_t *h)
     h->d_trace.release(); h->d_staging.release(); h->d_offsets.release(); h->d_bins.release();
     h->p_jobs.release(); h->p_res.release(); h->p_recs.release();
     h->d_balance.release(); h->d_env_streams.release(); h->d_env_E.release(); h->d_env_buf.release(); h->p_env_streams.release(); h->p_env_buf.release();
-    if (h->ev0) (void)hipEventDestroy(h->ev0);
-    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (hipEvent_t e : {h->ev0, h->ev1, h->ev_done, h->ev_pre0, h->ev_pre1, h->ev_dep})
+        if (e) (void)hipEventDestroy(e);
+    if (h->pre_stream) (void)hipStreamDestroy(h->pre_stream);
     delete h;
 }
 
@@ -655,21 +707,51 @@ lora_hip_status lora_hip_set_samp_rate(lora_hip_decoder_t *h, float samp_rate)
     return LORA_HIP_OK;
 }
 
-lora_hip_status lora_hip_decode_device(lora_hip_decoder_t *h, const void *d_iq, size_t total_items,
-                                       const uint64_t *stream_off, const uint64_t *stream_len, uint32_t n_streams,
-                                       void *hip_stream)
+lora_hip_status lora_hip_decode_device_begin(lora_hip_decoder_t *h, const void *d_iq, size_t total_items, const uint64_t *stream_off,
+                                             const uint64_t *stream_len, uint32_t n_streams, void *hip_stream, uint32_t flags)
 {
     if (!h || (!d_iq && total_items) || (n_streams && (!stream_off || !stream_len))) return LORA_HIP_ERR_ARG;
+    if (h->pass_open) return fail(h, LORA_HIP_ERR_ARG, "lora_hip_decode_device_begin: the previous pass has not been ended");
     HIP_TRY(h, hipSetDevice(h->device));
     h->timing = lora_hip_timing_t{};
-    std::vector<StreamDesc> sds(n_streams);
+    std::vector<StreamDesc> &sds = h->pass_streams;
+    sds.assign(n_streams, StreamDesc{});
     for (uint32_t i = 0; i < n_streams; i++) {
         if (stream_off[i] + stream_len[i] > total_items) return fail(h, LORA_HIP_ERR_ARG, "stream %u exceeds the buffer", i);
         sds[i].off = stream_off[i]; sds[i].len = stream_len[i]; sds[i].id = i;
         sds[i].cr_in = h->P.ctor_cr; sds[i].abs_base = 0;
         h->timing.items += stream_len[i];
     }
-    return decode_streams(h, (const float2 *)d_iq, sds, (hipStream_t)hip_stream);
+    h->pass_iq = (const float2 *)d_iq; h->pass_st = (hipStream_t)hip_stream;
+    h->iq_ready = (flags & LORA_HIP_BEGIN_IQ_READY) != 0u;
+    h->err.clear();
+    DeviceEnv env{h, h->pass_iq, h->pass_st};
+    const int rc = lora_hip::decode_begin(env, sds, h->pass);
+    h->iq_ready = false;
+    if (rc != 0) { h->pending.open = false; return h->err.empty() ? fail(h, LORA_HIP_ERR_INTERNAL, "scheduler failed") : LORA_HIP_ERR_HIP; }
+    h->pass_open = true;
+    return LORA_HIP_OK;
+}
+
+lora_hip_status lora_hip_decode_device_end(lora_hip_decoder_t *h)
+{
+    if (!h) return LORA_HIP_ERR_ARG;
+    if (!h->pass_open) return fail(h, LORA_HIP_ERR_ARG, "lora_hip_decode_device_end without a pass begun");
+    h->pass_open = false;
+    HIP_TRY(h, hipSetDevice(h->device));
+    h->err.clear();
+    DeviceEnv env{h, h->pass_iq, h->pass_st};
+    const int rc = lora_hip::decode_end(env, h->pass_streams, h->pass);
+    if (rc != 0) { h->pending.open = false; return h->err.empty() ? fail(h, LORA_HIP_ERR_INTERNAL, "scheduler failed") : LORA_HIP_ERR_HIP; }
+    return LORA_HIP_OK;
+}
+
+lora_hip_status lora_hip_decode_device(lora_hip_decoder_t *h, const void *d_iq, size_t total_items,
+                                       const uint64_t *stream_off, const uint64_t *stream_len, uint32_t n_streams,
+                                       void *hip_stream)
+{
+    const lora_hip_status s = lora_hip_decode_device_begin(h, d_iq, total_items, stream_off, stream_len, n_streams, hip_stream, 0u);
+    return s == LORA_HIP_OK ? lora_hip_decode_device_end(h) : s;
 }
 
 lora_hip_status lora_hip_gap_starts_device(lora_hip_decoder_t *h, const void *d_iq, size_t total_items, const uint64_t *stream_off,

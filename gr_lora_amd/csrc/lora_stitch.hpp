@@ -5,7 +5,8 @@
 // oracle's state machine -- so the scheduling logic is exercised by the CPU test-suite as well.
 //
 // Env must provide:  uint32_t sps(), ctor_cr(), segment_symbols(), resident_slots();  bool tracing(), implicit();
-//   int  run_jobs(const std::vector<Job> &, uint32_t recs_per_job, uint32_t trace_cap, RunOut &);   (0 = ok)
+//   int  run_jobs(const std::vector<Job> &, uint32_t recs_per_job, uint32_t trace_cap, RunOut &);   (0 = ok; launch and wait)
+//   int  run_jobs_begin(same) / run_jobs_end(RunOut &);   (the main launch of a pass, split: launch / wait and fetch)
 //   RunOut &run_out(int which);   (two reusable result holders)
 //   bool quiet_edges(const std::vector<StreamDesc> &, std::vector<std::vector<int64_t>> &);   (gap starts per stream, false = none)
 //   void publish(const AttemptRec &, StreamDesc &);   void append_trace(const RunOut &, uint32_t job, uint32_t cap, int64_t base);
@@ -223,12 +224,27 @@ inline bool plan_burst_segments(const std::vector<StreamDesc> &streams, const st
 // there on (the decoder state at header entry is position + d_phdr.cr), and the
 // job's remaining attempts are the true ones.  Anything else is re-run serially
 // from the true state.  The result is exactly the serial state machine's.
+struct Seg { uint32_t stream; int64_t b0, b1; };
+
+// What the first half of a pass (plan + main launch, decode_begin) hands to the second (decode_end: results, probes,
+// stitch).  The two halves exist so that a caller can put another pass's launch between them: while the device runs
+// one batch the host plans the next and stitches the previous.
+struct PassCtx {
+    std::vector<Seg> segs;
+    std::vector<size_t> first_seg;
+    std::vector<Job> jobs;
+    uint32_t rpj1 = 0, rpj2 = 8, trace_cap = 0;
+    bool segmenting = false, tracing = false, launched = false;
+    std::chrono::steady_clock::time_point tp_in, tp0;
+};
+
 template <class Env>
-int decode_streams(Env &env, std::vector<StreamDesc> &streams)
+int decode_begin(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
 {
     const uint32_t sps = env.sps();
     const bool tracing = env.tracing();
-    const auto tp_in = std::chrono::steady_clock::now();
+    ctx = PassCtx{};
+    ctx.tp_in = std::chrono::steady_clock::now();
     uint64_t total = 0;
     for (const StreamDesc &sd : streams) total += sd.len;
     // auto: as many segments as workgroups fit on the device at once (one wave of workgroups per launch;
@@ -239,6 +255,7 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
                                           : std::max<uint64_t>(64ull * sps, (total + want_jobs - 1) / want_jobs);
     if (seg < 16ull * sps) seg = 16ull * sps;
     const bool segmenting = !tracing && !env.implicit();
+    ctx.segmenting = segmenting; ctx.tracing = tracing;
 
     // auto mode on a batch worth cutting up: look for the gaps between bursts and plan the cuts around them
     std::vector<std::vector<int64_t>> cuts;
@@ -249,9 +266,9 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
         if (env.quiet_edges(streams, edges)) planned = plan_burst_segments(streams, edges, sps, slots, seg, cuts);
     }
 
-    struct Seg { uint32_t stream; int64_t b0, b1; };
-    std::vector<Seg> segs;
-    std::vector<size_t> first_seg(streams.size() + 1, 0);
+    std::vector<Seg> &segs = ctx.segs;
+    std::vector<size_t> &first_seg = ctx.first_seg;
+    first_seg.assign(streams.size() + 1, 0);
     for (size_t i = 0; i < streams.size(); i++) {
         first_seg[i] = segs.size();
         StreamDesc &sd = streams[i];
@@ -272,7 +289,8 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
     env.note_plan(planned, segs.size());
 
     // ---- round 1: every segment speculatively
-    std::vector<Job> jobs(segs.size());
+    std::vector<Job> &jobs = ctx.jobs;
+    jobs.assign(segs.size(), Job{});
     uint64_t max_span = 0;
     for (size_t k = 0; k < segs.size(); k++) {
         const StreamDesc &sd = streams[segs[k].stream];
@@ -286,14 +304,32 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
         j.probe_limit = (segmenting && has_next && !no_tail) ? std::min<int64_t>((int64_t)sd.len, segs[k + 1].b1 + 16ll * sps) : 0;
         max_span = std::max<uint64_t>(max_span, (uint64_t)(segs[k].b1 - segs[k].b0));
     }
-    const uint32_t rpj2 = 8;
-    const uint32_t rpj1 = recs_for(max_span, sps) + (segmenting ? rpj2 : 0u);
-    const uint32_t trace_cap = tracing ? (uint32_t)std::min<uint64_t>(2ull * (max_span / sps) + 64ull, 1ull << 22) : 0u;
-    RunOut &R1 = env.run_out(0); // (kept by the environment between calls)
+    ctx.rpj1 = recs_for(max_span, sps) + (segmenting ? ctx.rpj2 : 0u);
+    ctx.trace_cap = tracing ? (uint32_t)std::min<uint64_t>(2ull * (max_span / sps) + 64ull, 1ull << 22) : 0u;
     env.count_jobs((uint32_t)jobs.size());
+    ctx.tp0 = std::chrono::steady_clock::now();
+    const int s = env.run_jobs_begin(jobs, ctx.rpj1, ctx.trace_cap, env.run_out(0)); // (result holders are kept by the environment between calls)
+    if (s != 0) return s;
+    ctx.launched = true;
+    return 0;
+}
+
+template <class Env>
+int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
+{
+    if (!ctx.launched) return 0; // nothing to decode
+    ctx.launched = false;
+    const uint32_t sps = env.sps();
+    const bool tracing = ctx.tracing, segmenting = ctx.segmenting;
+    const std::vector<Seg> &segs = ctx.segs;
+    const std::vector<size_t> &first_seg = ctx.first_seg;
+    const std::vector<Job> &jobs = ctx.jobs;
+    const uint32_t rpj1 = ctx.rpj1, rpj2 = ctx.rpj2, trace_cap = ctx.trace_cap;
+    const auto tp_in = ctx.tp_in, tp0 = ctx.tp0;
+    (void)segmenting;
+    RunOut &R1 = env.run_out(0);
     static const bool dbg_t = getenv("LORA_HIP_DEBUG") != nullptr;
-    const auto tp0 = std::chrono::steady_clock::now();
-    int s = env.run_jobs(jobs, rpj1, trace_cap, R1);
+    int s = env.run_jobs_end(R1);
     if (s != 0) return s;
     const auto tp1 = std::chrono::steady_clock::now();
     static const bool dbg_jobs = getenv("LORA_HIP_DEBUG_JOBS") != nullptr;
@@ -527,6 +563,16 @@ int decode_streams(Env &env, std::vector<StreamDesc> &streams)
                 ms(tp_in, tp0), ms(tp0, tp1), jobs.size(), rpj1, ms(tp1, tp2), pjobs.size(), probes.size() - pjobs.size(), ms(tp2, tp3), env.walker_ms());
     }
     return 0;
+}
+
+// One pass, start to finish (the synchronous entry points and the CPU simulation).
+template <class Env>
+int decode_streams(Env &env, std::vector<StreamDesc> &streams)
+{
+    PassCtx ctx;
+    const int s = decode_begin(env, streams, ctx);
+    if (s != 0) return s;
+    return decode_end(env, streams, ctx);
 }
 
 

@@ -134,6 +134,20 @@ lora_hip_status lora_hip_decode_device(lora_hip_decoder_t *h, const void *d_iq, 
                                        const uint64_t *stream_off, const uint64_t *stream_len,
                                        uint32_t n_streams, void *hip_stream);
 
+/* The same pass in two halves, so that a caller can overlap passes: _begin plans the pass and launches its main kernel on
+ * hip_stream, then returns; _end waits for that kernel (an event, not the stream), runs the rare follow-up launches, stitches
+ * and queues the frames.  One pass per handle at a time; with two handles alternating on ONE stream the device runs
+ * pass k+1's kernel right behind pass k's while the host stitches pass k and plans pass k+2 (bench.py does this).
+ * lora_hip_decode_device(...) == _begin(..., 0) + _end().  flags: LORA_HIP_BEGIN_IQ_READY = the IQ is complete in memory
+ * now, whatever hip_stream still has queued (e.g. the previous pass's kernel): the planner's small envelope pre-pass, which
+ * runs on a stream of the handle's own, then does not wait for hip_stream.  Without it the pre-pass is ordered after
+ * everything queued on hip_stream so far.                                                                          */
+#define LORA_HIP_BEGIN_IQ_READY 1u
+lora_hip_status lora_hip_decode_device_begin(lora_hip_decoder_t *h, const void *d_iq, size_t total_items,
+                                             const uint64_t *stream_off, const uint64_t *stream_len,
+                                             uint32_t n_streams, void *hip_stream, uint32_t flags);
+lora_hip_status lora_hip_decode_device_end(lora_hip_decoder_t *h);
+
 /* Diagnostics: where the segment planner's energy-envelope pre-pass sees the streams go quiet (the start of every gap
  * between bursts; lora_hip_decode_device cuts its speculation segments there when the traffic is dense enough).
  * counts[i] = gap starts found in stream i; their item positions, relative to the stream and ascending, are packed stream

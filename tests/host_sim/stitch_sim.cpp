@@ -57,6 +57,8 @@ struct SimEnv {
         return true;
     }
     void note_plan(bool ok, size_t) { planned += ok ? 1u : 0u; }
+    int run_jobs_begin(const std::vector<Job> &jobs, uint32_t rpj, uint32_t tc, RunOut &out) { return run_jobs(jobs, rpj, tc, out); } // (no device: runs at once)
+    int run_jobs_end(RunOut &) { return 0; }
     int run_jobs(const std::vector<Job> &jobs, uint32_t rpj, uint32_t, RunOut &out)
     {
         out.rpj = rpj; out.cap = rpj;

@@ -369,3 +369,45 @@ def test_envelope_gap_starts_vs_numpy(torch_cuda, sf, snr_db):
         assert got[s].tolist() == sorted(g)
         total += certain.size
     assert total >= 12   # gaps of about two symbols and more are found (shorter ones need not leave a quiet block)
+
+
+@pytest.mark.gpu
+def test_pipelined_passes_equal_sequential(torch_cuda, oracle_mod):
+    """lora_hip_decode_device_begin/_end: two handles alternating on one stream, the next pass begun before the previous
+    one is ended (with and without IQ_READY), give exactly the frames of the plain synchronous call; misuse is refused."""
+    from gr_lora_amd import capi
+    cfg = synth.TxConfig(sf=7, cr=4)
+    rng = np.random.default_rng(91)
+    batches = []
+    for b in range(4):
+        pieces, offs, lens, off = [], [], [], 0
+        for s in range(4):
+            payloads = [bytes(rng.integers(0, 256, int(rng.integers(2, 40)), dtype=np.uint8)) for _ in range(40 + 10 * b)]
+            iq = synth.build_stream(payloads, cfg, rng=rng, gap_symbols=(1.0, 6.0)).iq
+            pieces.append(iq); offs.append(off); lens.append(iq.size); off += iq.size
+        allq = np.concatenate(pieces)
+        batches.append((allq, _to_dev(torch_cuda, allq), offs, lens))
+    ref = []
+    h = capi.Handle(sf=7, cr=4, demod=capi.DEMOD_FFT_COMPAT)
+    for allq, dev, offs, lens in batches:
+        h.decode_device(dev.data_ptr(), allq.size, offs, lens, 0)
+        ref.append([(g, i.stream, i.header_pos) for g, i in h.drain()])
+    assert all(len(r) >= 150 for r in ref)
+    with pytest.raises(Exception):
+        h.decode_device_end()                                  # nothing begun
+    for iq_ready in (False, True):
+        hs = [h, capi.Handle(sf=7, cr=4, demod=capi.DEMOD_FFT_COMPAT)]
+        got = []
+        a0 = batches[0]
+        hs[0].decode_device_begin(a0[1].data_ptr(), a0[0].size, a0[2], a0[3], 0, iq_ready=iq_ready)
+        with pytest.raises(Exception):
+            hs[0].decode_device_begin(a0[1].data_ptr(), a0[0].size, a0[2], a0[3], 0)   # one pass per handle at a time
+        for k in range(len(batches)):
+            if k + 1 < len(batches):
+                a = batches[k + 1]
+                hs[(k + 1) % 2].decode_device_begin(a[1].data_ptr(), a[0].size, a[2], a[3], 0, iq_ready=iq_ready)
+            hs[k % 2].decode_device_end()
+            got.append([(g, i.stream, i.header_pos) for g, i in hs[k % 2].drain()])
+        hs[1].close()
+        assert got == ref
+    h.close()
