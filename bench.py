@@ -92,8 +92,8 @@ def cpu_baseline(cfg, iq, offs, lens, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--sf", type=int, default=7)
     ap.add_argument("--cr", type=int, default=4)
     ap.add_argument("--packets", type=int, default=1024)
@@ -200,7 +200,7 @@ def main():
         # WRITE_SIZE passes, gfx950 FETCH x2 correction as MI355X_MICROARCH.md prescribes); null otherwise
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_e_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json")))
             if pmc.get("workload_items") == n_items and args.demod != 0:
                 traffic = int(pmc["hbm_bytes_per_pass_corrected"])
         except (OSError, ValueError, KeyError):
@@ -219,7 +219,7 @@ def main():
                        "pipeline_depth": depth},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "traffic_unit": "HBM bytes per pass (PMC, profiles/r01_e_pmc_traffic.json)",
+                         "traffic_unit": "HBM bytes per pass (PMC, profiles/r01_f_pmc_traffic.json)",
                          "kernel": kname, "kernel_ms_per_pass": round(kernel_ms, 4),
                          "launches_per_pass": launches / max(1, args.steps),
                          "algorithmic_bytes_per_pass": 8 * n_items},
