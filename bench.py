@@ -100,8 +100,9 @@ def main():
     ap.add_argument("--payload", type=int, default=32)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("LORA_BENCH_STREAMS", "8")))
     ap.add_argument("--demod", type=int, default=2, help="0 grad, 1 fft, 2 fft_compat")
-    ap.add_argument("--depth", type=int, default=2, help="passes in flight: 2 = while the device runs step k+1 the host stitches step k "
-                    "(two decoder handles alternating on one stream; kernels never overlap), 1 = strictly one after the other")
+    ap.add_argument("--depth", type=int, default=3, help="pipeline depth: 1 = strictly one pass after the other; 2 = while the device runs "
+                    "step k+1 the host stitches step k (decoder handles alternating on one stream; walker kernels never overlap); "
+                    "3 = also the envelope pre-pass of step k+2 is issued ahead (it runs in the tail of step k's walker)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -123,7 +124,7 @@ def main():
     cfg, iq, offs, lens, expect = make_workload(args.sf, args.cr, args.packets, args.payload, args.streams, seed=2 + 1000 * rank)
     n_items = int(iq.size)
     d_iq = torch.from_numpy(iq.view(np.float32)).to(dev)
-    depth = max(1, min(2, args.depth))
+    depth = max(1, min(3, args.depth))
     hs = [capi.Handle(samp_rate=cfg.samp_rate, bandwidth=cfg.bw, sf=cfg.sf, cr=4, crc=True, reduced_rate=cfg.reduced_rate,
                       device=local_rank, demod=args.demod) for _ in range(depth)]
     h = hs[0]
@@ -134,6 +135,9 @@ def main():
     # the same HIP stream, so the device goes from one walker kernel straight to the next while the host stitches.
     def begin(k):   # the IQ is resident and unchanged: the envelope pre-pass need not wait for the stream (IQ_READY)
         hs[k % depth].decode_device_begin(d_iq.data_ptr(), n_items, offs, lens, stream, iq_ready=True)
+
+    def prepass(k):
+        hs[k % depth].decode_device_prepass(d_iq.data_ptr(), n_items, offs, lens, stream, iq_ready=True)
 
     def finish(k):
         hk = hs[k % depth]
@@ -147,7 +151,11 @@ def main():
         if n_steps <= 0:
             return wk, ln
         begin(0)
+        if depth > 2 and n_steps > 1:
+            prepass(1)
         for k in range(n_steps):
+            if depth > 2 and k + 2 < n_steps:
+                prepass(k + 2)
             if depth > 1 and k + 1 < n_steps:
                 begin(k + 1)
             _s, _c, tm = finish(k)

@@ -21,7 +21,7 @@ EXPORTS = [
     "lora_hip_abi_version", "lora_hip_strerror", "lora_hip_last_error", "lora_hip_create", "lora_hip_destroy",
     "lora_hip_get_geometry", "lora_hip_set_sf", "lora_hip_set_samp_rate", "lora_hip_work", "lora_hip_flush",
     "lora_hip_decode_device", "lora_hip_frames_available", "lora_hip_poll_frame", "lora_hip_drain_frames", "lora_hip_drain_slots", "lora_hip_demod_symbols_device", "lora_hip_demod_symbols_ex_device",
-    "lora_hip_last_timing", "lora_hip_last_plan", "lora_hip_gap_starts_device", "lora_hip_decode_device_begin", "lora_hip_decode_device_end", "lora_hip_trace", "lora_hip_trace_clear",
+    "lora_hip_last_timing", "lora_hip_last_plan", "lora_hip_gap_starts_device", "lora_hip_decode_device_begin", "lora_hip_decode_device_end", "lora_hip_decode_device_prepass", "lora_hip_trace", "lora_hip_trace_clear",
 ]
 
 
@@ -113,6 +113,7 @@ def load():
     L.lora_hip_last_plan.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.lora_hip_decode_device_begin.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_uint32, vp, C.c_uint32]
     L.lora_hip_decode_device_end.argtypes = [vp]
+    L.lora_hip_decode_device_prepass.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_uint32, vp, C.c_uint32]
     L.lora_hip_gap_starts_device.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_uint32, vp, C.c_size_t, vp, vp]
     L.lora_hip_trace.restype = C.c_size_t
     L.lora_hip_trace.argtypes = [vp, C.POINTER(C.POINTER(Step))]
@@ -187,6 +188,12 @@ class Handle:
         o = np.ascontiguousarray(offs, dtype=np.uint64)
         l = np.ascontiguousarray(lens, dtype=np.uint64)
         self._check(self.L.lora_hip_decode_device_begin(self.h, dev_ptr, total_items, o.ctypes.data, l.ctypes.data, o.size, stream, 1 if iq_ready else 0))
+
+    def decode_device_prepass(self, dev_ptr: int, total_items: int, offs: Sequence[int], lens: Sequence[int], stream: int = 0, iq_ready: bool = False):
+        """Issues the envelope pre-pass of the pass that will be begun next on this handle (lora_hip_decode_device_prepass)."""
+        o = np.ascontiguousarray(offs, dtype=np.uint64)
+        l = np.ascontiguousarray(lens, dtype=np.uint64)
+        self._check(self.L.lora_hip_decode_device_prepass(self.h, dev_ptr, total_items, o.ctypes.data, l.ctypes.data, o.size, stream, 1 if iq_ready else 0))
 
     def decode_device_end(self):
         self._check(self.L.lora_hip_decode_device_end(self.h))

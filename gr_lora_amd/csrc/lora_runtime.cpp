@@ -132,6 +132,12 @@ struct lora_hip_decoder {
     const float2 *pass_iq = nullptr;
     hipStream_t pass_st = nullptr;
     bool pass_open = false, iq_ready = false;
+    // an envelope pre-pass between quiet_edges_enqueue and quiet_edges_collect
+    bool pre_issued = false;
+    const float2 *pre_iq = nullptr;
+    uint64_t pre_sig = 0;
+    uint32_t pre_ns = 0;
+    std::chrono::steady_clock::time_point pre_hq0;
     // outputs
     FrameQueue frames;
     PinnedBuf<Job> p_jobs;             // staging for run_jobs: jobs up, results and the first attempt records down
@@ -488,11 +494,22 @@ void append_trace(lora_hip_decoder *h, const RunOut &out, uint32_t job_index, ui
 }
 
 // Gap starts of every stream (item positions, ascending) from the energy envelope; see envelope_kernel.
-lora_hip_status quiet_edges(lora_hip_decoder *h, const float2 *d_iq, const std::vector<StreamDesc> &streams, hipStream_t st,
-                            std::vector<std::vector<int64_t>> &edges)
+uint64_t streams_signature(const std::vector<StreamDesc> &streams)
+{ // FNV-1a over (offset, length) of every stream: tells whether a pre-pass issued ahead belongs to the pass now begun
+    uint64_t x = 1469598103934665603ull;
+    for (const StreamDesc &sd : streams)
+        for (uint64_t v : {sd.off, sd.len}) { x ^= v; x *= 1099511628211ull; }
+    return x ^ streams.size();
+}
+
+// ... in two steps: the kernels are put on the handle's pre-pass stream (quiet_edges_enqueue), the gap list is read once they
+// are done (quiet_edges_collect).  A caller that pipelines passes issues the first step a pass ahead
+// (lora_hip_decode_device_prepass): the kernels then run in the tail of the walker launch before the previous one.
+lora_hip_status quiet_edges_enqueue(lora_hip_decoder *h, const float2 *d_iq, const std::vector<StreamDesc> &streams, hipStream_t st)
 {
     const uint32_t sps = h->P.sps, ns = (uint32_t)streams.size();
-    const auto hq0 = std::chrono::steady_clock::now();
+    h->pre_issued = false;
+    h->pre_hq0 = std::chrono::steady_clock::now();
     HIP_TRY(h, h->p_env_streams.reserve(ns));
     uint64_t nb = 0;
     for (uint32_t i = 0; i < ns; i++) {
@@ -522,8 +539,18 @@ lora_hip_status quiet_edges(lora_hip_decoder *h, const float2 *d_iq, const std::
         return fail(h, LORA_HIP_ERR_HIP, "envelope launch failed: %s", hipGetErrorString(hipGetLastError()));
     if (dbg) HIP_TRY(h, hipEventRecord(h->ev_pre1, ps));
     if (!direct) HIP_TRY(h, hipMemcpyAsync(h->p_env_buf.p, h->d_env_buf.p, words * 8u, hipMemcpyDeviceToHost, ps));
-    const auto hq1 = std::chrono::steady_clock::now();
-    HIP_TRY(h, hipStreamSynchronize(ps));
+    h->pre_issued = true; h->pre_iq = d_iq; h->pre_sig = streams_signature(streams); h->pre_ns = ns;
+    return LORA_HIP_OK;
+}
+
+lora_hip_status quiet_edges_collect(lora_hip_decoder *h, std::vector<std::vector<int64_t>> &edges)
+{
+    if (!h->pre_issued) return LORA_HIP_ERR_ARG;
+    h->pre_issued = false;
+    const uint32_t sps = h->P.sps, ns = h->pre_ns;
+    static const bool dbg = getenv("LORA_HIP_DEBUG") != nullptr;
+    const auto hq0 = h->pre_hq0, hq1 = std::chrono::steady_clock::now();
+    HIP_TRY(h, hipStreamSynchronize(h->pre_stream));
     const auto hq2 = std::chrono::steady_clock::now();
     if (dbg) { float ms = 0; if (hipEventElapsedTime(&ms, h->ev_pre0, h->ev_pre1) == hipSuccess) h->envelope_ms = ms; }
     // the set bits, stream by stream, in block order
@@ -549,6 +576,18 @@ lora_hip_status quiet_edges(lora_hip_decoder *h, const float2 *d_iq, const std::
         fprintf(stderr, "[lora_hip] envelope host: enqueue %.0f us, wait %.0f us, sort %.0f us (%u edges)\n", us(hq0, hq1), us(hq1, hq2), us(hq2, std::chrono::steady_clock::now()), n_found);
     }
     return LORA_HIP_OK;
+}
+
+// (a pre-pass issued ahead for exactly these streams is taken up; anything else is issued now)
+lora_hip_status quiet_edges(lora_hip_decoder *h, const float2 *d_iq, const std::vector<StreamDesc> &streams, hipStream_t st,
+                            std::vector<std::vector<int64_t>> &edges)
+{
+    if (!(h->pre_issued && h->pre_iq == d_iq && h->pre_sig == streams_signature(streams))) {
+        if (h->pre_issued) { (void)hipStreamSynchronize(h->pre_stream); h->pre_issued = false; } // stale: let it finish before its buffers are reused
+        const lora_hip_status s = quiet_edges_enqueue(h, d_iq, streams, st);
+        if (s != LORA_HIP_OK) return s;
+    }
+    return quiet_edges_collect(h, edges);
 }
 
 // The device environment of the scheduler (lora_stitch.hpp): jobs are run by the walker kernels.
@@ -731,6 +770,27 @@ lora_hip_status lora_hip_decode_device_begin(lora_hip_decoder_t *h, const void *
     if (rc != 0) { h->pending.open = false; return h->err.empty() ? fail(h, LORA_HIP_ERR_INTERNAL, "scheduler failed") : LORA_HIP_ERR_HIP; }
     h->pass_open = true;
     return LORA_HIP_OK;
+}
+
+lora_hip_status lora_hip_decode_device_prepass(lora_hip_decoder_t *h, const void *d_iq, size_t total_items, const uint64_t *stream_off,
+                                               const uint64_t *stream_len, uint32_t n_streams, void *hip_stream, uint32_t flags)
+{
+    if (!h || !d_iq || !n_streams || !stream_off || !stream_len) return LORA_HIP_ERR_ARG;
+    if (h->pass_open) return fail(h, LORA_HIP_ERR_ARG, "lora_hip_decode_device_prepass: a pass is open on this handle");
+    HIP_TRY(h, hipSetDevice(h->device));
+    // only where decode_begin would plan around the bursts (auto segment length, explicit header, no tracing); harmless otherwise
+    if (h->cfg.segment_symbols != 0 || h->P.implicit || (h->cfg.flags & LORA_HIP_FLAG_TRACE)) return LORA_HIP_OK;
+    std::vector<StreamDesc> sds(n_streams);
+    for (uint32_t i = 0; i < n_streams; i++) {
+        if (stream_off[i] + stream_len[i] > total_items) return fail(h, LORA_HIP_ERR_ARG, "stream %u exceeds the buffer", i);
+        sds[i].off = stream_off[i]; sds[i].len = stream_len[i]; sds[i].id = i;
+    }
+    if (h->pre_issued) { HIP_TRY(h, hipStreamSynchronize(h->pre_stream)); h->pre_issued = false; }
+    h->iq_ready = (flags & LORA_HIP_BEGIN_IQ_READY) != 0u;
+    h->err.clear();
+    const lora_hip_status s = quiet_edges_enqueue(h, (const float2 *)d_iq, sds, (hipStream_t)hip_stream);
+    h->iq_ready = false;
+    return (s == LORA_HIP_OK || h->err.empty()) ? LORA_HIP_OK : s; // streams without an envelope simply get none
 }
 
 lora_hip_status lora_hip_decode_device_end(lora_hip_decoder_t *h)

@@ -147,6 +147,13 @@ lora_hip_status lora_hip_decode_device_begin(lora_hip_decoder_t *h, const void *
                                              const uint64_t *stream_off, const uint64_t *stream_len,
                                              uint32_t n_streams, void *hip_stream, uint32_t flags);
 lora_hip_status lora_hip_decode_device_end(lora_hip_decoder_t *h);
+/* Optional third stage, one pass further ahead: issues the envelope pre-pass of the pass that will be begun NEXT on this
+ * handle (same d_iq and streams; anything else is simply issued again by _begin) and returns without waiting.  Issued
+ * while an earlier pass's kernel occupies the device, it runs in that kernel's tail, and _begin finds the gap list ready
+ * (bench.py --depth 3: prepass(k+2), begin(k+1), end(k) with three handles).  Same flags as _begin.                     */
+lora_hip_status lora_hip_decode_device_prepass(lora_hip_decoder_t *h, const void *d_iq, size_t total_items,
+                                               const uint64_t *stream_off, const uint64_t *stream_len,
+                                               uint32_t n_streams, void *hip_stream, uint32_t flags);
 
 /* Diagnostics: where the segment planner's energy-envelope pre-pass sees the streams go quiet (the start of every gap
  * between bursts; lora_hip_decode_device cuts its speculation segments there when the traffic is dense enough).

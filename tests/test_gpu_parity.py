@@ -373,8 +373,9 @@ def test_envelope_gap_starts_vs_numpy(torch_cuda, sf, snr_db):
 
 @pytest.mark.gpu
 def test_pipelined_passes_equal_sequential(torch_cuda, oracle_mod):
-    """lora_hip_decode_device_begin/_end: two handles alternating on one stream, the next pass begun before the previous
-    one is ended (with and without IQ_READY), give exactly the frames of the plain synchronous call; misuse is refused."""
+    """lora_hip_decode_device_begin/_end (+ _prepass): two handles alternating on one stream, the next pass begun before the
+    previous one is ended and its envelope pre-pass issued a pass ahead (with and without IQ_READY), give exactly the frames
+    of the plain synchronous call; misuse is refused."""
     from gr_lora_amd import capi
     cfg = synth.TxConfig(sf=7, cr=4)
     rng = np.random.default_rng(91)
@@ -408,6 +409,9 @@ def test_pipelined_passes_equal_sequential(torch_cuda, oracle_mod):
                 hs[(k + 1) % 2].decode_device_begin(a[1].data_ptr(), a[0].size, a[2], a[3], 0, iq_ready=iq_ready)
             hs[k % 2].decode_device_end()
             got.append([(g, i.stream, i.header_pos) for g, i in hs[k % 2].drain()])
+            if k + 2 < len(batches):   # third stage: the pre-pass of the pass this handle begins next, issued ahead ...
+                a = batches[k + 2] if k != 1 else batches[0]   # ... once for other streams than the ones then begun (it is redone)
+                hs[k % 2].decode_device_prepass(a[1].data_ptr(), a[0].size, a[2], a[3], 0, iq_ready=iq_ready)
         hs[1].close()
         assert got == ref
     h.close()
