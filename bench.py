@@ -129,6 +129,7 @@ def main():
                       device=local_rank, demod=args.demod) for _ in range(depth)]
     h = hs[0]
     stream = torch.cuda.current_stream().cuda_stream
+    gather_stream = torch.cuda.Stream(device=dev) if world > 1 else None
 
     # One step = one full pass over the batch.  With depth 2 the passes are software-pipelined the way a streaming receiver
     # runs them: the plan + launch of step k+1 (begin) is issued before the results of step k are collected (finish), on
@@ -143,7 +144,11 @@ def main():
         hk = hs[k % depth]
         hk.decode_device_end()
         mine = hk.drain_slots(gather.SLOT_BYTES)             # frames straight into the exchange layout
-        slots, counts = gather.gather_slots(mine, dev)       # RCCL all_gather of the frames when N > 1
+        if gather_stream is not None:                        # RCCL all_gather of the frames when N > 1, on a stream of its own:
+            with torch.cuda.stream(gather_stream):           # on the decode stream it would queue behind the next step's kernel
+                slots, counts = gather.gather_slots(mine, dev)
+        else:
+            slots, counts = gather.gather_slots(mine, dev)
         return slots, counts, hk.timing()
 
     def run(n_steps):
