@@ -141,3 +141,25 @@ extern "C" int stitch_sim_decode(const float *iq, size_t n_items, int sf, int ct
     stats[0] = env.n_jobs; stats[1] = env.n_probes; stats[2] = env.n_slow; stats[3] = sds[0].incomplete ? 1u : 0u; stats[4] = env.n_tails; stats[5] = env.planned;
     return n;
 }
+
+// plan_burst_segments on its own: edges[] holds the gap starts of all streams back to back (n_edges[i] of them for stream i);
+// cuts_out receives the cuts the same way, n_cuts[i] per stream.  Returns 1 when a burst-aware plan was made, 0 for the fixed grid.
+extern "C" int stitch_sim_plan(const long long *lens, const int *n_edges, const long long *edges, int n_streams, uint32_t sps, uint32_t slots,
+                               unsigned long long nominal, long long *cuts_out, int cap, int *n_cuts)
+{
+    std::vector<StreamDesc> sds(n_streams);
+    std::vector<std::vector<int64_t>> e(n_streams), cuts;
+    size_t k = 0;
+    for (int i = 0; i < n_streams; i++) {
+        sds[i].off = 0; sds[i].len = (uint64_t)lens[i]; sds[i].id = (uint32_t)i;
+        for (int q = 0; q < n_edges[i]; q++) e[i].push_back(edges[k++]);
+    }
+    const bool ok = plan_burst_segments(sds, e, sps, slots, nominal, cuts);
+    int used = 0;
+    for (int i = 0; i < n_streams; i++) {
+        n_cuts[i] = ok ? (int)cuts[i].size() : 0;
+        if (!ok) continue;
+        for (int64_t c : cuts[i]) { if (used >= cap) return -1; cuts_out[used++] = c; }
+    }
+    return ok ? 1 : 0;
+}

@@ -131,3 +131,61 @@ def test_gradient_mode_and_truncated_stream(sim, oracle_mod):
         got, gpos, stats = sim(cut, 7, demod=demod, seg=33)
         assert got == want and gpos == wpos and len(got) == 9
         assert stats["incomplete"] == 1
+
+
+def _plan(sim_lib, lens, edges, sps, slots, nominal):
+    import ctypes as C
+    L = C.CDLL(SIM_LIB)
+    ne = np.asarray([len(e) for e in edges], dtype=np.int32)
+    flat = np.asarray([x for e in edges for x in e], dtype=np.int64)
+    ln = np.asarray(lens, dtype=np.int64)
+    out = np.zeros(1 << 16, dtype=np.int64)
+    nc = np.zeros(len(lens), dtype=np.int32)
+    L.stitch_sim_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_ulonglong, C.c_void_p, C.c_int, C.c_void_p]
+    rc = L.stitch_sim_plan(ln.ctypes.data, ne.ctypes.data, flat.ctypes.data, len(lens), sps, slots, nominal, out.ctypes.data, out.size, nc.ctypes.data)
+    cuts, k = [], 0
+    for n in nc:
+        cuts.append(out[k:k + int(n)].tolist()); k += int(n)
+    return rc, cuts
+
+
+def test_burst_plan_properties(sim):
+    """plan_burst_segments by its contract: cuts ascending, strictly inside the stream, at gap starts (or on the grid inside
+    gap-less stretches), at most `slots` segments in all; equal bursts -> equal packets per job; too few bursts -> fixed grid."""
+    sps = 1024
+    rng = np.random.default_rng(3)
+    # 1. equal bursts, the bench shape: 8 streams x 128 bursts, 512 slots -> 2 bursts per job
+    period = 108 * sps
+    lens = [128 * period + 5 * sps] * 8
+    edges = [[(k + 1) * period - 4 * sps for k in range(128)] for _ in range(8)]
+    rc, cuts = _plan(sim, lens, edges, sps, 512, 225 * sps)
+    assert rc == 1 and sum(len(c) + 1 for c in cuts) <= 512
+    for c, e in zip(cuts, edges):
+        assert c == sorted(set(c)) and set(c) <= set(e) and 0 < c[0] and c[-1] < lens[0]
+        assert all((e.index(b) - e.index(a)) == 2 for a, b in zip(c, c[1:]))     # two bursts between consecutive cuts
+    # 2. ragged bursts and stream lengths: invariants only
+    lens, edges = [], []
+    for s in range(5):
+        n = int(rng.integers(40, 400))
+        gaps = rng.integers(30, 400, n) * sps
+        e = np.cumsum(gaps).tolist()
+        edges.append([int(x) for x in e]); lens.append(int(e[-1] + int(rng.integers(9, 50)) * sps))
+    total = sum(lens)
+    for slots in (64, 200, 512):
+        nominal = max(64 * sps, total // slots)
+        rc, cuts = _plan(sim, lens, edges, sps, slots, nominal)
+        if sum(len(e) for e in edges) < slots:
+            assert rc == 0
+            continue
+        assert rc == 1 and sum(len(c) + 1 for c in cuts) <= slots
+        for c, e, ln in zip(cuts, edges, lens):
+            assert c == sorted(set(c)) and all(0 < x < ln for x in c)
+            prev = 0
+            for x in c + [ln]:
+                assert x in e or x == ln or (x - prev) <= 3 * nominal   # a cut off the gap list only subdivides an over-long stretch
+                prev = x
+    # 3. a stretch without gaps is subdivided on the grid
+    lens = [4000 * sps]
+    edges = [[100 * sps * k for k in range(1, 11)] + [3990 * sps]]
+    rc, cuts = _plan(sim, lens, edges, sps, 16, 200 * sps)
+    assert rc == 1 and max(b - a for a, b in zip([0] + cuts[0], cuts[0] + lens)) <= 3 * 200 * sps
