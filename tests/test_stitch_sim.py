@@ -186,6 +186,6 @@ def test_burst_plan_properties(sim):
                 prev = x
     # 3. a stretch without gaps is subdivided on the grid
     lens = [4000 * sps]
-    edges = [[100 * sps * k for k in range(1, 11)] + [3990 * sps]]
+    edges = [[50 * sps * k for k in range(1, 21)] + [3990 * sps]]
     rc, cuts = _plan(sim, lens, edges, sps, 16, 200 * sps)
     assert rc == 1 and max(b - a for a, b in zip([0] + cuts[0], cuts[0] + lens)) <= 3 * 200 * sps
