@@ -1,0 +1,161 @@
+"""the GNU Radio block shim (shim/gnuradio/decoder_impl.{h,cc}) compiled, unchanged, against a small
+stand-in for the GNU Radio runtime (tests/mock_gnuradio/: sync_block, io_signature, pmt and the block's public header) and
+linked with liblora_hip.so.  On a GPU box a scheduler loop feeds it the known-answer capture the way GNU Radio would
+(multiples of 2 * samples-per-symbol items, consume_each honoured) and reads the frames off the "frames" message port."""
+import os
+import subprocess
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+HARNESS = textwrap.dedent(r'''
+    #include <cstdio>
+    #include <fstream>
+    #include <iterator>
+    #include <vector>
+    #include <lora/decoder.h>
+    int main(int argc, char **argv) {
+        if (argc < 2) return 2;
+        std::ifstream f(argv[1], std::ios::binary);
+        std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        const gr_complex *iq = reinterpret_cast<const gr_complex *>(raw.data());
+        const long long n = (long long)(raw.size() / sizeof(gr_complex));
+        gr::lora::decoder::sptr blk = gr::lora::decoder::make(1e6f, 125000, 7, false, 4, true, false, false);
+        if (blk->mock_name != "decoder" || blk->mock_in->item_size != (int)sizeof(gr_complex) || blk->mock_out->max_streams != 0) return 3;
+        if (blk->mock_ports.size() != 2 || blk->mock_ports[0] != "frames" || blk->mock_ports[1] != "control") return 4;
+        const int m = blk->mock_output_multiple;          // 2 * samples per symbol (decoder_impl.cc:91)
+        if (m != 2 * 1024) return 5;
+        long long pos = 0;                                  // the scheduler: offers multiples of m, advances by what was consumed
+        while (n - pos >= m) {
+            int offer = (int)(((n - pos < 16 * m ? n - pos : 16 * m) / m) * m);
+            gr_vector_const_void_star in{iq + pos};
+            gr_vector_void_star out;
+            const long long before = blk->mock_consumed;
+            if (blk->work(offer, in, out) != 0) return 6;  // the block consumes by hand and returns 0 (:902)
+            if (blk->mock_consumed == before) break;
+            pos += blk->mock_consumed - before;
+        }
+        blk->stop();
+        for (auto &m2 : blk->mock_published) {
+            if (m2.first != "frames") return 7;
+            const unsigned char *b = static_cast<const unsigned char *>(pmt::blob_data(m2.second));
+            for (size_t i = 15; i < pmt::blob_length(m2.second); i++) std::printf("%02x", b[i]);   // after the 15-byte loratap header
+            std::printf("\n");
+        }
+        return 0;
+    }
+''')
+
+
+def _build(tmp_path):
+    from gr_lora_amd import build
+    build.build_library()
+    src = tmp_path / "shim_harness.cpp"
+    src.write_text(HARNESS)
+    exe = tmp_path / "shim_harness"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "tests", "mock_gnuradio"), "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(ROOT, "shim", "gnuradio"), str(src), os.path.join(ROOT, "shim", "gnuradio", "decoder_impl.cc"),
+                           "-o", str(exe), "-L", os.path.join(ROOT, "gr_lora_amd"), "-llora_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "gr_lora_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_shim_compiles_and_links(tmp_path):
+    assert os.path.exists(_build(tmp_path))
+
+
+@pytest.mark.gpu
+def test_shim_block_decodes_known_answer(tmp_path):
+    exe = _build(tmp_path)
+    iq_path = os.path.join(ROOT, "tests", "golden", "sf7_cr4_deadbeef_x2.cf32")
+    res = subprocess.run([str(exe), iq_path], timeout=120, capture_output=True)
+    assert res.returncode == 0, (res.returncode, res.stderr.decode()[-400:])
+    lines = res.stdout.decode().split("\n")
+    assert "Bins per symbol: \t128" in lines and "Samples per symbol: \t1024" in lines and "Decimation: \t\t8" in lines   # the banner, :94-96
+    frames = [l for l in lines if l and all(c in "0123456789abcdef" for c in l)]
+    assert frames == ["049040deadbeef700d"] * 2
+
+
+XLATING_HARNESS = textwrap.dedent(r'''
+    #include <cstdio>
+    #include <fstream>
+    #include <iterator>
+    #include <vector>
+    #include "xlating_hip.h"
+    int main(int argc, char **argv) {      // in.cf32 out.cf32 decimation chunk_outputs
+        if (argc < 5) return 2;
+        std::ifstream f(argv[1], std::ios::binary);
+        std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        const gr_complex *iq = reinterpret_cast<const gr_complex *>(raw.data());
+        const long long n = (long long)(raw.size() / sizeof(gr_complex));
+        const unsigned D = (unsigned)atoi(argv[3]);
+        const int chunk = atoi(argv[4]);
+        auto blk = gr::lora::xlating_hip::make(1e6f, 868.0e6f, {868.1e6f}, 125000, D);
+        if (blk->decimation() != D || blk->taps().empty()) return 3;
+        std::vector<gr_complex> out((size_t)(n / D) + 8);
+        long long pos = 0, produced = 0;
+        int call = 0;
+        while ((n - pos) / D >= 1) {        // the scheduler of a sync_decimator: noutput_items outputs need noutput_items * D inputs
+            long long want = (n - pos) / D; if (want > chunk) want = chunk;
+            gr_vector_const_void_star in{iq + pos};
+            gr_vector_void_star o{out.data() + produced};
+            if (call++ == 3) blk->apply_cfo(-1234.5f);   // channelizer_impl::apply_cfo mid-stream (:68-71)
+            const int got = blk->work((int)want, in, o);
+            if (got != (int)want) return 4;
+            pos += want * D; produced += got;
+        }
+        std::ofstream g(argv[2], std::ios::binary);
+        g.write(reinterpret_cast<const char *>(out.data()), produced * sizeof(gr_complex));
+        return 0;
+    }
+''')
+
+
+def _build_xlating(tmp_path):
+    from gr_lora_amd import build
+    build.build_library()
+    src = tmp_path / "xlating_harness.cpp"
+    src.write_text(XLATING_HARNESS)
+    exe = tmp_path / "xlating_harness"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "tests", "mock_gnuradio"), "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(ROOT, "shim", "gnuradio"), str(src), os.path.join(ROOT, "shim", "gnuradio", "xlating_hip.cc"),
+                           "-o", str(exe), "-L", os.path.join(ROOT, "gr_lora_amd"), "-llora_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "gr_lora_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_channelizer_shim_compiles_and_links(tmp_path):
+    assert os.path.exists(_build_xlating(tmp_path))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("decimation,chunk", [(1, 4096), (4, 777)])
+def test_channelizer_shim_block_vs_oracle(tmp_path, decimation, chunk):
+    """The sync_decimator shim, driven in chunks with an apply_cfo in mid-stream, against the float64 restatement of
+    freq_xlating_fir_filter_ccf + firdes::low_pass (oracle/channelizer_oracle.py)."""
+    import numpy as np
+    from oracle import channelizer_oracle as co
+    exe = _build_xlating(tmp_path)
+    rng = np.random.default_rng(12 + decimation)
+    n = 40000
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    inp, outp = tmp_path / "in.cf32", tmp_path / "out.cf32"
+    x.tofile(inp)
+    res = subprocess.run([str(exe), str(inp), str(outp), str(decimation), str(chunk)], timeout=120, capture_output=True)
+    assert res.returncode == 0, (res.returncode, res.stderr.decode()[-400:])
+    got = np.fromfile(outp, dtype=np.complex64)
+    ch = co.Channelizer(1e6, 868.0e6, 868.1e6, 125000, decimation)
+    want = []
+    pos, call = 0, 0
+    while (n - pos) // decimation >= 1:
+        w = min((n - pos) // decimation, chunk)
+        if call == 3:
+            ch.apply_cfo(-1234.5)
+        call += 1
+        want.append(ch.work(x[pos:pos + w * decimation]))
+        pos += w * decimation
+    want = np.concatenate(want)
+    assert got.size == want.size
+    assert np.max(np.abs(got - want)) <= 2e-5 * np.max(np.abs(want))
