@@ -133,11 +133,11 @@ constexpr uint32_t kBalanceWords = 3u * kBalanceCus;   // per CU: remaining work
 // burst envelope pre-pass (segment planning): one entry per stream, blocks of one symbol
 struct EnvStream {
     uint64_t off;          // first item of the stream
-    uint32_t first_block;  // index of its first block in E
+    uint32_t first_block;  // index of its first block in E (a multiple of 64: one bitmap word per wavefront)
     uint32_t n_blocks;
 };
-int launch_envelope(const float2 *iq, const EnvStream *d_streams, uint32_t n_streams, uint32_t total_blocks, uint32_t sps, float *d_E,
-                    unsigned long long *d_bitmap /* (total_blocks + 63) / 64 words */, void *stream);
+int launch_envelope(const float2 *iq, const EnvStream *streams /* host table; first_block a multiple of 64 */, uint32_t n_streams, uint32_t sps,
+                    float *d_E, unsigned long long *d_bitmap /* one bit per block of E */, void *stream);
 
 int launch_walker(const DevParams &p, const LaunchCfg &c, void *stream);
 int launch_demod_symbols(const DevParams &p, const float2 *iq, const int64_t *d_offsets, uint32_t n,

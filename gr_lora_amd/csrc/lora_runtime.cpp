@@ -145,7 +145,6 @@ struct lora_hip_decoder {
     PinnedBuf<AttemptRec> p_recs;
     // burst-envelope pre-pass (segment planning)
     DevBuf<uint32_t> d_balance;             // LaunchCfg::balance, zeroed when allocated
-    DevBuf<EnvStream> d_env_streams;
     DevBuf<float> d_env_E;
     DevBuf<unsigned long long> d_env_buf;   // gap-start bitmap, one bit per block
     PinnedBuf<EnvStream> p_env_streams;
@@ -514,12 +513,12 @@ lora_hip_status quiet_edges_enqueue(lora_hip_decoder *h, const float2 *d_iq, con
     uint64_t nb = 0;
     for (uint32_t i = 0; i < ns; i++) {
         const uint64_t n = streams[i].len / sps;
+        nb = (nb + 63u) & ~63ull;                                        // every stream starts a bitmap word
         if (n == 0 || nb + n > 0xffffffffull) return LORA_HIP_ERR_ARG; // caller falls back to the fixed grid
         h->p_env_streams.p[i] = EnvStream{streams[i].off, (uint32_t)nb, (uint32_t)n};
         nb += n;
     }
     const size_t words = (size_t)((nb + 63u) / 64u);                 // one bit per block
-    HIP_TRY(h, h->d_env_streams.reserve(ns));
     HIP_TRY(h, h->d_env_E.reserve(nb));
     HIP_TRY(h, h->d_env_buf.reserve(words));
     HIP_TRY(h, h->p_env_buf.reserve(words));
@@ -531,11 +530,10 @@ lora_hip_status quiet_edges_enqueue(lora_hip_decoder *h, const float2 *d_iq, con
         HIP_TRY(h, hipEventRecord(h->ev_dep, st));
         HIP_TRY(h, hipStreamWaitEvent(ps, h->ev_dep, 0));
     }
-    HIP_TRY(h, hipMemcpyAsync(h->d_env_streams.p, h->p_env_streams.p, ns * sizeof(EnvStream), hipMemcpyHostToDevice, ps));
     static const bool dbg = getenv("LORA_HIP_DEBUG") != nullptr;
     if (dbg) HIP_TRY(h, hipEventRecord(h->ev_pre0, ps));
     static const bool direct = getenv("LORA_HIP_STAGED") == nullptr; // the bitmap is written straight into page-locked host memory
-    if (launch_envelope(d_iq, h->d_env_streams.p, ns, (uint32_t)nb, sps, h->d_env_E.p, direct ? h->p_env_buf.p : h->d_env_buf.p, ps) != 0)
+    if (launch_envelope(d_iq, h->p_env_streams.p, ns, sps, h->d_env_E.p, direct ? h->p_env_buf.p : h->d_env_buf.p, ps) != 0)
         return fail(h, LORA_HIP_ERR_HIP, "envelope launch failed: %s", hipGetErrorString(hipGetLastError()));
     if (dbg) HIP_TRY(h, hipEventRecord(h->ev_pre1, ps));
     if (!direct) HIP_TRY(h, hipMemcpyAsync(h->p_env_buf.p, h->d_env_buf.p, words * 8u, hipMemcpyDeviceToHost, ps));
@@ -712,7 +710,7 @@ void lora_hip_destroy(lora_hip_decoder_t *h)
     h->d_jobs.release(); h->d_results.release(); h->d_recs.release(); h->d_scratch.release();
     h->d_trace.release(); h->d_staging.release(); h->d_offsets.release(); h->d_bins.release();
     h->p_jobs.release(); h->p_res.release(); h->p_recs.release();
-    h->d_balance.release(); h->d_env_streams.release(); h->d_env_E.release(); h->d_env_buf.release(); h->p_env_streams.release(); h->p_env_buf.release();
+    h->d_balance.release(); h->d_env_E.release(); h->d_env_buf.release(); h->p_env_streams.release(); h->p_env_buf.release();
     for (hipEvent_t e : {h->ev0, h->ev1, h->ev_done, h->ev_pre0, h->ev_pre1, h->ev_dep})
         if (e) (void)hipEventDestroy(e);
     if (h->pre_stream) (void)hipStreamDestroy(h->pre_stream);
