@@ -8,15 +8,32 @@
  *
  * It is a from-scratch plain-C restatement of the arithmetic and the state
  * machine of the reference's gr::lora::decoder_impl (lib/decoder_impl.cc), each
- * function citing the reference file:line it follows.  The reference itself
- * cannot be compiled here (GNU Radio, liquid-dsp, VOLK, Boost absent), so the
- * three third-party pieces are restated from their published behaviour:
- *   - VOLK reductions   -> sequential float loops (summation order unpinned),
- *   - liquid fft_execute -> iterative radix-2 FFT (any DFT agrees to rounding),
+ * function citing the reference file:line it follows.
+ *
+ * PARITY PINNING.  The reference itself IS compiled here: oracle/ref_build/
+ * builds /root/reference/lib/decoder_impl.cc unmodified against stand-in
+ * headers for GNU Radio / pmt / VOLK / liquid-dsp / boost into
+ * oracle/_ref/libref_decoder.so, and tests/test_ref_pin.py asserts that this
+ * restatement and that library publish identical frames at identical positions
+ * through an identical sequence of work() calls with bit-identical decision
+ * values over the reference's whole `short` / `decode_long` matrix (SF7-12 x
+ * CR4/5-4/8, drift correction on/off, explicit/implicit header, AWGN, CFO),
+ * plus every table and per-stage primitive.  tests/golden/golden.json is
+ * generated from oracle/_ref, not from this file.  Also: README.md:75-85 known
+ * answer, SURVEY Appendix-C symbol list (tests/test_oracle_kat.py).
+ *
+ * What stays UNPINNED (third-party arithmetic absent from /root/reference, the
+ * stand-ins restate published behaviour and this file follows the same reading):
+ *   - VOLK reductions   -> VOLK's generic sequential loops (a SIMD protokernel
+ *     sums in another order: float-rounding level),
+ *   - liquid fft_execute -> any DFT agrees to rounding (the stand-in is a double
+ *     DFT, this file a float radix-2; tests bound the disagreement),
  *   - liquid fec_decode(HAMMING84) -> nearest-codeword table; unique for <=1 bit
- *     error, lowest-symbol tie-break for >=2 bit errors (PARITY UNPINNED there).
- * Parity pinning: README.md:75-85 known-answer bytes and the SURVEY Appendix-C
- * symbol list (tests/test_oracle_kat.py).
+ *     error, lowest-symbol tie-break ASSUMED for >=2 bit errors,
+ *   - three out-of-bounds reads of the reference, given defined values here
+ *     (whitening index past the table -> no whitening; d_upchirp_ifreq_v past
+ *     3*sps -> last value, unreachable with the gradient demodulator;
+ *     (uint8_t) of an out-of-range SNR -> 0).
  */
 #ifndef LORA_ORACLE_H
 #define LORA_ORACLE_H

@@ -1,0 +1,375 @@
+/*
+ * ref_driver.cc -- C driver around the REFERENCE decoder itself (TEST INFRASTRUCTURE ONLY).
+ *
+ * oracle/ref_build/Makefile compiles /root/reference/lib/decoder_impl.cc (included below) and lib/debugger.cc
+ * UNMODIFIED, from where they lie, against the stand-in headers in stubs/ (GNU Radio block contract, pmt, VOLK generic loops,
+ * liquid DFT + Hamming(8,4), boost::circular_buffer) and links them with this file into
+ * oracle/_ref/libref_decoder.so.  This file plays the GNU Radio scheduler: it calls decoder_impl::work() the way
+ * a sync_block with set_output_multiple(2*sps) is called (lib/decoder_impl.cc:91,:740-903), one call per state
+ * step, advancing the stream by whatever the call passed to consume_each(), and it collects what the block
+ * published on its "frames" port (:607-608).
+ *
+ * Used by tests/ to pin oracle/lora_oracle.c (the restatement) to the reference's own arithmetic and state
+ * machine, and to generate tests/golden/.  Nothing under gr_lora_amd/, include/ or shim/ may load it.
+ *
+ * `#define private public` below only opens the class for inspection (state, tables, the per-stage member
+ * functions); it changes no behaviour and no object layout.
+ */
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <memory>
+#include <new>
+#include <numeric>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include <gnuradio/sync_block.h>
+#include <gnuradio/expj.h>
+#include <liquid/liquid.h>
+#include <volk/volk.h>
+#include <boost/circular_buffer.hpp>
+
+#define private public
+#define protected public
+/* The reference translation unit itself, textually and unmodified (-I/root/reference/lib): being in one unit with it
+ * is what makes its `inline` members (instantaneous_frequency, :224) callable from here. */
+#include "decoder_impl.cc"
+#undef private
+#undef protected
+
+using gr::lora::decoder_impl;
+using gr::lora::DecoderState;
+
+extern "C" {
+
+/* same layout as oracle_step_t (oracle/lora_oracle.h) so that traces compare field by field */
+typedef struct {
+    int32_t state;    /* d_state on entry of this work() call */
+    int64_t pos;      /* absolute sample index of input[0] */
+    int32_t consumed; /* consume_each() amount (0 when the call did not consume: DETECT -> SYNC, :755-763) */
+    int32_t bin;      /* max_frequency_gradient_idx(input) in the DECODE states, else -1 */
+    int32_t fine;     /* d_fine_sync after the call */
+    float value;      /* autocorrelation (DETECT), sliding max (SYNC), SFD correlation (FIND_SFD), else 0 */
+} ref_step_t;
+
+struct ref_frame {
+    std::vector<uint8_t> bytes;
+    int64_t hdr_pos;
+};
+
+struct ref_handle {
+    void* mem;
+    decoder_impl* d;
+    int64_t abs_pos;
+    int64_t hdr_pos;
+    std::vector<ref_frame> frames;
+    bool trace_on;
+    std::vector<ref_step_t> steps;
+    std::ostringstream out; /* what the block printed on std::cout (banner :93-103, hex dumps :832,:872) */
+};
+
+struct cout_capture {
+    std::streambuf* old;
+    explicit cout_capture(std::ostringstream& to) : old(std::cout.rdbuf(to.rdbuf())) {}
+    ~cout_capture() { std::cout.rdbuf(old); }
+};
+
+/* Mirrors decoder::make (lib/decoder_impl.cc:41-44).  The object is constructed in ZEROED storage, so the members the
+ * reference leaves uninitialised until first use (d_snr, d_corr_fails, d_payload_length, d_mac_crc:
+ * lib/decoder_impl.h:100-103) read as 0 instead of heap garbage.  Returns NULL where the constructor would exit(1). */
+void* ref_create(float samp_rate, uint32_t bandwidth, uint8_t sf, int implicit, uint8_t cr, int crc, int reduced_rate,
+                 int disable_drift_correction)
+{
+    if (sf < 6 || sf > 13)
+        return nullptr; /* :57-61 */
+    ref_handle* h = new ref_handle;
+    h->abs_pos = 0;
+    h->hdr_pos = -1;
+    h->trace_on = false;
+    cout_capture cap(h->out);
+    /* print_vector_hex (utilities.h:352-368) leaves std::cout in hex / setfill('0') for the rest of the process; a block
+     * constructed afterwards would print its banner in hex.  Every handle starts from the stream state of a fresh process. */
+    static std::ios fresh(nullptr);
+    static bool have_fresh = false;
+    if (!have_fresh) {
+        fresh.copyfmt(std::cout);
+        have_fresh = true;
+    }
+    std::cout.copyfmt(fresh);
+    h->mem = calloc(1, sizeof(decoder_impl));
+    h->d = new (h->mem) decoder_impl(samp_rate, bandwidth, sf, implicit != 0, cr, crc != 0, reduced_rate != 0,
+                                     disable_drift_correction != 0);
+    return h;
+}
+
+void ref_destroy(void* hv)
+{
+    ref_handle* h = (ref_handle*)hv;
+    if (!h)
+        return;
+    h->d->~decoder_impl();
+    free(h->mem);
+    delete h;
+}
+
+/* the factory itself, to show it links and yields a usable block (frames are identical; heap garbage in d_snr aside) */
+int ref_make_smoke(void)
+{
+    std::ostringstream sink;
+    cout_capture cap(sink);
+    gr::lora::decoder::sptr p = gr::lora::decoder::make(1e6f, 125000u, 7, false, 4, true, false, false);
+    return p && p->output_multiple() == 2048 && p->name() == "decoder" ? 1 : 0;
+}
+
+uint32_t ref_sps(void* hv) { return ((ref_handle*)hv)->d->d_samples_per_symbol; }
+uint32_t ref_bins(void* hv) { return ((ref_handle*)hv)->d->d_number_of_bins; }
+uint32_t ref_bins_hdr(void* hv) { return ((ref_handle*)hv)->d->d_number_of_bins_hdr; }
+uint32_t ref_decim(void* hv) { return ((ref_handle*)hv)->d->d_decim_factor; }
+uint32_t ref_delay_after_sync(void* hv) { return ((ref_handle*)hv)->d->d_delay_after_sync; }
+int ref_output_multiple(void* hv) { return ((ref_handle*)hv)->d->output_multiple(); }
+int ref_state(void* hv) { return (int)((ref_handle*)hv)->d->d_state; }
+int ref_phdr_cr(void* hv) { return ((ref_handle*)hv)->d->d_phdr.cr; }
+double ref_dt(void* hv) { return ((ref_handle*)hv)->d->d_dt; }
+int ref_num_ports(void* hv) { return (int)((ref_handle*)hv)->d->stub_ports.size(); }
+const char* ref_port_name(void* hv, int i) { return ((ref_handle*)hv)->d->stub_ports[i].c_str(); }
+int ref_in_sig(void* hv, int which)
+{
+    gr::io_signature::sptr s = ((ref_handle*)hv)->d->stub_in;
+    return which == 0 ? s->min_streams() : which == 1 ? s->max_streams() : s->sizeof_stream_item(0);
+}
+
+size_t ref_stdout(void* hv, char* buf, size_t cap)
+{
+    const std::string s = ((ref_handle*)hv)->out.str();
+    if (buf && cap) {
+        const size_t n = std::min(cap - 1, s.size());
+        memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return s.size();
+}
+
+void ref_enable_trace(void* hv, int on) { ((ref_handle*)hv)->trace_on = on != 0; }
+size_t ref_trace(void* hv, const ref_step_t** steps)
+{
+    ref_handle* h = (ref_handle*)hv;
+    *steps = h->steps.data();
+    return h->steps.size();
+}
+
+/* The scheduler: a sync_block whose output multiple is 2*sps is only called with >= 2*sps items available, in multiples
+ * of it.  Each call is one state step; the stream advances by the consume_each() of that call.  Returns items consumed. */
+size_t ref_run(void* hv, const float* iq, size_t n)
+{
+    ref_handle* h = (ref_handle*)hv;
+    decoder_impl* d = h->d;
+    cout_capture cap(h->out);
+    const size_t mult = (size_t)d->output_multiple();
+    const gr_complex* base = (const gr_complex*)iq;
+    size_t pos = 0;
+    gr_vector_const_void_star in(1);
+    gr_vector_void_star out;
+    while (n - pos >= mult) {
+        const gr_complex* input = base + pos;
+        const int noutput = (int)std::min<size_t>(((n - pos) / mult) * mult, (size_t)1 << 30);
+        const DecoderState st = d->d_state;
+        ref_step_t s;
+        s.state = (int32_t)st;
+        s.pos = h->abs_pos + (int64_t)pos;
+        s.bin = -1;
+        s.value = 0.0f;
+        if (h->trace_on) {
+            /* observe what this call is about to compute, through the block's own (pure) member functions */
+            const uint32_t sps = d->d_samples_per_symbol;
+            if (st == DecoderState::DETECT) {
+                boost::circular_buffer<float> q = d->d_pwr_queue;
+                const float thr = d->d_energy_threshold;
+                s.value = d->detect_preamble_autocorr(input, sps);
+                d->d_pwr_queue = q;
+                d->d_energy_threshold = thr;
+            } else if (st == DecoderState::SYNC) {
+                int32_t i = 0;
+                s.value = d->detect_upchirp(input, sps, &i);
+            } else if (st == DecoderState::FIND_SFD) {
+                s.value = d->detect_downchirp(input, sps);
+            } else if (st == DecoderState::DECODE_HEADER) {
+                s.bin = (int32_t)d->max_frequency_gradient_idx(input);
+            } else if (st == DecoderState::DECODE_PAYLOAD) {
+                if (!(d->d_implicit && d->determine_energy(input) < d->d_energy_threshold))
+                    s.bin = (int32_t)d->max_frequency_gradient_idx(input);
+            }
+        }
+        if (st == DecoderState::DECODE_HEADER && h->hdr_pos < 0)
+            h->hdr_pos = h->abs_pos + (int64_t)pos;
+        in[0] = input;
+        d->stub_consumed = -1;
+        d->stub_published.clear();
+        const int rc = d->work(noutput, in, out);
+        (void)rc;
+        const long long c = d->stub_consumed < 0 ? 0 : d->stub_consumed;
+        for (auto& m : d->stub_published) {
+            if (m.first == "frames" && m.second->is_blob) {
+                ref_frame f;
+                f.bytes = m.second->blob;
+                f.hdr_pos = h->hdr_pos;
+                h->frames.push_back(f);
+            }
+        }
+        if (d->d_state == DecoderState::DETECT || d->d_state == DecoderState::SYNC)
+            h->hdr_pos = -1;
+        if (h->trace_on) {
+            s.consumed = (int32_t)c;
+            s.fine = d->d_fine_sync;
+            h->steps.push_back(s);
+        }
+        pos += (size_t)c;
+    }
+    h->abs_pos += (int64_t)pos;
+    return pos;
+}
+
+int ref_num_frames(void* hv) { return (int)((ref_handle*)hv)->frames.size(); }
+int ref_get_frame(void* hv, int idx, uint8_t* buf, int cap)
+{
+    const ref_frame& f = ((ref_handle*)hv)->frames[idx];
+    if (buf && cap >= (int)f.bytes.size())
+        memcpy(buf, f.bytes.data(), f.bytes.size());
+    return (int)f.bytes.size();
+}
+int64_t ref_frame_pos(void* hv, int idx) { return ((ref_handle*)hv)->frames[idx].hdr_pos; }
+void ref_clear_frames(void* hv) { ((ref_handle*)hv)->frames.clear(); }
+
+/* tables of build_ideal_chirps (:141-175); same numbering as lora_oracle_table */
+const float* ref_table(void* hv, int which, size_t* n_floats)
+{
+    decoder_impl* d = ((ref_handle*)hv)->d;
+    switch (which) {
+    case 0: *n_floats = 2 * d->d_downchirp.size(); return (const float*)d->d_downchirp.data();
+    case 1: *n_floats = 2 * d->d_upchirp.size(); return (const float*)d->d_upchirp.data();
+    case 2: *n_floats = d->d_downchirp_ifreq.size(); return d->d_downchirp_ifreq.data();
+    case 3: *n_floats = d->d_upchirp_ifreq.size(); return d->d_upchirp_ifreq.data();
+    case 4: *n_floats = d->d_upchirp_ifreq_v.size(); return d->d_upchirp_ifreq_v.data();
+    }
+    *n_floats = 0;
+    return nullptr;
+}
+
+/* ---- the block's own per-stage member functions, for primitive-level pinning ---- */
+uint32_t ref_get_shift_fft(void* hv, const float* iq) { return ((ref_handle*)hv)->d->get_shift_fft((const gr_complex*)iq); } /* :430-464 */
+uint32_t ref_max_frequency_gradient_idx(void* hv, const float* iq)
+{
+    return ((ref_handle*)hv)->d->max_frequency_gradient_idx((const gr_complex*)iq); /* :466-491 */
+}
+int32_t ref_fine_sync(void* hv, const float* iq, int32_t bin_idx, int32_t search_space)
+{
+    decoder_impl* d = ((ref_handle*)hv)->d;
+    d->fine_sync((const gr_complex*)iq, bin_idx, search_space); /* :300-338 */
+    return d->d_fine_sync;
+}
+float ref_detect_preamble_autocorr(void* hv, const float* iq)
+{
+    decoder_impl* d = ((ref_handle*)hv)->d;
+    return d->detect_preamble_autocorr((const gr_complex*)iq, d->d_samples_per_symbol); /* :340-366 */
+}
+float ref_energy_threshold(void* hv) { return ((ref_handle*)hv)->d->d_energy_threshold; }
+int ref_pwr_queue(void* hv, float* out4)
+{
+    decoder_impl* d = ((ref_handle*)hv)->d;
+    const int n = (int)d->d_pwr_queue.size();
+    for (int i = 0; i < n; i++)
+        out4[i] = d->d_pwr_queue[i];
+    return n;
+}
+float ref_determine_energy(void* hv, const float* iq) { return ((ref_handle*)hv)->d->determine_energy((const gr_complex*)iq); } /* :368-375 */
+float ref_detect_downchirp(void* hv, const float* iq)
+{
+    decoder_impl* d = ((ref_handle*)hv)->d;
+    return d->detect_downchirp((const gr_complex*)iq, d->d_samples_per_symbol); /* :385-390 */
+}
+float ref_detect_upchirp(void* hv, const float* iq, int32_t* index)
+{
+    decoder_impl* d = ((ref_handle*)hv)->d;
+    return d->detect_upchirp((const gr_complex*)iq, d->d_samples_per_symbol, index); /* :392-413 */
+}
+void ref_instantaneous_frequency(void* hv, const float* iq, float* out, uint32_t window)
+{
+    ((ref_handle*)hv)->d->instantaneous_frequency((const gr_complex*)iq, out, window); /* :224-244 */
+}
+
+/* deinterleave (:535-565): words -> ppm codewords */
+void ref_deinterleave(void* hv, const uint32_t* words, uint32_t n_words, uint32_t ppm, uint8_t* out)
+{
+    decoder_impl* d = ((ref_handle*)hv)->d;
+    std::vector<uint32_t> w0 = d->d_words;
+    std::vector<uint8_t> d0 = d->d_demodulated;
+    d->d_words.assign(words, words + n_words);
+    d->d_demodulated.clear();
+    d->deinterleave(ppm);
+    memcpy(out, d->d_demodulated.data(), ppm);
+    d->d_words = w0;
+    d->d_demodulated = d0;
+}
+
+/* decode() (:567-586) on a caller-given codeword stream with a caller-given d_phdr.cr: deshuffle -> dewhiten ->
+ * hamming_decode.  Returns the number of decoded bytes written (d_decoded.size()); *left = codewords that stay queued
+ * in d_demodulated (the header block's left-overs). */
+int ref_decode(void* hv, const uint8_t* demodulated, uint32_t n, int is_header, uint8_t cr, uint8_t* out, int cap, int* left)
+{
+    decoder_impl* d = ((ref_handle*)hv)->d;
+    const uint8_t cr0 = d->d_phdr.cr;
+    d->d_phdr.cr = cr;
+    d->d_demodulated.assign(demodulated, demodulated + n);
+    d->d_words_deshuffled.clear();
+    d->d_words_dewhitened.clear();
+    d->d_decoded.clear();
+    d->decode(is_header != 0);
+    const int m = (int)d->d_decoded.size();
+    if (m <= cap)
+        memcpy(out, d->d_decoded.data(), (size_t)m);
+    if (left)
+        *left = (int)d->d_demodulated.size();
+    d->d_decoded.clear();
+    d->d_demodulated.clear();
+    d->d_phdr.cr = cr0;
+    return m;
+}
+
+/* ---- include/lora/utilities.h and lib/tables.h, directly ---- */
+uint32_t ref_rotl(uint32_t bits, uint32_t count, uint32_t size) { return gr::lora::rotl(bits, count, size); }
+uint8_t ref_hamming_encode_soft(uint8_t v) { return gr::lora::hamming_encode_soft(v); }
+uint32_t ref_select_bits(uint32_t data, const uint8_t* indices, uint8_t n) { return gr::lora::select_bits(data, indices, n); }
+void ref_swap_nibbles(uint8_t* a, uint32_t n) { gr::lora::swap_nibbles(a, n); }
+uint32_t ref_build_packet(uint8_t* buffer, uint32_t offset, const void* header, uint32_t header_size)
+{
+    return gr::lora::build_packet(buffer, offset, header, header_size);
+}
+uint8_t ref_hamming84_decode_stub(uint8_t cw)
+{
+    fec q = fec_create(LIQUID_FEC_HAMMING84, NULL);
+    unsigned char in[2] = { 0, cw }, o = 0;
+    fec_decode(q, 1, in, &o);
+    fec_destroy(q);
+    return (uint8_t)(o & 0xf);
+}
+const uint8_t* ref_prng(int which, size_t* n)
+{
+    switch (which) {
+    case 0: *n = sizeof(gr::lora::prng_header); return gr::lora::prng_header;
+    case 1: *n = sizeof(gr::lora::prng_payload_cr56); return gr::lora::prng_payload_cr56;
+    case 2: *n = sizeof(gr::lora::prng_payload_cr78); return gr::lora::prng_payload_cr78;
+    }
+    *n = 0;
+    return nullptr;
+}
+int ref_sizeof(int which) { return which == 0 ? (int)sizeof(loratap_header_t) : (int)sizeof(loraphy_header_t); }
+
+} /* extern "C" */
