@@ -55,6 +55,8 @@ struct DevParams {
     const float2 *twN;          // e^{-2 pi i t / N},   t < N/2
     const float2 *tws;          // e^{-2 pi i m / sps}, m < sps
     const float  *wave_tabs;    // packed table block of the wave demodulator (lora_wave_demod.inc.hip), SF7/SF8 at D = 8
+    const float2 *w3_tw;        // walker3 (SF9-12 at D = 8): W_N^t, and the combine coefficients in pass-3 thread order
+    const float2 *w3_ctab;
 };
 
 struct Job {
@@ -142,6 +144,9 @@ int launch_envelope(const float2 *iq, const EnvStream *streams /* host table; fi
 int launch_walker(const DevParams &p, const LaunchCfg &c, void *stream);
 int launch_demod_symbols(const DevParams &p, const float2 *iq, const int64_t *d_offsets, uint32_t n,
                          int demod, uint32_t *d_bins, int32_t *d_fine, float *scratch, void *stream);
+bool walker3_covers(uint32_t sf);                                          // SF9-12: lora_walker3.inc.hip
+uint32_t w3_tw_entries(uint32_t sf);
+void build_w3_tables(uint32_t sf, float2 *tw, float2 *ctab /* sps entries */);
 uint32_t wave_tables_floats(uint32_t sf);                                  // 0 when the wave demodulator does not cover sf
 void build_wave_tables(uint32_t sf, const float2 *down, float *out);
 uint32_t walker_lds_bytes(const DevParams &p);

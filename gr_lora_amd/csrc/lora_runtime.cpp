@@ -106,6 +106,7 @@ struct lora_hip_decoder {
     // device tables
     float2 *d_down = nullptr, *d_twN = nullptr, *d_tws = nullptr;
     float *d_wave_tabs = nullptr;
+    float2 *d_w3_tw = nullptr, *d_w3_ctab = nullptr;
     float *d_up_ifreq = nullptr, *d_down_ifreq = nullptr, *d_up_ifreq_v = nullptr;
     // per-pass buffers
     DevBuf<Job> d_jobs;
@@ -304,6 +305,14 @@ lora_hip_status build_tables(lora_hip_decoder *h)
         build_wave_tables(c.sf, down.data(), wt.data());
         if ((s = upload(h, &h->d_wave_tabs, wt)) != LORA_HIP_OK) return s;
         P.wave_tabs = h->d_wave_tabs;
+    }
+    P.w3_tw = nullptr; P.w3_ctab = nullptr;
+    if (D == 8u && walker3_covers(c.sf)) { // tables of the workgroup-per-symbol walker (SF9-12)
+        std::vector<float2> tw(w3_tw_entries(c.sf)), ct(sps);
+        build_w3_tables(c.sf, tw.data(), ct.data());
+        if ((s = upload(h, &h->d_w3_tw, tw)) != LORA_HIP_OK) return s;
+        if ((s = upload(h, &h->d_w3_ctab, ct)) != LORA_HIP_OK) return s;
+        P.w3_tw = h->d_w3_tw; P.w3_ctab = h->d_w3_ctab;
     }
     P.up_ifreq = h->d_up_ifreq; P.down_ifreq = h->d_down_ifreq; P.up_ifreq_v = h->d_up_ifreq_v;
     return LORA_HIP_OK;
@@ -704,6 +713,8 @@ void lora_hip_destroy(lora_hip_decoder_t *h)
     if (h->d_twN) (void)hipFree(h->d_twN);
     if (h->d_tws) (void)hipFree(h->d_tws);
     if (h->d_wave_tabs) (void)hipFree(h->d_wave_tabs);
+    if (h->d_w3_tw) (void)hipFree(h->d_w3_tw);
+    if (h->d_w3_ctab) (void)hipFree(h->d_w3_ctab);
     if (h->d_up_ifreq) (void)hipFree(h->d_up_ifreq);
     if (h->d_down_ifreq) (void)hipFree(h->d_down_ifreq);
     if (h->d_up_ifreq_v) (void)hipFree(h->d_up_ifreq_v);

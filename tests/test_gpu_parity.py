@@ -129,16 +129,16 @@ def test_symbol_bins_exact_and_awgn(torch_cuda, oracle_mod):
         h.close()
 
 
-@pytest.mark.parametrize("sf", [7, 8])
+@pytest.mark.parametrize("sf", [7, 8, 9, 10, 11, 12])
 def test_wave_demod_shift_and_fine_sync_vs_oracle(torch_cuda, oracle_mod, sf):
-    """The wave-per-symbol demodulator (the walker's decode rounds) on its own: shift and d_fine_sync per
+    """The wave-per-symbol (SF7/8) and workgroup-per-symbol (SF9-12) demodulators on their own: shift and d_fine_sync per
     window against get_shift_fft / fine_sync of the oracle -- clean symbols, windows cut a few samples
     early/late (fine_sync = -+1), and AWGN (shift within +-1 bin; where the shift agrees, fine_sync too)."""
     from gr_lora_amd import capi
     cfg = synth.TxConfig(sf=sf)
     rng = np.random.default_rng(100 + sf)
     up = synth.base_upchirp(cfg)
-    n_sym = 96
+    n_sym = 96 if sf <= 10 else 32
     shifts = rng.integers(0, cfg.nbins, n_sym)
     shifts[:4] = [0, 1, cfg.nbins - 1, cfg.nbins // 2]
     ar = np.arange(cfg.sps)
@@ -172,7 +172,7 @@ def test_wave_demod_shift_and_fine_sync_vs_oracle(torch_cuda, oracle_mod, sf):
                 wf = o.fine_sync(x[offs[i]:offs[i] + cfg.sps], bin_idx, 2)
                 assert int(gf[i]) == wf, (sf, mode, sigma, i, sres, int(gf[i]), wf)
                 n_nonzero += wf != 0
-            assert n_nonzero > 10 # the slipped windows exercise lags -1 and +1
+            assert n_nonzero > (10 if sf <= 10 else 4) # the slipped windows exercise lags -1 and +1
         h.close()
 
 

@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """BASELINE config 3: per-SF throughput (IQ Msamples/s, symbols/s) and walker-kernel GB/s vs the HBM roofline.
-usage: tools/sf_sweep.py [packets_per_sf]   (prints one JSON line per SF)"""
+usage: tools/sf_sweep.py [packets_per_sf [first_sf [last_sf]]]   (prints one JSON line per SF; 0 packets = the reduced default set)"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
 from gr_lora_amd import capi
 pk = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-for sf in range(7, 13):
+sf_lo = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+sf_hi = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+for sf in range(sf_lo, sf_hi + 1):
     n = pk or {7: 256, 8: 256, 9: 128, 10: 64, 11: 32, 12: 16}[sf]
     cfg, iq, offs, lens, expect = bench.make_workload(sf, 4, n, 32, min(8, n), seed=100 * sf + 4)
     d = torch.from_numpy(iq.view(np.float32)).cuda()
