@@ -29,7 +29,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return LIB
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
-           "-Wall", "-Wno-unused-function", "-I", CSRC, "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-Wall", "-Wno-unused-function"] + os.environ.get("LORA_HIP_EXTRA_FLAGS", "").split() + ["-I", CSRC, "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)

@@ -33,32 +33,40 @@
 
 template <int SF> struct W3Geom {
     static constexpr int N = 1 << SF, SPS = 8 * N;
-    static constexpr int T = SF >= 11 ? 1024 : N / 2;   // threads per workgroup
-    static constexpr int WAVES = T / 64;
-    static constexpr int PAIRS = SPS / (16 * T);        // (q0, r) pairs per thread: 1; SF12: 2
+    static constexpr int T = 1024;                      // threads per workgroup (16 wavefronts, one workgroup per CU)
+    static constexpr int TG = SF >= 11 ? 1024 : N / 2;  // threads of one group = one symbol window
+    static constexpr int NG = T / TG;                   // groups: windows evaluated per round (SF9: 4, SF10: 2, SF11/12: 1)
+    static constexpr int GW = TG / 64;                  // wavefronts per group
+    static constexpr int PAIRS = SPS / (16 * TG);       // (q0, r) pairs per thread: 1; SF12: 2
     static constexpr int ROUNDS = PAIRS;                // passes over the rows of pass 1
     static constexpr int AR = 16 / ROUNDS;              // rows resident in LDS per round
     static constexpr int M = N / 16, M2 = M / 16, LOGM2 = ilog2(M2);
     static constexpr int SA = 8 * M + 8;                // entries per row
     static constexpr int NTW = N > 2048 ? N / 2 : N;    // W_N^t entries kept in LDS (SF12: half, the rest by sign)
     static constexpr int CH = SPS / 16;                 // samples between a thread's consecutive loads
-    static constexpr int NWL = T / (8 * AR), NB = 16 / NWL; // pass 3: butterflies per thread
-    static constexpr int LEN = SPS / T;                 // SYNC: shifts per thread
-    static constexpr uint32_t data_entries = (uint32_t)AR * SA;
+    static constexpr int NWL = TG / (8 * AR), NB = 16 / NWL; // pass 3: butterflies per thread
+    static constexpr int LEN = SPS / T;                 // SYNC: shifts per thread (all groups together)
+    static constexpr bool LATE_F = PAIRS > 1;           // fine_sync's ifreq from a second read of the window (SF12)
+    static constexpr uint32_t data_entries = (uint32_t)AR * SA; // per group
     static_assert(NB * M2 == 16, "pass 3 covers 16 values per thread");
-    static_assert(AR * M2 * 8 == T, "pass 2 uses every thread once per round");
+    static_assert(AR * M2 * 8 == TG, "pass 2 uses every thread of the group once per round");
 };
 
 struct alignas(16) W3Shared {
-    float    red[2][16 * 8 + 8];   // block reductions, double-buffered (one barrier each)
-    double   dred[2][16 * 4 + 4];  // block scans / sums of doubles (SYNC, FIND_SFD)
-    float    sfd[72];              // FIND_SFD: head / tail samples of the window's ifreq
-    int32_t  ibc[8];               // broadcasts
+    float    red[2][4][72];        // group reductions, double-buffered (one barrier each): [slot][group][wave * K + k]
+    double   dred[2][72];          // block scans / sums of doubles (SYNC; FIND_SFD at [group * 18 + ..])
+    float    sfd[4][72];           // FIND_SFD: head / tail samples of the window's ifreq, per group
+    int32_t  ibc[8];               // broadcasts (FIND_SFD lag per group)
+    W2Plan   plan[2];              // the round plan, double-buffered
+    W2State  st;                   // decoder state: thread 0 only
+    W2Stats  stats;                // per-state time accounting (LORA_HIP_DEBUG)
+    int64_t  ph_start;             // hand-over from the job proper to its tail probe (Job.probe_limit)
+    uint32_t ph_go, ph_cr, ph_natt, ph_pad;
     Shared   sh;                   // integer chain (words / codewords / decoded bytes)
 };
 
 template <int SF> struct W3Lds {
-    v2f      *data;  // [AR][SA]
+    v2f      *data;  // [NG][AR][SA]
     v2f      *tw;    // [NTW]  W_N^t
     W3Shared *ws;
 };
@@ -69,14 +77,14 @@ __device__ __forceinline__ W3Lds<SF> w3_carve(unsigned char *smem)
     using G = W3Geom<SF>;
     W3Lds<SF> L;
     L.data = reinterpret_cast<v2f *>(smem);
-    L.tw = L.data + G::data_entries;
+    L.tw = L.data + (size_t)G::NG * G::data_entries;
     L.ws = reinterpret_cast<W3Shared *>(L.tw + G::NTW);
     return L;
 }
 template <int SF> constexpr uint32_t w3_lds_bytes()
 {
     using G = W3Geom<SF>;
-    return (uint32_t)((G::data_entries + G::NTW) * sizeof(v2f) + ((sizeof(W3Shared) + 15) & ~(size_t)15));
+    return (uint32_t)(((size_t)G::NG * G::data_entries + G::NTW) * sizeof(v2f) + ((sizeof(W3Shared) + 15) & ~(size_t)15));
 }
 
 template <int SF>
@@ -90,36 +98,99 @@ __device__ __forceinline__ v2f w3_tw(const W3Lds<SF> &L, uint32_t idx)
     }
 }
 
-__device__ __forceinline__ v2f cmul2(v2f a, v2f w) { return __builtin_elementwise_fma(a.xx, w, a.yy * (v2f){-w.y, w.x}); }
-
-// ---- block reductions (T threads, slot alternates between consecutive calls) ---------------------------------
-template <int WAVES, int K>
-__device__ __forceinline__ void w3_block_sum(float (&v)[K], W3Shared &ws, int &slot)
+// a * w in two packed instructions: t = a.yy * (-w.y, w.x) through op_sel / neg_lo, then a.xx * w + t (written out: from
+// vector code the compiler builds (-w.y, w.x) with a v_xor and a v_mov first)
+__device__ __forceinline__ v2f cmul2(v2f a, v2f w)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *red = ws.red[slot];
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// K complex multiplies a[i] *= w[i], the multiplies first and the multiply-adds after them (a v_pk_fma_f32 directly behind
+// the v_pk_mul_f32 it depends on costs a wait state)
+template <int K>
+__device__ __forceinline__ void cmul_batch(v2f *a, const v2f *w)
+{
+    v2f t[K];
+#pragma unroll
+    for (int i = 0; i < K; i++) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t[i]) : "v"(a[i]), "v"(w[i]));
+#pragma unroll
+    for (int i = 0; i < K; i++) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(a[i]) : "v"(a[i]), "v"(w[i]), "v"(t[i]));
+}
+// Sums each of the 32 floats v[0..31] over the 8 lanes that share lane bits 3-5 (r = lane bits 0-2): quad xor 1, quad xor 2,
+// then the mirror inside each half row (which pairs the two quads) - one v_add_f32 with a DPP operand per step, written out
+// level by level: left to the compiler the adds are re-packed into v_pk_add_f32 (no DPP operand: a v_mov_b32_dpp per
+// component in front) and every dependent step then waits out the VALU -> DPP hazard
+__device__ __forceinline__ void w3_sum_r32(float (&v)[32])
+{
+#pragma unroll
+    for (int i = 0; i < 32; i++) asm volatile("v_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(v[i]) : "v"(v[i]));
+#pragma unroll
+    for (int i = 0; i < 32; i++) asm volatile("v_add_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(v[i]) : "v"(v[i]));
+#pragma unroll
+    for (int i = 0; i < 32; i++) asm volatile("v_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(v[i]) : "v"(v[i]));
+}
+// Raw buffer loads: address = descriptor base (scalar) + lane byte offset (one VGPR shared by all the loads of a thread)
+// + a scalar or immediate offset per load - no per-load address arithmetic on the VALU (global_load with 64-bit lane
+// addresses costs two VALU adds per load once the chunk offsets exceed the 12-bit immediate).
+typedef __amdgpu_buffer_rsrc_t w3_buf_t;
+__device__ __forceinline__ w3_buf_t w3_buf(const void *uniform_base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(uniform_base), 0, 0x7fffffff, 0x00020000); // raw, 32-bit elements (gfx9 word 3)
+}
+__device__ __forceinline__ v2f w3_ld2(w3_buf_t b, uint32_t voff, uint32_t soff)
+{
+    return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(b, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ float w3_ld1(w3_buf_t b, uint32_t voff, uint32_t soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, (int)voff, (int)soff, 0));
+}
+template <typename T> __device__ __forceinline__ T *w3_uniform_ptr(T *p)
+{
+    const uint64_t b = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    return (T *)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ float w3_uni(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+// a decision derived from floats (VALU results: there is no scalar float ALU) as a scalar condition, so that what depends
+// on it - the whole replicated state machine - stays in scalar registers
+__device__ __forceinline__ bool w3_ub(bool b) { return __builtin_amdgcn_readfirstlane(b ? 1 : 0) != 0; }
+
+// ---- group reductions: every thread gets the totals of EVERY group (uniform); one barrier; slots alternate --------
+template <int SF, int K>
+__device__ __forceinline__ void w3_group_sums(float (&v)[K], W3Shared &ws, int &slot, int grp, int gwave, float (&out)[W3Geom<SF>::NG][K])
+{
+    using G = W3Geom<SF>;
+    const int lane = threadIdx.x & 63;
+    float (*red)[72] = ws.red[slot];
     slot ^= 1;
 #pragma unroll
     for (int k = 0; k < K; k++) v[k] = wave_sum_rows(v[k]);
     if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < K; k++) red[wave * K + k] = v[k];
+        for (int k = 0; k < K; k++) red[grp][gwave * K + k] = v[k];
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        float s = 0.0f;
+    for (int g = 0; g < G::NG; g++)
 #pragma unroll
-        for (int w = 0; w < WAVES; w++) s += red[w * K + k];
-        v[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s)));
-    }
+        for (int k = 0; k < K; k++) {
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < G::GW; w++) s += red[g][w * K + k];
+            out[g][k] = w3_uni(s);
+        }
 }
 
-template <int WAVES>
-__device__ __forceinline__ void w3_block_argmax_first(float &v, int &idx, W3Shared &ws, int &slot)
+template <int SF>
+__device__ __forceinline__ void w3_group_argmax_first(float v, int idx, W3Shared &ws, int &slot, int grp, int gwave, float (&bv_out)[W3Geom<SF>::NG],
+                                                      int (&bi_out)[W3Geom<SF>::NG])
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *red = ws.red[slot];
+    using G = W3Geom<SF>;
+    const int lane = threadIdx.x & 63;
+    float (*red)[72] = ws.red[slot];
     slot ^= 1;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -127,18 +198,21 @@ __device__ __forceinline__ void w3_block_argmax_first(float &v, int &idx, W3Shar
         const int oi = __shfl_xor(idx, o, 64);
         if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
     }
-    if (lane == 0) { red[wave] = v; ((int *)red)[64 + wave] = idx; }
+    if (lane == 0) { red[grp][gwave] = v; ((int *)red[grp])[32 + gwave] = idx; }
     __syncthreads();
-    float bv = red[0];
-    int bi = ((int *)red)[64];
 #pragma unroll
-    for (int w = 1; w < WAVES; w++) {
-        const float ov = red[w];
-        const int oi = ((int *)red)[64 + w];
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    for (int g = 0; g < G::NG; g++) {
+        float bv = red[g][0];
+        int bi = ((int *)red[g])[32];
+#pragma unroll
+        for (int w = 1; w < G::GW; w++) {
+            const float ov = red[g][w];
+            const int oi = ((int *)red[g])[32 + w];
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        bv_out[g] = w3_uni(bv);
+        bi_out[g] = __builtin_amdgcn_readfirstlane(bi);
     }
-    v = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, bv)));
-    idx = __builtin_amdgcn_readfirstlane(bi);
 }
 
 __device__ __forceinline__ double w3_wave_sum_d(double v)
@@ -148,74 +222,156 @@ __device__ __forceinline__ double w3_wave_sum_d(double v)
     return v;
 }
 
-// ---- the cooperative symbol demodulator ----------------------------------------------------------------------
-// s_out = get_shift_fft's value for the window x[0 .. sps) (:430-464); fine_out = d_fine_sync after fine_sync(bin_idx, 2)
-// (:300-338, :501-502; 0 when drift correction is off); energy_out = determine_energy (:368-375) when want_energy.
-// Called by all T threads of the workgroup; the LDS twiddle table must be in place.
+// atan2 of four points, as two packed evaluations of lean_atan2_pk's polynomial with the Horner steps interleaved (a
+// v_pk_fma_f32 directly behind the one it depends on costs a wait state)
+__device__ __forceinline__ void w3_atan2_x4(v2f y0, v2f x0, v2f y1, v2f x1, v2f &r0_out, v2f &r1_out)
+{
+    const float ax00 = fabsf(x0.x), ay00 = fabsf(y0.x), ax01 = fabsf(x0.y), ay01 = fabsf(y0.y);
+    const float ax10 = fabsf(x1.x), ay10 = fabsf(y1.x), ax11 = fabsf(x1.y), ay11 = fabsf(y1.y);
+    const float m00 = fmaxf(fmaxf(ax00, ay00), 1.0e-37f), m01 = fmaxf(fmaxf(ax01, ay01), 1.0e-37f); // atan2(0, 0) = 0
+    const float m10 = fmaxf(fmaxf(ax10, ay10), 1.0e-37f), m11 = fmaxf(fmaxf(ax11, ay11), 1.0e-37f);
+    v2f a0, a1;
+    a0.x = fminf(ax00, ay00) * __builtin_amdgcn_rcpf(m00);
+    a1.x = fminf(ax10, ay10) * __builtin_amdgcn_rcpf(m10);
+    a0.y = fminf(ax01, ay01) * __builtin_amdgcn_rcpf(m01);
+    a1.y = fminf(ax11, ay11) * __builtin_amdgcn_rcpf(m11);
+    const v2f s0 = a0 * a0, s1 = a1 * a1;
+    v2f p0 = (v2f){-0.0040545230731368065f, -0.0040545230731368065f}, p1 = p0;
+#define LORA_W3_HORNER(C) p0 = __builtin_elementwise_fma(p0, s0, (v2f){C, C}); p1 = __builtin_elementwise_fma(p1, s1, (v2f){C, C})
+    LORA_W3_HORNER(0.02186279185116291f);
+    LORA_W3_HORNER(-0.0559120774269104f);
+    LORA_W3_HORNER(0.09642177820205688f);
+    LORA_W3_HORNER(-0.13908621668815613f);
+    LORA_W3_HORNER(0.19946564733982086f);
+    LORA_W3_HORNER(-0.33329859375953674f);
+    LORA_W3_HORNER(0.9999993443489075f);
+#undef LORA_W3_HORNER
+    const v2f q0 = a0 * p0, q1 = a1 * p1;
+    float r00 = q0.x, r01 = q0.y, r10 = q1.x, r11 = q1.y;
+    r00 = (ay00 > ax00) ? 1.57079632679489662f - r00 : r00;
+    r10 = (ay10 > ax10) ? 1.57079632679489662f - r10 : r10;
+    r01 = (ay01 > ax01) ? 1.57079632679489662f - r01 : r01;
+    r11 = (ay11 > ax11) ? 1.57079632679489662f - r11 : r11;
+    r00 = (x0.x < 0.0f) ? 3.14159265358979324f - r00 : r00;
+    r10 = (x1.x < 0.0f) ? 3.14159265358979324f - r10 : r10;
+    r01 = (x0.y < 0.0f) ? 3.14159265358979324f - r01 : r01;
+    r11 = (x1.y < 0.0f) ? 3.14159265358979324f - r11 : r11;
+    r0_out = (v2f){copysignf(r00, y0.x), copysignf(r01, y0.y)};
+    r1_out = (v2f){copysignf(r10, y1.x), copysignf(r11, y1.y)};
+}
+
+// the ifreq of a thread's 16 chunk samples a[c] (n = c CH + base): f[c] = ifreq[n - 1] = arg(x[n] conj(x[n-1])), with the
+// predecessors x[n-1] loaded by the caller (a second, cache-hot round of coalesced loads: cheaper than moving the neighbour
+// lane's sample over with DPP and patching lane 0 from a boundary load - 8 VALU instructions per sample pair)
+template <bool FIRST>
+__device__ __forceinline__ void w3_ifreq16(const v2f (&a)[16], const v2f (&ap)[16], bool n0_thread, float (&f)[16])
+{
+#pragma unroll
+    for (int c = 0; c < 16; c += 4) {
+        if (c == 8) __builtin_amdgcn_sched_barrier(0);
+        v2f im0, re0, im1, re1, o0, o1;
+        im0 = (v2f){a[c].y * ap[c].x - a[c].x * ap[c].y, a[c + 1].y * ap[c + 1].x - a[c + 1].x * ap[c + 1].y};
+        re0 = (v2f){a[c].x * ap[c].x + a[c].y * ap[c].y, a[c + 1].x * ap[c + 1].x + a[c + 1].y * ap[c + 1].y};
+        im1 = (v2f){a[c + 2].y * ap[c + 2].x - a[c + 2].x * ap[c + 2].y, a[c + 3].y * ap[c + 3].x - a[c + 3].x * ap[c + 3].y};
+        re1 = (v2f){a[c + 2].x * ap[c + 2].x + a[c + 2].y * ap[c + 2].y, a[c + 3].x * ap[c + 3].x + a[c + 3].y * ap[c + 3].y};
+        w3_atan2_x4(im0, re0, im1, re1, o0, o1);
+        f[c] = (FIRST && c == 0 && n0_thread) ? 0.0f : o0.x; // n = 0 has no predecessor in the window
+        f[c + 1] = o0.y; f[c + 2] = o1.x; f[c + 3] = o1.y;
+    }
+}
+
+// ---- the cooperative symbol demodulator, one window per group -------------------------------------------------
+// Group g evaluates the window at x_g (when valid_g): s[g] = get_shift_fft's value (:430-464); fine[g] = d_fine_sync after
+// fine_sync(bin_idx, 2) (:300-338, :501-502; 0 when drift correction is off); en[g] = determine_energy (:368-375) when
+// want_energy.  Called by all threads of the workgroup (barriers inside); the results of every group come back uniform.
+struct W3DemodOut { uint32_t s[4]; int32_t fine[4]; float en[4]; int slot; };
+struct W3DemodArgs { const float2 *down, *ctab; const float *up_ifreq_v; uint32_t enable_fine_sync, demod_mode; };
 template <int SF>
-__device__ __forceinline__ void w3_demod_symbol(const DevParams &P, const W3Lds<SF> &L, const float2 *__restrict__ x, bool want_energy, int &slot,
-                                                uint32_t &s_out, int32_t &fine_out, float &energy_out)
+__device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds<SF> &L, const float2 *__restrict__ x, bool valid, bool want_energy, int &slot,
+                                               uint32_t (&s_out)[W3Geom<SF>::NG], int32_t (&fine_out)[W3Geom<SF>::NG], float (&en_out)[W3Geom<SF>::NG])
 {
     using G = W3Geom<SF>;
-    constexpr int N = G::N, SPS = G::SPS, T = G::T, CH = G::CH, M2 = G::M2, AR = G::AR, SA = G::SA, PAIRS = G::PAIRS, ROUNDS = G::ROUNDS;
-    int t = threadIdx.x;
-    asm volatile("" : "+v"(t)); // keeps per-thread table addresses out of the caller's loop-invariant set
-    const int lane = t & 63, wave = t >> 6, r = t & 7;
+    constexpr int N = G::N, SPS = G::SPS, TG = G::TG, CH = G::CH, M2 = G::M2, AR = G::AR, SA = G::SA, PAIRS = G::PAIRS, ROUNDS = G::ROUNDS, NG = G::NG;
+    int tt = threadIdx.x;
+    asm volatile("" : "+v"(tt)); // keeps per-thread table addresses out of the caller's loop-invariant set
+    const int grp = __builtin_amdgcn_readfirstlane(tt / TG), t = tt % TG;
+    const int lane = t & 63, gwave = __builtin_amdgcn_readfirstlane(t >> 6), r = t & 7;
     const bool want_fine = P.enable_fine_sync != 0u;
-    const auto xv = (const __attribute__((address_space(1))) v2f *)x;
-    const auto dv = (const __attribute__((address_space(1))) v2f *)P.down;
-    const auto cv = (const __attribute__((address_space(1))) v2f *)P.w3_ctab;
+    const w3_buf_t xb = w3_buf(w3_uniform_ptr(x)), db = w3_buf(w3_uniform_ptr(P.down)), cb = w3_buf(w3_uniform_ptr(P.ctab));
     W3Shared &ws = *L.ws;
+    v2f *data = L.data + (size_t)grp * G::data_entries;
+    const uint32_t tu = (uint32_t)t;
 
-    float f[PAIRS][16];     // ifreq[n - 1] of this thread's samples
+    float f[G::LATE_F ? 1 : 16]; // ifreq[n - 1] of this thread's samples (kept from pass 1 unless LATE_F)
     v2f hold[ROUNDS > 1 ? PAIRS : 1][8]; // SF12: rows 8..15 of pass 1 wait here for round 1
     float en = 0.0f;
 
     // ---- pass 1 ----
+    if (valid) {
 #pragma unroll
-    for (int p = 0; p < PAIRS; p++) {
-        const int base = p * T + t;
-        v2f a[16], d[16];
+        for (int p = 0; p < PAIRS; p++) {
+            const int base = p * TG + t;
+            const uint32_t ob = 8u * ((uint32_t)(p * TG) + tu); // byte offset of this thread's sample inside a chunk
+            v2f a[16];
 #pragma unroll
-        for (int c = 0; c < 16; c++) a[c] = xv[c * CH + base];
-        v2f bnd = (v2f){0.0f, 0.0f}; // lane c: the sample before this wavefront's first one in chunk c
-        if (want_fine) {
-            const int bi = (lane & 15) * CH + p * T + 64 * wave - 1;
-            bnd = xv[bi < 0 ? 0 : bi];
-        }
+            for (int c = 0; c < 16; c++) a[c] = w3_ld2(xb, ob, (uint32_t)(c * CH * 8));
+            if (want_energy) {
 #pragma unroll
-        for (int c = 0; c < 16; c++) d[c] = dv[c * CH + base];
-        if (want_fine) {
-            const float bnd_xf = bnd.x, bnd_yf = bnd.y; // scalars first: bit_cast on a vector element reads element 0 with this compiler
-            const int bnd_xi = __builtin_bit_cast(int, bnd_xf), bnd_yi = __builtin_bit_cast(int, bnd_yf);
-#pragma unroll
-            for (int c = 0; c < 16; c += 2) {
-                const float bx0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bnd_xi, c));
-                const float by0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bnd_yi, c));
-                const float bx1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bnd_xi, c + 1));
-                const float by1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bnd_yi, c + 1));
-                const v2f r0 = dpp2<kDppWaveRor1>(a[c]), r1 = dpp2<kDppWaveRor1>(a[c + 1]);
-                const v2f p0 = (lane == 0) ? (v2f){bx0, by0} : r0, p1 = (lane == 0) ? (v2f){bx1, by1} : r1;
-                const v2f fp = ifreq_prod_pk(p0, a[c], p1, a[c + 1]);
-                f[p][c] = (c == 0 && p == 0 && t == 0) ? 0.0f : fp.x; // n = 0 has no predecessor in the window
-                f[p][c + 1] = fp.y;
+                for (int c = 0; c < 16; c++) en += a[c].x * a[c].x + a[c].y * a[c].y;
             }
-        }
-        if (want_energy) {
+            if constexpr (!G::LATE_F) {
+                if (want_fine) {
+                    // x[n - 1], eight at a time (a + all 16 predecessors + the dechirp table would not fit the register budget)
 #pragma unroll
-            for (int c = 0; c < 16; c++) en += a[c].x * a[c].x + a[c].y * a[c].y;
-        }
+                    for (int h = 0; h < 2; h++) {
+                        v2f ap[8];
 #pragma unroll
-        for (int c = 0; c < 16; c++) a[c] = cmul2(a[c], d[c]); // dechirp (:437)
-        fft_inlane_dif_pk<16>(a);
-        const int q0 = base >> 3;
+                        for (int c = 0; c < 8; c++)
+                            ap[c] = (h == 0 && c == 0) ? w3_ld2(xb, ob >= 8u ? ob - 8u : 0u, 0u) : w3_ld2(xb, ob, (uint32_t)((8 * h + c) * CH * 8 - 8));
 #pragma unroll
-        for (int m = 1; m < 16; m++) a[m] = cmul2(a[m], w3_tw<SF>(L, (uint32_t)(q0 * brev_bits(m, 4))));
+                        for (int c = 0; c < 8; c += 4) {
+                            const int q = 8 * h + c;
+                            v2f im0, re0, im1, re1, o0, o1;
+                            im0 = (v2f){a[q].y * ap[c].x - a[q].x * ap[c].y, a[q + 1].y * ap[c + 1].x - a[q + 1].x * ap[c + 1].y};
+                            re0 = (v2f){a[q].x * ap[c].x + a[q].y * ap[c].y, a[q + 1].x * ap[c + 1].x + a[q + 1].y * ap[c + 1].y};
+                            im1 = (v2f){a[q + 2].y * ap[c + 2].x - a[q + 2].x * ap[c + 2].y, a[q + 3].y * ap[c + 3].x - a[q + 3].x * ap[c + 3].y};
+                            re1 = (v2f){a[q + 2].x * ap[c + 2].x + a[q + 2].y * ap[c + 2].y, a[q + 3].x * ap[c + 3].x + a[q + 3].y * ap[c + 3].y};
+#ifdef LORA_W3_DBG_ATAN
+                            o0 = lean_atan2_pk(im0, re0); o1 = lean_atan2_pk(im1, re1);
+#else
+                            w3_atan2_x4(im0, re0, im1, re1, o0, o1);
+#endif
+                            f[q] = (q == 0 && t == 0) ? 0.0f : o0.x; // n = 0 has no predecessor in the window
+                            f[q + 1] = o0.y; f[q + 2] = o1.x; f[q + 3] = o1.y;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
 #pragma unroll
-        for (int m = 0; m < AR; m++) L.data[m * SA + q0 * 8 + r] = a[m];
-        if constexpr (ROUNDS > 1) {
+            for (int h = 0; h < 2; h++) { // dechirp (:437)
+                v2f d[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) hold[p][i] = a[8 + i];
+                for (int c = 0; c < 8; c++) d[c] = w3_ld2(db, ob, (uint32_t)((8 * h + c) * CH * 8));
+                cmul_batch<8>(a + 8 * h, d);
+            }
+            fft_inlane_dif_pk<16>(a);
+            const int q0 = base >> 3;
+            {
+                v2f w[8];
+#pragma unroll
+                for (int m = 1; m < 8; m++) w[m] = w3_tw<SF>(L, (uint32_t)(q0 * brev_bits(m, 4)));
+                cmul_batch<7>(a + 1, w + 1);
+#pragma unroll
+                for (int m = 8; m < 16; m++) w[m - 8] = w3_tw<SF>(L, (uint32_t)(q0 * brev_bits(m, 4)));
+                cmul_batch<8>(a + 8, w);
+            }
+#pragma unroll
+            for (int m = 0; m < AR; m++) data[m * SA + q0 * 8 + r] = a[m];
+            if constexpr (ROUNDS > 1) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) hold[p][i] = a[8 + i];
+            }
         }
     }
 
@@ -226,112 +382,147 @@ __device__ __forceinline__ void w3_demod_symbol(const DevParams &P, const W3Lds<
         if (g > 0) {
             if constexpr (ROUNDS > 1) {
                 __syncthreads(); // round 0's pass 3 has read the rows
+                if (valid) {
 #pragma unroll
-                for (int p = 0; p < PAIRS; p++) {
-                    const int q0 = (p * T + t) >> 3;
+                    for (int p = 0; p < PAIRS; p++) {
+                        const int q0 = (p * TG + t) >> 3;
 #pragma unroll
-                    for (int i = 0; i < 8; i++) L.data[i * SA + q0 * 8 + r] = hold[p][i];
+                        for (int i = 0; i < 8; i++) data[i * SA + q0 * 8 + r] = hold[p][i];
+                    }
                 }
             }
         }
         __syncthreads();
         // ---- pass 2 (in place) ----
-        v2f cc[16]; // combine coefficients of pass 3: loaded here, used there
-#pragma unroll
-        for (int i = 0; i < 16; i++) cc[i] = cv[(g * 16 + i) * T + t];
-        {
-            const int row = (t >> 3) % AR, q1 = t / (8 * AR);
-            v2f *pe = L.data + row * SA + q1 * 8 + r;
+        if (valid) {
+            const int row = (t >> 3) % AR, q1 = __builtin_amdgcn_readfirstlane(t / (8 * AR)); // (8 AR >= 64: the same in all lanes)
+            v2f *pe = data + row * SA + q1 * 8 + r;
             v2f a[16];
 #pragma unroll
             for (int c2 = 0; c2 < 16; c2++) a[c2] = pe[M2 * 8 * c2];
             fft_inlane_dif_pk<16>(a);
             if (q1 != 0) { // W_{N/16}^{q1 a2} = W_N^{16 q1 a2}; q1 is the same in all lanes of a wavefront
+                v2f w[8];
 #pragma unroll
-                for (int m = 1; m < 16; m++) a[m] = cmul2(a[m], w3_tw<SF>(L, (uint32_t)(16 * q1 * brev_bits(m, 4))));
+                for (int m = 1; m < 8; m++) w[m] = w3_tw<SF>(L, (uint32_t)(16 * q1 * brev_bits(m, 4)));
+                cmul_batch<7>(a + 1, w + 1);
+#pragma unroll
+                for (int m = 8; m < 16; m++) w[m - 8] = w3_tw<SF>(L, (uint32_t)(16 * q1 * brev_bits(m, 4)));
+                cmul_batch<8>(a + 8, w);
             }
 #pragma unroll
             for (int m = 0; m < 16; m++) pe[M2 * 8 * m] = a[m];
         }
         __syncthreads();
         // ---- pass 3 + combine ----
-        {
+        if (valid) {
             const int w = t >> 3, row = w % AR, wl = w / AR;
-            v2f out[16];
+            v2f out[16]; // the combine coefficients first (pass-3 thread order; requesting them before pass 2 costs more in registers than the latency it hides)
+#pragma unroll
+            for (int i = 0; i < 16; i++) out[i] = w3_ld2(cb, 8u * tu, (uint32_t)((g * 16 + i) * TG * 8));
 #pragma unroll
             for (int j = 0; j < G::NB; j++) {
                 const int m2 = wl * G::NB + j;
                 v2f b[M2];
 #pragma unroll
-                for (int q1 = 0; q1 < M2; q1++) b[q1] = L.data[row * SA + (q1 + M2 * m2) * 8 + r];
+                for (int q1 = 0; q1 < M2; q1++) b[q1] = data[row * SA + (q1 + M2 * m2) * 8 + r];
                 fft_inlane_dif_pk<M2>(b);
-#pragma unroll
-                for (int m = 0; m < M2; m++) out[j * M2 + m] = cmul2(b[m], cc[j * M2 + m]);
+                cmul_batch<M2>(out + j * M2, b);
             }
+            float mag[16];
+            {
+                float o32[32]; // sum over r = lane bits 0, 1, 2
 #pragma unroll
-            for (int i = 0; i < 16; i++) { // sum over r = lane bits 0, 1, 2
-                v2f s = out[i];
-                s += dpp2<kDppQuadXor1>(s);
-                s += dpp2<kDppQuadXor2>(s);
-                const float ox = s.x, oy = s.y;
-                out[i] = (v2f){ox + lane_xor<4>(ox), oy + lane_xor<4>(oy)};
+                for (int i = 0; i < 16; i++) { const float ox = out[i].x, oy = out[i].y; o32[2 * i] = ox; o32[2 * i + 1] = oy; }
+                w3_sum_r32(o32);
+#pragma unroll
+                for (int i = 0; i < 16; i++) mag[i] = o32[2 * i] * o32[2 * i] + o32[2 * i + 1] * o32[2 * i + 1]; // |X|^2: monotone in std::abs (:454)
             }
-            const int a_bin = (int)(__brev((uint32_t)(row + AR * g)) >> 28);
+            // first maximum in bin order among this thread's 16 bins: k1 = a + 16 a2 + 256 b2 with a = bitrev4(row + AR g),
+            // a2 = bitrev4(wl NB + j) = bitrev4(wl NB) + bitrev4(j): a per-thread base plus a compile-time constant per value
+            float mx = mag[0];
 #pragma unroll
-            for (int j = 0; j < G::NB; j++) {
-                const int a2 = (int)(__brev((uint32_t)(wl * G::NB + j)) >> 28);
+            for (int i = 1; i < 16; i++) mx = fmaxf(mx, mag[i]);
+            int kc = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < G::NB; j++)
 #pragma unroll
                 for (int m = 0; m < M2; m++) {
-                    const int k1 = a_bin + 16 * a2 + 256 * brev_bits(m, G::LOGM2);
-                    const v2f o = out[j * M2 + m];
-                    const float mag = o.x * o.x + o.y * o.y; // monotone in std::abs (:454)
-                    if (mag > bv || (mag == bv && k1 < bi)) { bv = mag; bi = k1; }
+                    const int kconst = 16 * brev_bits(j, 4) + 256 * brev_bits(m, G::LOGM2);
+                    kc = min(kc, mag[j * M2 + m] == mx ? kconst : 0x7fffffff);
                 }
-            }
+            const int k1 = kc + (int)(__brev((uint32_t)(row + AR * g)) >> 28) + 16 * (int)(__brev((uint32_t)(wl * G::NB)) >> 28);
+            const bool better = mx > bv || (mx == bv && k1 < bi);
+            bv = better ? mx : bv;
+            bi = better ? k1 : bi;
         }
     }
-    w3_block_argmax_first<G::WAVES>(bv, bi, ws, slot);
-    const uint32_t s = (uint32_t)bi;
-    s_out = s;
-    fine_out = 0;
-    energy_out = 0.0f;
+    float bvs[NG];
+    int bis[NG];
+    w3_group_argmax_first<SF>(bv, bi, ws, slot, grp, gwave, bvs, bis);
+#pragma unroll
+    for (int g = 0; g < NG; g++) { s_out[g] = (uint32_t)bis[g]; fine_out[g] = 0; en_out[g] = 0.0f; }
     if (want_energy) {
-        float e1[1] = {en};
-        w3_block_sum<G::WAVES, 1>(e1, ws, slot);
-        energy_out = e1[0];
+        float e1[1] = {en}, eo[NG][1];
+        w3_group_sums<SF, 1>(e1, ws, slot, grp, gwave, eo);
+#pragma unroll
+        for (int g = 0; g < NG; g++) en_out[g] = eo[g][0];
     }
     if (!want_fine) return;
     // fine_sync (:300-338) with search = max(D/4, 2) = 2 -> lags -1, 0, +1
-    const uint32_t bin_idx = (s == 0u && P.demod_mode == 2u) ? 0u : (s + (uint32_t)N - 1u) % (uint32_t)N;
-    const auto vv = (const __attribute__((address_space(1))) float *)P.up_ifreq_v + ((int)(bin_idx + 1u) * 8 + SPS);
     float cs[3] = {0.f, 0.f, 0.f};
+    if (valid) {
+        uint32_t s = s_out[0];
 #pragma unroll
-    for (int p = 0; p < PAIRS; p++) {
-        float v0[16], v1[16], v2[16];
+        for (int g = 1; g < NG; g++) s = (grp == g) ? s_out[g] : s;
+        const uint32_t bin_idx = (s == 0u && P.demod_mode == 2u) ? 0u : (s + (uint32_t)N - 1u) % (uint32_t)N;
+        // descriptor base one element before v[shift_ref + sps]: lag -1 at k = 0 reads v[-1] of that origin, and buffer offsets are unsigned
+        const w3_buf_t vb = w3_buf(w3_uniform_ptr(P.up_ifreq_v + ((int)(bin_idx + 1u) * 8 + SPS - 1)));
 #pragma unroll
-        for (int c = 0; c < 16; c++) {
-            const int n = c * CH + p * T + t;
-            const int k = (n >= 1) ? n - 1 : 1; // f is 0 for the non-existent k = -1
-            v0[c] = vv[k - 1]; v1[c] = vv[k]; v2[c] = vv[k + 1];
-        }
+        for (int p = 0; p < PAIRS; p++) {
+            const uint32_t nb = (uint32_t)(p * TG) + tu; // n inside chunk 0
+            const uint32_t k0 = 4u * (nb >= 1u ? nb - 1u : 1u); // byte offset of k = n - 1 in chunk 0 (f is 0 for the non-existent k = -1)
+            float v0[16], v1[16], v2[16];
+            v0[0] = w3_ld1(vb, k0, 0u); v1[0] = w3_ld1(vb, k0, 4u); v2[0] = w3_ld1(vb, k0, 8u); // v[k-1], v[k], v[k+1]
 #pragma unroll
-        for (int c = 0; c < 16; c++) {
-            const float fk = f[p][c];
-            cs[0] += fk * v0[c]; cs[1] += fk * v1[c]; cs[2] += fk * v2[c];
-        }
-        if (p == PAIRS - 1 && t == T - 1) { // ifreq[sps-1] = ifreq[sps-2] (:243): the duplicated tap at k = sps-1
-            const float fl = f[p][15];
-            const int k = SPS - 1;
-            cs[0] += fl * vv[k - 1]; cs[1] += fl * vv[k]; cs[2] += fl * vv[k + 1];
+            for (int c = 1; c < 16; c++) {
+                v0[c] = w3_ld1(vb, 4u * nb, (uint32_t)(c * CH * 4 - 4)); v1[c] = w3_ld1(vb, 4u * nb, (uint32_t)(c * CH * 4)); v2[c] = w3_ld1(vb, 4u * nb, (uint32_t)(c * CH * 4 + 4));
+            }
+            float fl[16];
+            if constexpr (G::LATE_F) { // second read of the window
+                const uint32_t ob = 8u * nb;
+                v2f a[16], ap[16];
+#pragma unroll
+                for (int c = 0; c < 16; c++) a[c] = w3_ld2(xb, ob, (uint32_t)(c * CH * 8));
+                ap[0] = w3_ld2(xb, (p == 0) ? (ob >= 8u ? ob - 8u : 0u) : ob - 8u, 0u);
+#pragma unroll
+                for (int c = 1; c < 16; c++) ap[c] = w3_ld2(xb, ob, (uint32_t)(c * CH * 8 - 8));
+                if (p == 0) w3_ifreq16<true>(a, ap, t == 0, fl);
+                else w3_ifreq16<false>(a, ap, false, fl);
+            }
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                const float fk = G::LATE_F ? fl[c] : f[G::LATE_F ? 0 : c];
+                cs[0] += fk * v0[c]; cs[1] += fk * v1[c]; cs[2] += fk * v2[c];
+            }
+            if (p == PAIRS - 1 && t == TG - 1) { // ifreq[sps-1] = ifreq[sps-2] (:243): the duplicated tap at k = sps-1
+                const float flast = G::LATE_F ? fl[15] : f[G::LATE_F ? 0 : 15];
+                const uint32_t ko = 4u * (uint32_t)(SPS - 1);
+                cs[0] += flast * w3_ld1(vb, ko, 0u); cs[1] += flast * w3_ld1(vb, ko, 4u); cs[2] += flast * w3_ld1(vb, ko, 8u);
+            }
         }
     }
-    w3_block_sum<G::WAVES, 3>(cs, ws, slot);
-    float mx = 0.0f;
-    int32_t lag = 0;
-    if (cs[0] > mx) { mx = cs[0]; lag = -1; }
-    if (cs[1] > mx) { mx = cs[1]; lag = 0; }
-    if (cs[2] > mx) { mx = cs[2]; lag = 1; }
-    fine_out = -lag;
+    float co[NG][3];
+    w3_group_sums<SF, 3>(cs, ws, slot, grp, gwave, co);
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        float mx = 0.0f;
+        int32_t lag = 0;
+        if (co[g][0] > mx) { mx = co[g][0]; lag = -1; }
+        if (co[g][1] > mx) { mx = co[g][1]; lag = 0; }
+        if (co[g][2] > mx) { mx = co[g][2]; lag = 1; }
+        fine_out[g] = __builtin_amdgcn_readfirstlane(-lag);
+    }
 }
 
 // copies W_N^t into LDS; all threads; the caller synchronises
@@ -343,34 +534,36 @@ __device__ __forceinline__ void w3_tables_to_lds(const DevParams &P, const W3Lds
     for (int i = threadIdx.x; i < G::NTW; i += G::T) L.tw[i] = src[i];
 }
 
-// ---- DETECT (:340-366): sums of c1 conj(c2), |c1|^2, |c2|^2 over the symbol pair at x ------------------------
+// ---- DETECT (:340-366): sums of c1 conj(c2), |c1|^2, |c2|^2 over the symbol pair at x, one window per group ----
 template <int SF>
-__device__ __forceinline__ void w3_detect_window(const float2 *__restrict__ x, W3Shared &ws, int &slot, float (&a)[4])
+__device__ __forceinline__ void w3_detect_round(const float2 *__restrict__ x, bool valid, W3Shared &ws, int &slot, float (&out)[W3Geom<SF>::NG][4])
 {
     using G = W3Geom<SF>;
     const auto xv = (const __attribute__((address_space(1))) v2f *)x;
-    const int t = threadIdx.x;
-    a[0] = a[1] = a[2] = a[3] = 0.0f;
+    const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x / G::TG), t = (int)threadIdx.x % G::TG, gwave = __builtin_amdgcn_readfirstlane(t >> 6);
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (valid) {
 #pragma unroll
-    for (int p = 0; p < G::PAIRS; p++) {
-        v2f u[16], w[16];
+        for (int p = 0; p < G::PAIRS; p++) {
+            v2f u[16], w[16];
 #pragma unroll
-        for (int c = 0; c < 16; c++) u[c] = xv[c * G::CH + p * G::T + t];
+            for (int c = 0; c < 16; c++) u[c] = xv[c * G::CH + p * G::TG + t];
 #pragma unroll
-        for (int c = 0; c < 16; c++) w[c] = xv[G::SPS + c * G::CH + p * G::T + t];
+            for (int c = 0; c < 16; c++) w[c] = xv[G::SPS + c * G::CH + p * G::TG + t];
 #pragma unroll
-        for (int c = 0; c < 16; c++) {
-            const v2f c1 = u[c], c2 = w[c];
-            a[0] += c1.x * c2.x + c1.y * c2.y;
-            a[1] += c1.y * c2.x - c1.x * c2.y;
-            a[2] += c1.x * c1.x + c1.y * c1.y;
-            a[3] += c2.x * c2.x + c2.y * c2.y;
+            for (int c = 0; c < 16; c++) {
+                const v2f c1 = u[c], c2 = w[c];
+                a[0] += c1.x * c2.x + c1.y * c2.y;
+                a[1] += c1.y * c2.x - c1.x * c2.y;
+                a[2] += c1.x * c1.x + c1.y * c1.y;
+                a[3] += c2.x * c2.x + c2.y * c2.y;
+            }
         }
     }
-    w3_block_sum<G::WAVES, 4>(a, ws, slot);
+    w3_group_sums<SF, 4>(a, ws, slot, grp, gwave, out);
 }
 
-// ---- SYNC (:770-783, detect_upchirp :392-413) -----------------------------------------------------------------
+// ---- SYNC (:770-783, detect_upchirp :392-413), all threads of the workgroup together --------------------------
 // C[i] = sum_{k<n} f[i+k] u[k], n = sps-1, i < sps, f = ifreq of x[0 .. 2 sps).  d_upchirp_ifreq is the line a + b k (up
 // to float noise ~1e-5 of the peak), so C[i] = a S0[i] + b S1[i] with S0 = sum_k f[i+k], S1 = sum_k k f[i+k], both from
 // prefix sums of f and (t - sps) f in double.  Thread tau owns the LEN shifts i0 = LEN tau ..: it computes f on
@@ -380,10 +573,10 @@ struct W3SyncOut { float bv; int bi; int slot; };
 template <int SF>
 __device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double sync_b, const float2 *__restrict__ x, W3Shared *wsp, int slot)
 {
-    W3Shared &ws = *wsp;
     using G = W3Geom<SF>;
-    constexpr int SPS = G::SPS, LEN = G::LEN, WAVES = G::WAVES;
+    constexpr int SPS = G::SPS, LEN = G::LEN, WAVES = G::T / 64;
     constexpr int n = SPS - 1;
+    W3Shared &ws = *wsp;
     const auto xv = (const __attribute__((address_space(1))) v2f *)x;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int i0 = t * LEN;
@@ -451,86 +644,104 @@ __device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double syn
         s0 += fin - fout;
         s1 += (double)n * fin - s0;
     }
-    __syncthreads(); // dred is free again
-    w3_block_argmax_first<WAVES>(bv, bi, ws, slot);
+    // first maximum over the workgroup
+    float *red = ws.red[slot][0];
+    slot ^= 1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { red[wave] = bv; ((int *)red)[32 + wave] = bi; }
+    __syncthreads();
+    bv = red[0]; bi = ((int *)red)[32];
+    for (int w = 1; w < WAVES; w++) {
+        const float ov = red[w];
+        const int oi = ((int *)red)[32 + w];
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
     return W3SyncOut{bv, bi, slot};
 }
 
-// ---- FIND_SFD (:385-390, :283-298, :801-803) ------------------------------------------------------------------
+// ---- FIND_SFD (:385-390, :283-298, :801-803), one window per group --------------------------------------------
 // Pearson correlation of the window's ifreq with the ideal downchirp ifreq (one pass); for an upchirp (c < -0.97)
-// fine_sync(-1, 4 D) over the 63 lags in closed form (see w2_sfd_window for the derivation).
-struct W3SfdOut { float c; int32_t fine; int slot; };
+// fine_sync(-1, 4 D) over the 63 lags in closed form (see w2_sfd_window for the derivation).  Results of all groups
+// come back packed: c[g] and fine[g].
+struct W3SfdOut { float c[4]; int32_t fine[4]; int slot; };
 struct W3SfdArgs { const float *down_ifreq, *up_ifreq_v; float down_ifreq_avg, down_ifreq_sd, down_ifreq_dsum; double sync_a, sync_b; };
 template <int SF>
-__device__ __attribute__((noinline)) W3SfdOut w3_sfd_window(W3SfdArgs P, const float2 *__restrict__ x, W3Shared *wsp, int slot)
+__device__ __attribute__((noinline)) W3SfdOut w3_sfd_round(W3SfdArgs P, const float2 *__restrict__ x, int valid_i, W3Shared *wsp, int slot)
 {
-    W3Shared &ws = *wsp;
     using G = W3Geom<SF>;
-    constexpr int SPS = G::SPS, T = G::T, CH = G::CH, PAIRS = G::PAIRS, WAVES = G::WAVES;
-    const auto xv = (const __attribute__((address_space(1))) v2f *)x;
-    const auto ddv = (const __attribute__((address_space(1))) float *)P.down_ifreq;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    constexpr int SPS = G::SPS, TG = G::TG, CH = G::CH, PAIRS = G::PAIRS, GW = G::GW, NG = G::NG;
+    W3Shared &ws = *wsp;
+    const bool valid = valid_i != 0;
+    const w3_buf_t xb = w3_buf(w3_uniform_ptr(x)), ddb = w3_buf(P.down_ifreq);
+    const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x / TG), t = (int)threadIdx.x % TG, lane = t & 63, gwave = __builtin_amdgcn_readfirstlane(t >> 6);
     float a3[3] = {0.f, 0.f, 0.f};
     double g0 = 0.0, g1 = 0.0;
     float f_first = 0.0f, f_last = 0.0f; // chunk 0 of pair 0, chunk 15 of the last pair
+    if (valid) {
 #pragma unroll
-    for (int p = 0; p < PAIRS; p++) {
-        const int base = p * T + t;
-        v2f a[16];
-        float dd[16], f[16];
+        for (int p = 0; p < PAIRS; p++) {
+            const int base = p * TG + t;
+            const uint32_t ob = 8u * (uint32_t)base;
+            v2f a[16], ap[16];
+            float dd[16], f[16];
 #pragma unroll
-        for (int c = 0; c < 16; c++) a[c] = xv[c * CH + base];
-        const int bi = (lane & 15) * CH + p * T + 64 * wave - 1;
-        const v2f bnd = xv[bi < 0 ? 0 : bi];
+            for (int c = 0; c < 16; c++) a[c] = w3_ld2(xb, ob, (uint32_t)(c * CH * 8));
+            ap[0] = w3_ld2(xb, (p == 0) ? (ob >= 8u ? ob - 8u : 0u) : ob - 8u, 0u);
 #pragma unroll
-        for (int c = 0; c < 16; c++) { const int k = c * CH + base - 1; dd[c] = ddv[k < 0 ? 0 : k]; }
-        const float bnd_xf = bnd.x, bnd_yf = bnd.y; // (scalars first, as in w3_demod_symbol)
-        const int bnd_xi = __builtin_bit_cast(int, bnd_xf), bnd_yi = __builtin_bit_cast(int, bnd_yf);
+            for (int c = 1; c < 16; c++) ap[c] = w3_ld2(xb, ob, (uint32_t)(c * CH * 8 - 8));
+            dd[0] = w3_ld1(ddb, base >= 1 ? 4u * (uint32_t)(base - 1) : 0u, 0u);
 #pragma unroll
-        for (int c = 0; c < 16; c += 2) {
-            const float bx0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bnd_xi, c));
-            const float by0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bnd_yi, c));
-            const float bx1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bnd_xi, c + 1));
-            const float by1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bnd_yi, c + 1));
-            const v2f r0 = dpp2<kDppWaveRor1>(a[c]), r1 = dpp2<kDppWaveRor1>(a[c + 1]);
-            const v2f p0 = (lane == 0) ? (v2f){bx0, by0} : r0, p1 = (lane == 0) ? (v2f){bx1, by1} : r1;
-            const v2f fp = ifreq_prod_pk(p0, a[c], p1, a[c + 1]);
-            f[c] = (c == 0 && p == 0 && t == 0) ? 0.0f : fp.x;
-            f[c + 1] = fp.y;
+            for (int c = 1; c < 16; c++) dd[c] = w3_ld1(ddb, 4u * (uint32_t)base, (uint32_t)(c * CH * 4 - 4));
+            if (p == 0) w3_ifreq16<true>(a, ap, t == 0, f);
+            else w3_ifreq16<false>(a, ap, false, f);
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                const float fk = f[c];
+                const float d = dd[c] - P.down_ifreq_avg;
+                a3[0] += fk; a3[1] += fk * fk; a3[2] += fk * d; // f is 0 for the non-existent k = -1
+                const int k = c * CH + base - 1;
+                g0 += (double)fk; g1 += (double)k * (double)fk;
+            }
+            if (p == 0) f_first = f[0];
+            if (p == PAIRS - 1) f_last = f[15];
         }
-#pragma unroll
-        for (int c = 0; c < 16; c++) {
-            const float fk = f[c];
-            const float d = dd[c] - P.down_ifreq_avg;
-            a3[0] += fk; a3[1] += fk * fk; a3[2] += fk * d; // f is 0 for the non-existent k = -1
-            const int k = c * CH + base - 1;
-            g0 += (double)fk; g1 += (double)k * (double)fk;
-        }
-        if (p == 0) f_first = f[0];
-        if (p == PAIRS - 1) f_last = f[15];
     }
-    w3_block_sum<WAVES, 3>(a3, ws, slot);
-    const float nf = (float)(SPS - 1);
-    const float average = a3[0] / nf;
-    const float var = fmaxf(a3[1] / nf - average * average, 0.0f);
-    const float sd = sqrtf(var) * P.down_ifreq_sd;
-    const float c = (a3[2] - average * P.down_ifreq_dsum) / sd / nf;
-    if (!(c < -0.97f) || c > 0.96f) return W3SfdOut{c, 0, slot}; // (uniform)
+    float a3o[NG][3];
+    w3_group_sums<SF, 3>(a3, ws, slot, grp, gwave, a3o);
+    W3SfdOut R;
+    bool any_up = false;
+#pragma unroll
+    for (int g = 0; g < 4; g++) { R.c[g] = 0.0f; R.fine[g] = 0; }
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        const float nf = (float)(SPS - 1);
+        const float average = a3o[g][0] / nf;
+        const float var = fmaxf(a3o[g][1] / nf - average * average, 0.0f);
+        const float sd = sqrtf(var) * P.down_ifreq_sd;
+        R.c[g] = (a3o[g][2] - average * P.down_ifreq_dsum) / sd / nf;
+        any_up = any_up || (R.c[g] < -0.97f);
+    }
+    R.slot = slot;
+    if (!any_up) return R; // (uniform)
     // fine_sync(-1, 32): c_i = sum_{k<sps} fe[k] v[sps + i + k], i = -31 .. 31, fe[sps-1] = fe[sps-2]
-    if (t == T - 1) { g0 += (double)f_last; g1 += (double)(SPS - 1) * (double)f_last; } // duplicated last tap (:243)
+    if (valid && t == TG - 1) { g0 += (double)f_last; g1 += (double)(SPS - 1) * (double)f_last; } // duplicated last tap (:243)
     g0 = w3_wave_sum_d(g0); g1 = w3_wave_sum_d(g1);
-    double *dr = ws.dred[slot & 1];
-    if (lane == 0) { dr[wave * 2] = g0; dr[wave * 2 + 1] = g1; }
+    double *dr = ws.dred[slot & 1] + grp * 18;
+    if (lane == 0) { dr[gwave] = g0; dr[GW + gwave] = g1; }
     // head[k] = fe[k], k < 32 (threads 1 .. 32 of chunk 0); tail[q] = fe[sps-1-q], q <= 32 (the last threads of chunk 15)
-    float *scr = ws.sfd;
+    float *scr = ws.sfd[grp];
     if (t >= 1 && t <= 32) scr[t - 1] = f_first;
-    if (t >= T - 32) scr[32 + 1 + (T - 1 - t)] = f_last;
-    if (t == T - 1) scr[32] = f_last;
+    if (t >= TG - 32) scr[32 + 1 + (TG - 1 - t)] = f_last;
+    if (t == TG - 1) scr[32] = f_last;
     __syncthreads();
-    double G0 = 0.0, G1 = 0.0;
-    for (int w = 0; w < WAVES; w++) { G0 += dr[w * 2]; G1 += dr[w * 2 + 1]; }
-    int32_t lag = 0;
-    if (wave == 0) {
+    if (gwave == 0) {
+        double G0 = 0.0, G1 = 0.0;
+        for (int w = 0; w < GW; w++) { G0 += dr[w]; G1 += dr[GW + w]; }
         const int i = lane - 31; // this lane's lag
         float ps = scr[lane];
 #pragma unroll
@@ -556,298 +767,416 @@ __device__ __attribute__((noinline)) W3SfdOut w3_sfd_window(W3SfdArgs P, const f
             const int oi = __shfl_xor(li, o, 64);
             if (ov > c_i || (ov == c_i && oi < li)) { c_i = ov; li = oi; }
         }
-        lag = (c_i > 0.0f) ? li - 31 : 0;
-        if (lane == 0) ws.ibc[0] = lag;
+        const int32_t lag = (c_i > 0.0f) ? li - 31 : 0;
+        if (lane == 0) ws.ibc[grp] = lag;
     }
     __syncthreads();
-    return W3SfdOut{c, -__builtin_amdgcn_readfirstlane(ws.ibc[0]), slot};
+#pragma unroll
+    for (int g = 0; g < NG; g++) R.fine[g] = (R.c[g] < -0.97f) ? -ws.ibc[g] : 0;
+    return R;
+}
+
+// ---- thread-0 bookkeeping ---------------------------------------------------------------------------------------
+// everything demodulate() / work() do once the bin is known (:506-529, :826-886), explicit or implicit header.
+// Returns true when the payload is complete: the caller requests the workgroup-wide finalisation round.
+__device__ __forceinline__ bool w3_post_symbol(const DevParams &P, W2State &S, Shared &sh, bool do_demod, uint32_t bin_idx, bool is_first)
+{
+    bool block_done = false;
+    if (do_demod) {
+        const bool reduced = is_first || P.reduced_rate; // :495
+        if (reduced) bin_idx = (uint32_t)(lroundf((float)bin_idx / 4.0f) % (long)P.nbins_hdr); // :507-509
+        const uint32_t word = bin_idx ^ (bin_idx >> 1u); // :512
+        const uint32_t need = 4u + (is_first ? 4u : S.cr); // :521
+        if (S.n_words < 16u) sh.words[S.n_words] = word;
+        S.n_words++;
+        S.n_sym++;
+        if (S.n_words == need) {
+            const uint32_t ppm = reduced ? P.sf - 2u : P.sf;
+            uint32_t tmp = S.n_cw;
+            deinterleave_block(sh, need, ppm, tmp);
+            S.n_cw = (S.n_cw + ppm <= (uint32_t)kMaxCodewords) ? S.n_cw + ppm : (uint32_t)kMaxCodewords;
+            S.n_words = 0;
+            block_done = true;
+        }
+    }
+    if (is_first) {
+        if (block_done) {
+            if (P.implicit) {
+                S.payload_symbols = 1; // :829
+            } else { // decode(true) and header parse (:831-847)
+                uint8_t hA[3], hB[3], h0[3] = {0, 0, 0};
+                decode_header_bytes(sh, S.n_cw, 2, hA);
+                decode_header_bytes(sh, S.n_cw, 1, hB);
+                const uint8_t *use = (S.cr >= 3u) ? hA : (S.cr >= 1u ? hB : h0);
+                S.phdr[0] = use[0]; S.phdr[1] = use[1]; S.phdr[2] = use[2];
+                S.att_ambig = (uint32_t)((hA[0] != hB[0]) || (hA[1] != hB[1]) || (hA[2] != hB[2]));
+                const uint32_t rem = S.n_cw > 5u ? S.n_cw - 5u : 0u; // erase the 5 header codewords (:632)
+                for (uint32_t i = 0; i < rem; i++) sh.cw[i] = sh.cw[i + 5u];
+                S.n_cw = rem;
+                if ((S.phdr[1] >> 5) > 4) S.phdr[1] = (uint8_t)((S.phdr[1] & 0x1f) | (4u << 5)); // :834-835
+                S.cr = S.phdr[1] >> 5;
+                S.has_crc = (S.phdr[1] >> 4) & 1u;
+                S.payload_length = (uint32_t)S.phdr[0] + 2u * S.has_crc; // MAC_CRC_SIZE (:838)
+                const uint32_t redundancy = P.reduced_rate ? 2u : 0u; // :842-847
+                const int symbols_per_block = (int)S.cr + 4;
+                const float bits_needed = (float)S.payload_length * 8.0f;
+                const float symbols_needed = bits_needed * ((float)symbols_per_block / 4.0f) / (float)(P.sf - redundancy);
+                const int blocks_needed = (int)ceilf(symbols_needed / (float)symbols_per_block);
+                S.payload_symbols = blocks_needed * symbols_per_block;
+            }
+            S.state = kDecodePayload;
+        }
+        return false;
+    }
+    if (block_done && !P.implicit) S.payload_symbols -= (int32_t)(4u + S.cr); // :866-867
+    if (S.payload_symbols <= 0) { // :870-881
+        uint32_t n_bytes;
+        if (S.cr >= 3u) n_bytes = (uint32_t)ceilf((float)S.n_cw * 4.0f / (4.0f + (float)S.cr)); // :658
+        else n_bytes = (S.n_cw + 1u) / 2u;
+        if (n_bytes > (uint32_t)(kMaxCodewords / 2 + 8)) n_bytes = kMaxCodewords / 2 + 8;
+        S.fin_n_bytes = n_bytes;
+        S.fin_plen = S.payload_length > 257u ? 257u : S.payload_length;
+        return true;
+    }
+    return false;
 }
 
 // ---- the kernel -----------------------------------------------------------------------------------------------
+// ROUNDS.  The decoder state (W2State, as in walker2) lives in LDS and belongs to thread 0.  Every round starts from a
+// PLAN (position, what to evaluate, how many windows): in DETECT, FIND_SFD and DECODE_* the NG groups evaluate the NG
+// upcoming windows pos + g sps (zero drift assumed) - the results come back uniform in every thread - and thread 0
+// replays the reference's per-call logic over them in order on a register copy of the state, stopping at the first
+// outcome that invalidates the later windows (a trigger, a state change, d_fine_sync != 0, a loop-top check, the end of
+// the data); it then writes the state back and the next plan.  The accepted sequence is exactly the serial one.  Keeping
+// the state out of the other wavefronts' registers is what lets the demodulator run without spills.
 template <int SF>
 __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg &C)
 {
     using G = W3Geom<SF>;
     constexpr uint32_t sps = G::SPS;
-    constexpr int T = G::T;
+    constexpr int T = G::T, NG = G::NG;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const W3Lds<SF> L = w3_carve<SF>(smem);
     W3Shared &ws = *L.ws;
     Shared &sh = ws.sh;
+    W2State &S = ws.st;
 
     const uint32_t jid = blockIdx.x;
     if (jid >= C.n_jobs) return;
-    const Job job = C.jobs[jid];
+    Job job = C.jobs[jid];             // (phase 1 rewrites start / limits: the job carries on as the next segment's probe)
+    uint32_t rec_cap = C.recs_per_job; // ... with what is left of the attempt-record capacity
     const float2 *__restrict__ X = C.iq + job.stream_off;
     const int64_t n_items = (int64_t)job.stream_len;
     AttemptRec *recs = C.recs + (size_t)jid * C.recs_per_job;
     StepRec *trace = C.trace ? C.trace + (size_t)jid * C.trace_cap : nullptr;
     const bool t0 = threadIdx.x == 0;
+    const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x / G::TG);
     int slot = 0;
+    const W3DemodArgs DA{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode};
 
     w3_tables_to_lds<SF>(P, L);
-    __syncthreads();
 
-    // uniform (replicated) decoder state -- decoder_impl.h:70-123
-    int32_t state = kDetect;
-    int64_t pos = job.start;
-    uint32_t corr_fails = 0, cr = job.cr_prev, has_crc = P.ctor_crc;
-    int32_t payload_symbols = 0;
-    uint32_t payload_length = 0, n_words = 0, n_cw = 0, n_sym = 0;
-    float energy_threshold = 0.0f;
-    uint8_t phdr0 = 0, phdr1 = (uint8_t)((P.ctor_cr << 5) | (P.ctor_crc << 4)), phdr2 = 0;
-    uint32_t n_att = 0, npush = 0, n_steps = 0, stop_reason = 0;
-    float push_tail[4] = {0.f, 0.f, 0.f, 0.f};
-    int64_t att_start = pos, att_trig = -1, att_hdr = -1;
-    uint32_t att_cr_prev = cr, att_ambig = 0;
-    bool in_attempt = false, frame_ok = false;
-
-    auto end_step = [&](int32_t st_in, int32_t consumed, int32_t step_bin, int32_t fine, float step_val, long long t_start) -> bool {
-        if (trace && t0 && n_steps < C.trace_cap) {
-            StepRec &s = trace[n_steps];
-            s.state = st_in; s.consumed = consumed; s.pos = pos; s.bin = step_bin; s.fine = fine; s.value = step_val;
-            s.stream = job.stream_id; s.cycles = (uint32_t)(clock64() - t_start); s.pad = 0;
-        }
-        n_steps++;
-        pos += consumed;
-        if (in_attempt && state == kDetect) { // attempt finished: frame published, or sync lost
-            if (t0) {
-                AttemptRec &r = recs[n_att];
-                r.status = frame_ok ? kAttemptFrame : kAttemptLostSync;
-                if (!frame_ok) r.frame_len = 0;
-                r.start_pos = att_start; r.trig_pos = att_trig; r.hdr_pos = att_hdr; r.end_pos = pos;
-                r.npush = npush;
-                for (int i = 0; i < 4; i++) r.push_tail[i] = push_tail[i];
-                r.cr_prev = att_cr_prev; r.hdr_ambig = att_ambig; r.n_symbols = n_sym;
-            }
-            n_att++;
-            in_attempt = false;
-            frame_ok = false;
-            npush = 0;
-            att_start = pos;
-        } else if (in_attempt && job.stop_at_header && state == kDecodeHeader) {
-            stop_reason = 3;
-            return true;
-        }
-        return false;
-    };
-
-    // everything demodulate() / work() do after the bin is known (:506-529, :826-886)
-    auto post_symbol = [&](bool do_demod, uint32_t bin_idx, bool is_first) {
-        bool block_done = false;
-        if (do_demod) {
-            const bool reduced = is_first || P.reduced_rate; // :495
-            if (reduced) bin_idx = (uint32_t)(lroundf((float)bin_idx / 4.0f) % (long)P.nbins_hdr); // :507-509
-            const uint32_t word = bin_idx ^ (bin_idx >> 1u); // :512
-            const uint32_t need = 4u + (is_first ? 4u : cr); // :521
-            if (t0 && n_words < 16u) sh.words[n_words] = word;
-            n_words++;
-            n_sym++;
-            if (n_words == need) {
-                const uint32_t ppm = reduced ? P.sf - 2u : P.sf;
-                if (t0) { uint32_t tmp = n_cw; deinterleave_block(sh, need, ppm, tmp); }
-                n_cw = (n_cw + ppm <= (uint32_t)kMaxCodewords) ? n_cw + ppm : (uint32_t)kMaxCodewords;
-                n_words = 0;
-                block_done = true;
-            }
-        }
-        if (is_first) {
-            if (block_done) {
-                if (P.implicit) {
-                    payload_symbols = 1; // :829
-                } else { // decode(true) and header parse (:831-847)
-                    __syncthreads();
-                    if (t0) {
-                        uint8_t hA[3], hB[3], h0[3] = {0, 0, 0};
-                        decode_header_bytes(sh, n_cw, 2, hA);
-                        decode_header_bytes(sh, n_cw, 1, hB);
-                        const uint8_t *use = (cr >= 3u) ? hA : (cr >= 1u ? hB : h0);
-                        sh.hdr[0] = use[0]; sh.hdr[1] = use[1]; sh.hdr[2] = use[2];
-                        sh.hdr[3] = (uint8_t)((hA[0] != hB[0]) || (hA[1] != hB[1]) || (hA[2] != hB[2]));
-                        const uint32_t rem = n_cw > 5u ? n_cw - 5u : 0u; // erase the 5 header codewords (:632)
-                        for (uint32_t i = 0; i < rem; i++) sh.cw[i] = sh.cw[i + 5u];
-                    }
-                    __syncthreads();
-                    n_cw = n_cw > 5u ? n_cw - 5u : 0u;
-                    { // (uniform: keeps the state machine in scalar registers)
-                        const uint32_t hw = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t *>(sh.hdr));
-                        phdr0 = (uint8_t)hw; phdr1 = (uint8_t)(hw >> 8); phdr2 = (uint8_t)(hw >> 16);
-                        att_ambig = hw >> 24;
-                    }
-                    if ((phdr1 >> 5) > 4) phdr1 = (uint8_t)((phdr1 & 0x1f) | (4u << 5)); // :834-835
-                    cr = phdr1 >> 5;
-                    has_crc = (phdr1 >> 4) & 1u;
-                    payload_length = (uint32_t)phdr0 + 2u * has_crc; // MAC_CRC_SIZE (:838)
-                    const uint32_t redundancy = P.reduced_rate ? 2u : 0u; // :842-847
-                    const int symbols_per_block = (int)cr + 4;
-                    const float bits_needed = (float)payload_length * 8.0f;
-                    const float symbols_needed = bits_needed * ((float)symbols_per_block / 4.0f) / (float)(P.sf - redundancy);
-                    const int blocks_needed = (int)ceilf(symbols_needed / (float)symbols_per_block);
-                    payload_symbols = blocks_needed * symbols_per_block;
-                }
-                state = kDecodePayload;
-            }
-        } else {
-            if (block_done && !P.implicit) payload_symbols -= (int32_t)(4u + cr); // :866-867
-            if (payload_symbols <= 0) { // :870-881
-                uint32_t n_bytes;
-                if (cr >= 3u) n_bytes = (uint32_t)ceilf((float)n_cw * 4.0f / (4.0f + (float)cr)); // :658
-                else n_bytes = (n_cw + 1u) / 2u;
-                if (n_bytes > (uint32_t)(kMaxCodewords / 2 + 8)) n_bytes = kMaxCodewords / 2 + 8;
-                decode_payload_bytes(sh, n_cw, cr, n_bytes);
-                const uint32_t plen = payload_length > 257u ? 257u : payload_length;
-                AttemptRec &r = recs[n_att];
-                for (uint32_t i = threadIdx.x; i < plen; i += (uint32_t)T) r.frame[3u + i] = (i < n_bytes) ? sh.dec[i] : 0;
-                if (t0) {
-                    r.frame[0] = phdr0; r.frame[1] = phdr1; r.frame[2] = phdr2; // d_phdr (:600)
-                    r.frame_len = 3u + plen;
-                }
-                frame_ok = true;
-                state = kDetect;
-                n_words = 0; n_cw = 0;
-            }
-        }
-    };
-
-    while (true) {
-        if (state == kDetect && !in_attempt) {
-            if (pos >= job.scan_limit) { stop_reason = 0; break; }
-            if (n_att >= C.recs_per_job) { stop_reason = 2; break; }
-            if (job.max_attempts && n_att >= job.max_attempts) { stop_reason = 3; break; }
-        }
-        if (pos + 2 * (int64_t)sps > n_items) { stop_reason = 1; break; } // set_output_multiple(2*sps) (:91)
-        const float2 *__restrict__ x = X + pos;
-        int32_t consumed = 0, fine = 0, step_bin = -1; // d_fine_sync = 0 on every call (:749)
-        float step_val = 0.0f;
-        const int32_t st_in = state;
-        const long long t_start = trace ? clock64() : 0;
-
-        switch (state) {
-        case kDetect: { // :752-768, detect_preamble_autocorr :340-366
-            float a[4];
-            w3_detect_window<SF>(x, ws, slot, a);
-            energy_threshold = a[3] / 2.0f; // :357
-            const float pushed = a[2] / (float)sps; // d_pwr_queue.push_back (:360)
-            if (npush >= 4u) { push_tail[0] = push_tail[1]; push_tail[1] = push_tail[2]; push_tail[2] = push_tail[3]; push_tail[3] = pushed; }
-            else {
-                const uint32_t k = npush;
-                if (k == 0u) push_tail[0] = pushed; else if (k == 1u) push_tail[1] = pushed; else if (k == 2u) push_tail[2] = pushed; else push_tail[3] = pushed;
-            }
-            npush++;
-            const float s = sqrtf(a[2] * a[3]);
-            const float autocorr = hypotf(a[0] / s, a[1] / s); // :363
-            step_val = autocorr;
-            if (autocorr >= 0.90f) { // :755
-                corr_fails = 0u;
-                state = kSync;
-                in_attempt = true;
-                att_trig = pos; att_hdr = -1; att_cr_prev = cr; att_ambig = 0; n_sym = 0;
-            } else {
-                consumed = (int32_t)sps;
-            }
-            break;
-        }
-        case kSync: { // :770-783
-            const W3SyncOut so = w3_sync<SF>(P.sync_a, P.sync_b, x, &ws, slot);
-            slot = __builtin_amdgcn_readfirstlane(so.slot);
-            step_val = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, so.bv)));
-            const int sbi = __builtin_amdgcn_readfirstlane(so.bi);
-            consumed = (sbi == 0x7fffffff) ? 0 : sbi; // `int i = 0` stays when nothing exceeds 0 (:771)
-            state = kFindSfd;
-            break;
-        }
-        case kFindSfd: { // :785-818
-            const W3SfdOut fo = w3_sfd_window<SF>(W3SfdArgs{P.down_ifreq, P.up_ifreq_v, P.down_ifreq_avg, P.down_ifreq_sd, P.down_ifreq_dsum, P.sync_a, P.sync_b}, x, &ws, slot);
-            slot = __builtin_amdgcn_readfirstlane(fo.slot);
-            const float c = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fo.c)));
-            const int32_t fs = __builtin_amdgcn_readfirstlane(fo.fine);
-            step_val = c;
-            if (c > 0.96f) { // :792
-                state = kPause;
-            } else {
-                if (c < -0.97f) fine = fs; // :801-803
-                else corr_fails++;
-                if (corr_fails > 4u) state = kDetect; // :808-809
-            }
-            consumed = (int32_t)sps + fine; // :816
-            break;
-        }
-        case kPause: // :820-824
-            state = kDecodeHeader;
-            consumed = (int32_t)(sps + P.delay_after_sync);
-            att_hdr = pos + consumed;
-            break;
-        case kDecodeHeader:
-        case kDecodePayload: { // :826-886, demodulate :493-529
-            const bool is_first = state == kDecodeHeader;
-            const bool want_energy = !is_first && P.implicit; // determine_energy (:861-864)
-            uint32_t s;
-            int32_t fs;
-            float en;
-            w3_demod_symbol<SF>(P, L, x, want_energy, slot, s, fs, en);
-            bool do_demod = true;
-            if (want_energy && en < energy_threshold) { payload_symbols = 0; payload_length = n_cw / 2u; do_demod = false; }
-            uint32_t bin_idx = 0;
-            if (do_demod) { // :500, bin_idx = (s-1) mod N; compat keeps the s==0 -> 0 quirk of the gradient path
-                bin_idx = (s == 0u && P.demod_mode == 2u) ? 0u : (s + P.nbins - 1u) % P.nbins;
-                step_bin = (int32_t)bin_idx;
-                fine = fs; // :501-502
-            }
-            post_symbol(do_demod, bin_idx, is_first);
-            consumed = (int32_t)sps + fine; // :856,:883
-            break;
-        }
+    // plan for the next round from the TRUE state (thread 0 only)
+    auto plan_from = [&](W2State &St, W2Plan &pl) {
+        pl.buf = 0; pl.resolve_prev = 0; pl.n_win = NG; pl.pos = St.pos; pl.prev_n = 0; pl.pad = 0;
+        if (!St.done) (void)w2_pre_step(St, job, rec_cap, sps);
+        if (St.done) { pl.mode = kPlanExit; return; }
+        if (St.fin_pending) { pl.mode = kPlanFinalize; return; }
+        switch (St.state) {
+        case kDetect: pl.mode = kPlanDetect; break;
+        case kSync: pl.mode = kPlanSync; break;
+        case kFindSfd: pl.mode = kPlanSfd; break;
+        case kPause: pl.mode = kPlanPause; break;
         default:
-            consumed = (int32_t)sps;
+            pl.mode = kPlanDecode;
+            if (St.state == kDecodePayload && !P.implicit) { // symbols left in the packet (:866-870)
+                const int32_t rem = St.payload_symbols - (int32_t)St.n_words;
+                pl.n_win = rem < NG ? (rem > 0 ? rem : 1) : NG;
+            }
             break;
         }
-        if (end_step(st_in, consumed, step_bin, fine, step_val, t_start)) break;
+    };
+
+    for (int phase = 0; phase < 2; phase++) {
+    if (t0) {
+        S = W2State{};
+        S.state = kDetect; S.pos = job.start; S.cr = job.cr_prev; S.has_crc = P.ctor_crc;
+        S.phdr[1] = (uint8_t)((P.ctor_cr << 5) | (P.ctor_crc << 4));
+        S.att_start = job.start; S.att_trig = -1; S.att_hdr = -1; S.att_cr_prev = job.cr_prev;
+        if (phase == 0) ws.stats = W2Stats{};
+        ws.stats.prev_state = -1;
+        plan_from(S, ws.plan[0]);
     }
 
-    if (in_attempt && n_att < C.recs_per_job && t0) {
-        AttemptRec &r = recs[n_att];
-        r.status = (stop_reason == 3u) ? kAttemptAtHeader : kAttemptOutOfData;
-        r.start_pos = att_start; r.trig_pos = att_trig; r.hdr_pos = att_hdr; r.end_pos = pos;
-        r.npush = npush;
-        for (int i = 0; i < 4; i++) r.push_tail[i] = push_tail[i];
-        r.cr_prev = att_cr_prev; r.hdr_ambig = att_ambig; r.n_symbols = n_sym; r.frame_len = 0;
+    for (uint32_t it = 0;; it++) {
+        __syncthreads(); // plan[it & 1] and everything thread 0 wrote are visible; plan[(it + 1) & 1] is free
+        const W2Plan &pl_in = ws.plan[it & 1u];
+        const uint64_t pl_pp = (uint64_t)pl_in.pos;
+        const int64_t pos = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(pl_pp >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)pl_pp));
+        const int32_t plan_mode = __builtin_amdgcn_readfirstlane(pl_in.mode), plan_n_win = __builtin_amdgcn_readfirstlane(pl_in.n_win);
+        W2Plan &next = ws.plan[(it + 1u) & 1u];
+        if (plan_mode == kPlanExit) break;
+        const long long t_start = clock64();
+        if (t0) {
+            W2Stats &Q = ws.stats;
+            const int sidx = plan_mode == kPlanDetect ? 0 : plan_mode == kPlanSync ? 1 : plan_mode == kPlanSfd ? 2 : plan_mode == kPlanPause ? 3 : 5;
+            if (Q.prev_state >= 0) { Q.cyc[Q.prev_state] += (uint32_t)((t_start - Q.prev_t) >> 6); Q.rounds[Q.prev_state]++; }
+            Q.prev_state = sidx; Q.prev_t = t_start;
+        }
+        const int64_t gpos = pos + (int64_t)grp * sps;
+        const bool gvalid = gpos + 2 * (int64_t)sps <= n_items; // this group's window lies inside the data (:91)
+        const float2 *__restrict__ xg = X + (gvalid ? gpos : pos);
+
+        if (plan_mode == kPlanDetect) { // :752-768, detect_preamble_autocorr :340-366
+            float a[NG][4];
+            w3_detect_round<SF>(xg, gvalid, ws, slot, a);
+            if (t0) {
+                W2State St = S;
+                for (int g = 0; g < NG; g++) {
+                    if (g > 0 && (St.state != kDetect || !w2_pre_step(St, job, rec_cap, sps))) break;
+                    float a0 = a[0][0], a1 = a[0][1], a2 = a[0][2], a3 = a[0][3];
+#pragma unroll
+                    for (int q = 1; q < NG; q++) if (g == q) { a0 = a[q][0]; a1 = a[q][1]; a2 = a[q][2]; a3 = a[q][3]; }
+                    St.energy_threshold = a3 / 2.0f; // :357
+                    const float pushed = a2 / (float)sps; // d_pwr_queue.push_back (:360)
+                    if (St.npush >= 4u) { St.push_tail[0] = St.push_tail[1]; St.push_tail[1] = St.push_tail[2]; St.push_tail[2] = St.push_tail[3]; St.push_tail[3] = pushed; }
+                    else {
+                        const uint32_t k = St.npush;
+                        if (k == 0u) St.push_tail[0] = pushed; else if (k == 1u) St.push_tail[1] = pushed; else if (k == 2u) St.push_tail[2] = pushed; else St.push_tail[3] = pushed;
+                    }
+                    St.npush++;
+                    const float sq = sqrtf(a2 * a3);
+                    const float autocorr = hypotf(a0 / sq, a1 / sq); // :363
+                    int32_t consumed = 0;
+                    if (autocorr >= 0.90f) { // :755
+                        St.corr_fails = 0u;
+                        St.state = kSync;
+                        St.in_attempt = 1;
+                        St.att_trig = St.pos; St.att_hdr = -1; St.att_cr_prev = St.cr; St.att_ambig = 0; St.n_sym = 0;
+                    } else {
+                        consumed = (int32_t)sps;
+                    }
+                    w2_end_step(St, job, C, recs, trace, kDetect, consumed, -1, 0, autocorr, t_start);
+                    if (St.done) break;
+                }
+                W2Plan np;
+                plan_from(St, np);
+                next = np; S = St;
+            }
+            continue;
+        }
+
+        if (plan_mode == kPlanSync) { // :770-783
+            const W3SyncOut so = w3_sync<SF>(P.sync_a, P.sync_b, X + pos, &ws, slot);
+            slot = __builtin_amdgcn_readfirstlane(so.slot);
+            if (t0) {
+                W2State St = S;
+                const int32_t consumed = (so.bi == 0x7fffffff) ? 0 : so.bi; // `int i = 0` stays when nothing exceeds 0 (:771)
+                St.state = kFindSfd;
+                w2_end_step(St, job, C, recs, trace, kSync, consumed, -1, 0, so.bv, t_start);
+                W2Plan np;
+                plan_from(St, np);
+                next = np; S = St;
+            }
+            continue;
+        }
+
+        if (plan_mode == kPlanSfd) { // :785-818
+            const W3SfdOut fo = w3_sfd_round<SF>(W3SfdArgs{P.down_ifreq, P.up_ifreq_v, P.down_ifreq_avg, P.down_ifreq_sd, P.down_ifreq_dsum, P.sync_a, P.sync_b}, xg,
+                                                 gvalid ? 1 : 0, &ws, slot);
+            slot = __builtin_amdgcn_readfirstlane(fo.slot);
+            if (t0) {
+                W2State St = S;
+                for (int g = 0; g < NG; g++) {
+                    if (g > 0 && (St.state != kFindSfd || !w2_pre_step(St, job, rec_cap, sps))) break;
+                    float c = fo.c[0];
+                    int32_t fs = fo.fine[0];
+#pragma unroll
+                    for (int q = 1; q < NG; q++) if (g == q) { c = fo.c[q]; fs = fo.fine[q]; }
+                    int32_t fine = 0;
+                    if (c > 0.96f) { // :792
+                        St.state = kPause;
+                    } else {
+                        if (c < -0.97f) fine = fs; // :801-803
+                        else St.corr_fails++;
+                        if (St.corr_fails > 4u) St.state = kDetect; // :808-809
+                    }
+                    w2_end_step(St, job, C, recs, trace, kFindSfd, (int32_t)sps + fine, -1, fine, c, t_start); // :816
+                    if (St.done || fine != 0) break; // (fine != 0: the later windows started at the wrong sample)
+                }
+                W2Plan np;
+                plan_from(St, np);
+                next = np; S = St;
+            }
+            continue;
+        }
+
+        if (plan_mode == kPlanPause) { // :820-824
+            if (t0) {
+                W2State St = S;
+                St.state = kDecodeHeader;
+                const int32_t consumed = (int32_t)(sps + P.delay_after_sync);
+                St.att_hdr = St.pos + consumed;
+                w2_end_step(St, job, C, recs, trace, kPause, consumed, -1, 0, 0.0f, t_start);
+                W2Plan np;
+                plan_from(St, np);
+                next = np; S = St;
+            }
+            continue;
+        }
+
+        if (plan_mode == kPlanFinalize) { // decode(false) + frame bytes (:870-881), all threads
+            const uint32_t n_cw = S.n_cw, cr = S.cr, n_bytes = S.fin_n_bytes, plen = S.fin_plen, n_att = S.n_att;
+            decode_payload_bytes(sh, n_cw, cr, n_bytes);
+            AttemptRec &r = recs[n_att];
+            for (uint32_t i = threadIdx.x; i < plen; i += (uint32_t)T) r.frame[3u + i] = (i < n_bytes) ? sh.dec[i] : 0;
+            __syncthreads();
+            if (t0) {
+                W2State St = S;
+                r.frame[0] = St.phdr[0]; r.frame[1] = St.phdr[1]; r.frame[2] = St.phdr[2]; // d_phdr (:600)
+                r.frame_len = 3u + plen;
+                St.frame_ok = 1;
+                St.state = kDetect;
+                St.n_words = 0; St.n_cw = 0;
+                St.fin_pending = 0;
+                w2_end_step(St, job, C, recs, trace, St.fin_st, St.fin_consumed, St.fin_bin, St.fin_fine, 0.0f, t_start);
+                W2Plan np;
+                plan_from(St, np);
+                next = np; S = St;
+            }
+            continue;
+        }
+
+        // ---- kPlanDecode: DECODE_HEADER / DECODE_PAYLOAD rounds (:826-886, demodulate :493-529) ----
+        {
+            const bool dvalid = gvalid && grp < plan_n_win;
+            uint32_t sq[NG];
+            int32_t fq[NG];
+            float eq[NG];
+            w3_demod_round<SF>(DA, L, xg, dvalid, P.implicit != 0u, slot, sq, fq, eq);
+            if (t0) {
+                W2State St = S;
+                for (int g = 0; g < NG; g++) {
+                    if (g >= plan_n_win) break;
+                    if (g > 0 && (!(St.state == kDecodeHeader || St.state == kDecodePayload) || !w2_pre_step(St, job, rec_cap, sps))) break;
+                    uint32_t sg = sq[0];
+                    int32_t fg = fq[0];
+                    float eg = eq[0];
+#pragma unroll
+                    for (int q = 1; q < NG; q++) if (g == q) { sg = sq[q]; fg = fq[q]; eg = eq[q]; }
+                    const bool is_first = St.state == kDecodeHeader;
+                    const int32_t st_w = St.state;
+                    bool do_demod = true;
+                    if (!is_first && P.implicit && eg < St.energy_threshold) { St.payload_symbols = 0; St.payload_length = St.n_cw / 2u; do_demod = false; } // :861-864
+                    uint32_t bin_idx = 0;
+                    int32_t fine = 0, step_bin = -1;
+                    if (do_demod) { // :500, bin_idx = (s-1) mod N; compat keeps the s==0 -> 0 quirk of the gradient path
+                        bin_idx = (sg == 0u && P.demod_mode == 2u) ? 0u : (sg + P.nbins - 1u) % P.nbins;
+                        step_bin = (int32_t)bin_idx;
+                        fine = fg; // :501-502
+                    }
+                    if (w3_post_symbol(P, St, sh, do_demod, bin_idx, is_first)) { // payload complete: finalise with all threads
+                        St.fin_pending = 1; St.fin_st = st_w; St.fin_consumed = (int32_t)sps + fine; St.fin_bin = step_bin; St.fin_fine = fine;
+                        break;
+                    }
+                    w2_end_step(St, job, C, recs, trace, st_w, (int32_t)sps + fine, step_bin, fine, 0.0f, t_start); // :856,:883
+                    if (St.done || fine != 0) break; // (fine != 0: the later windows started at the wrong sample)
+                }
+                W2Plan np;
+                plan_from(St, np);
+                next = np; S = St;
+            }
+        }
     }
+
+    // an attempt cut short (out of data, or probe stop) is reported but not counted as complete
+    __syncthreads();
     if (t0) {
+        const bool in_attempt = S.in_attempt != 0;
+        if (in_attempt && S.n_att < rec_cap) {
+            AttemptRec &r = recs[S.n_att];
+            r.status = (S.stop_reason == 3) ? kAttemptAtHeader : kAttemptOutOfData;
+            r.start_pos = S.att_start; r.trig_pos = S.att_trig; r.hdr_pos = S.att_hdr; r.end_pos = S.pos;
+            r.npush = S.npush;
+            for (int i = 0; i < 4; i++) r.push_tail[i] = S.push_tail[i];
+            r.cr_prev = S.att_cr_prev; r.hdr_ambig = S.att_ambig; r.n_symbols = S.n_sym; r.frame_len = 0;
+        }
         JobResult &jr = C.results[jid];
-        jr.final_pos = in_attempt ? att_start : pos;
-        jr.n_attempts = n_att + (in_attempt ? 1u : 0u);
-        jr.final_cr = cr;
-        jr.npush = in_attempt ? 0u : npush;
-        for (int i = 0; i < 4; i++) jr.push_tail[i] = push_tail[i];
-        jr.stop_reason = stop_reason;
-        jr.n_steps = n_steps < C.trace_cap ? n_steps : C.trace_cap;
-        jr.pad = in_attempt ? 1u : 0u;
-        for (int i = 0; i < 6; i++) { jr.cyc[i] = 0; jr.rounds[i] = 0; }
-        jr.tail_valid = 0;
+        const int64_t e_pos = in_attempt ? S.att_start : S.pos;
+        const uint32_t e_natt = S.n_att + (in_attempt ? 1u : 0u), e_npush = in_attempt ? 0u : S.npush, e_pad = in_attempt ? 1u : 0u;
+        bool go = false;
+        if (phase == 0) {
+            jr.final_pos = e_pos;
+            jr.n_attempts = e_natt;
+            jr.final_cr = S.cr;
+            jr.npush = e_npush;
+            for (int i = 0; i < 4; i++) jr.push_tail[i] = S.push_tail[i];
+            jr.stop_reason = (uint32_t)S.stop_reason;
+            jr.n_steps = S.n_steps < C.trace_cap ? S.n_steps : C.trace_cap;
+            jr.pad = e_pad;
+            jr.tail_valid = 0;
+            // Job.probe_limit: having reached its scan limit the workgroup runs what a separate probe job started from its end state
+            // would run - a FRESH job (state re-initialised, tables kept) that stops at the next header - and reports it as the tail
+            go = job.probe_limit > job.scan_limit && S.stop_reason == 0 && !in_attempt && !trace && e_natt < C.recs_per_job;
+            ws.ph_go = go ? 1u : 0u; ws.ph_start = e_pos; ws.ph_cr = S.cr; ws.ph_natt = e_natt;
+        } else {
+            jr.tail_valid = 1; jr.tail_first_rec = ws.ph_natt;
+            jr.tail_final_pos = e_pos; jr.tail_n_attempts = e_natt; jr.tail_final_cr = S.cr; jr.tail_npush = e_npush;
+            for (int i = 0; i < 4; i++) jr.tail_push_tail[i] = S.push_tail[i];
+            jr.tail_stop_reason = (uint32_t)S.stop_reason; jr.tail_pad = e_pad; jr.tail_rsv = 0;
+        }
+        if (!go) { // last phase of this job: the per-state time accounting goes out with it
+            W2Stats &Q = ws.stats;
+            if (Q.prev_state >= 0) { Q.cyc[Q.prev_state] += (uint32_t)((clock64() - Q.prev_t) >> 6); Q.rounds[Q.prev_state]++; }
+            for (int i = 0; i < 6; i++) { jr.cyc[i] = Q.cyc[i]; jr.rounds[i] = Q.rounds[i]; }
+            for (int i = 0; i < 4; i++) jr.ctl[i] = 0;
+            for (int i = 0; i < 6; i++) jr.dbg[i] = 0;
+        }
     }
+    if (phase == 1) break;
+    __syncthreads();
+    if (!ws.ph_go) break;
+    { // the probe: a job from the end state of the job proper to the next header (what decode_streams would launch)
+        const int64_t st = ws.ph_start;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)st), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)st >> 32));
+        const uint32_t natt = __builtin_amdgcn_readfirstlane(ws.ph_natt);
+        job.start = (int64_t)(((uint64_t)hi << 32) | lo);
+        job.cr_prev = __builtin_amdgcn_readfirstlane(ws.ph_cr);
+        job.scan_limit = job.probe_limit; job.stop_at_header = 1; job.max_attempts = 0;
+        recs += natt;
+        rec_cap = C.recs_per_job - natt;
+    }
+    __syncthreads(); // everyone has read the hand-over before thread 0 re-initialises the state
+    } // phase
 }
 
-__global__ __launch_bounds__(W3Geom<9>::T, 4) void walker3_kernel_sf9(DevParams P, LaunchCfg C) { walker3_body<9>(P, C); }
-__global__ __launch_bounds__(W3Geom<10>::T, 4) void walker3_kernel_sf10(DevParams P, LaunchCfg C) { walker3_body<10>(P, C); }
-__global__ __launch_bounds__(W3Geom<11>::T, 4) void walker3_kernel_sf11(DevParams P, LaunchCfg C) { walker3_body<11>(P, C); }
-__global__ __launch_bounds__(W3Geom<12>::T, 4) void walker3_kernel_sf12(DevParams P, LaunchCfg C) { walker3_body<12>(P, C); }
+__global__ __launch_bounds__(1024, 4) void walker3_kernel_sf9(DevParams P, LaunchCfg C) { walker3_body<9>(P, C); }
+__global__ __launch_bounds__(1024, 4) void walker3_kernel_sf10(DevParams P, LaunchCfg C) { walker3_body<10>(P, C); }
+__global__ __launch_bounds__(1024, 4) void walker3_kernel_sf11(DevParams P, LaunchCfg C) { walker3_body<11>(P, C); }
+__global__ __launch_bounds__(1024, 4) void walker3_kernel_sf12(DevParams P, LaunchCfg C) { walker3_body<12>(P, C); }
 
-// ---- symbol-level kernel: one workgroup per symbol, for lora_hip_demod_symbols_device --------------------------
+// ---- symbol-level kernel: one group per symbol, for lora_hip_demod_symbols_device ------------------------------
 template <int SF>
-__global__ __launch_bounds__(W3Geom<SF>::T, 4) void demod_symbols_w3_kernel(DevParams P, const float2 *iq, const int64_t *offsets, uint32_t n,
-                                                                             uint32_t *bins, int32_t *fine)
+__global__ __launch_bounds__(1024, 4) void demod_symbols_w3_kernel(DevParams P, const float2 *iq, const int64_t *offsets, uint32_t n,
+                                                                    uint32_t *bins, int32_t *fine)
 {
+    using G = W3Geom<SF>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const W3Lds<SF> L = w3_carve<SF>(smem);
     w3_tables_to_lds<SF>(P, L);
     __syncthreads();
     int slot = 0;
-    for (uint32_t s = blockIdx.x; s < n; s += gridDim.x) {
-        uint32_t b;
-        int32_t fs;
-        float en;
-        w3_demod_symbol<SF>(P, L, iq + offsets[s], false, slot, b, fs, en);
-        if (threadIdx.x == 0) { bins[s] = b; if (fine) fine[s] = fs; }
+    const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x / G::TG);
+    for (uint32_t s0 = blockIdx.x * G::NG; s0 < n; s0 += gridDim.x * G::NG) {
+        const bool valid = s0 + (uint32_t)grp < n;
+        uint32_t b[G::NG];
+        int32_t fs[G::NG];
+        float en[G::NG];
+        w3_demod_round<SF>(W3DemodArgs{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode}, L, iq + offsets[valid ? s0 + grp : s0], valid, false, slot, b, fs, en);
+        if (threadIdx.x == 0) {
+            for (int g = 0; g < G::NG; g++)
+                if (s0 + (uint32_t)g < n) { bins[s0 + g] = b[g]; if (fine) fine[s0 + g] = fs[g]; }
+        }
         __syncthreads();
     }
 }
@@ -859,7 +1188,7 @@ template <int SF>
 static void build_w3_tables_sf(float2 *tw, float2 *ctab)
 {
     using G = W3Geom<SF>;
-    constexpr int N = G::N, SPS = G::SPS, T = G::T;
+    constexpr int N = G::N, SPS = G::SPS, T = G::TG;
     for (int t = 0; t < G::NTW; t++) {
         const double a = -2.0 * M_PI * (double)t / (double)N;
         tw[t] = make_float2((float)std::cos(a), (float)std::sin(a));
@@ -897,5 +1226,6 @@ void build_w3_tables(uint32_t sf, float2 *tw, float2 *ctab /* sps entries */)
     else if (sf == 12u) build_w3_tables_sf<12>(tw, ctab);
 }
 
-static uint32_t walker3_threads(uint32_t sf) { return sf == 9u ? W3Geom<9>::T : sf == 10u ? W3Geom<10>::T : 1024u; }
+static uint32_t walker3_threads(uint32_t) { return 1024u; }
+static uint32_t walker3_groups(uint32_t sf) { return sf == 9u ? W3Geom<9>::NG : sf == 10u ? W3Geom<10>::NG : 1u; }
 static uint32_t walker3_lds(uint32_t sf) { return sf == 9u ? w3_lds_bytes<9>() : sf == 10u ? w3_lds_bytes<10>() : sf == 11u ? w3_lds_bytes<11>() : w3_lds_bytes<12>(); }
