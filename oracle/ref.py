@@ -17,6 +17,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _BUILD = os.path.join(_HERE, "ref_build")
 _LIB_PATH = os.path.join(_HERE, "_ref", "libref_decoder.so")
+_LIB_SIMD_PATH = os.path.join(_HERE, "_ref", "libref_decoder_simd.so")   # VOLK stand-in summing in 8 lanes
 REFERENCE_ROOT = "/root/reference"
 
 
@@ -41,13 +42,24 @@ def available() -> bool:
 
 
 _lib = None
+_lib_simd = None
 
 
-def lib():
-    global _lib
+def lib(simd: bool = False):
+    global _lib, _lib_simd
+    if simd:
+        if _lib_simd is None:
+            build()
+            _lib_simd = _bind(C.CDLL(_LIB_SIMD_PATH))
+        return _lib_simd
     if _lib is None:
         build()
-        L = C.CDLL(_LIB_PATH)
+        _lib = _bind(C.CDLL(_LIB_PATH))
+    return _lib
+
+
+def _bind(L):
+    if True:
         vp = C.c_void_p
         L.ref_create.restype = vp
         L.ref_create.argtypes = [C.c_float, C.c_uint32, C.c_uint8, C.c_int, C.c_uint8, C.c_int, C.c_int, C.c_int]
@@ -116,8 +128,7 @@ def lib():
         L.ref_prng.argtypes = [C.c_int, C.POINTER(C.c_size_t)]
         L.ref_sizeof.restype = C.c_int
         L.ref_sizeof.argtypes = [C.c_int]
-        _lib = L
-    return _lib
+    return L
 
 
 def _iq(a) -> np.ndarray:
@@ -129,8 +140,8 @@ class Reference:
     driven by the scheduler loop of oracle/ref_build/ref_driver.cc."""
 
     def __init__(self, samp_rate=1e6, bandwidth=125000, sf=7, implicit=False, cr=4, crc=True,
-                 reduced_rate=False, disable_drift_correction=False):
-        self.L = lib()
+                 reduced_rate=False, disable_drift_correction=False, simd=False):
+        self.L = lib(simd)
         self.h = self.L.ref_create(samp_rate, int(bandwidth), int(sf), int(implicit), int(cr), int(crc),
                                    int(reduced_rate), int(disable_drift_correction))
         if not self.h:

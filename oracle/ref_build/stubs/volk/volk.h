@@ -7,26 +7,43 @@
 #include <complex>
 typedef std::complex<float> lv_32fc_t;
 
+/* REFSTUB_VOLK_LANES = L > 1 builds the SECOND variant of the reference (oracle/_ref/libref_decoder_simd.so): the
+ * reductions keep L partial sums (element i goes to lane i mod L, the lanes are added up at the end) the way VOLK's
+ * SIMD protokernels (_a_sse / _a_avx, L = 4 / 8 floats per register) do.  Same mathematics, another float summation
+ * order: tests/test_ref_pin.py uses the pair to MEASURE how far the reference's own decisions depend on which VOLK
+ * protokernel the machine selects. */
+#ifndef REFSTUB_VOLK_LANES
+#define REFSTUB_VOLK_LANES 1
+#endif
+
 static inline void volk_32f_x2_dot_prod_32f(float* result, const float* input, const float* taps, unsigned int num_points)
 {
-    float acc = 0.0f;
+    float acc[REFSTUB_VOLK_LANES] = { 0.0f };
     for (unsigned int i = 0; i < num_points; i++)
-        acc += input[i] * taps[i];
-    *result = acc;
+        acc[i % REFSTUB_VOLK_LANES] += input[i] * taps[i];
+    float r = acc[0];
+    for (int l = 1; l < REFSTUB_VOLK_LANES; l++)
+        r += acc[l];
+    *result = r;
 }
 
 /* result = sum input[i] * conj(taps[i]) */
 static inline void volk_32fc_x2_conjugate_dot_prod_32fc(lv_32fc_t* result, const lv_32fc_t* input, const lv_32fc_t* taps,
                                                         unsigned int num_points)
 {
-    float re = 0.0f, im = 0.0f;
+    float re[REFSTUB_VOLK_LANES] = { 0.0f }, im[REFSTUB_VOLK_LANES] = { 0.0f };
     for (unsigned int i = 0; i < num_points; i++) {
         const float ar = input[i].real(), ai = input[i].imag();
         const float br = taps[i].real(), bi = taps[i].imag();
-        re += ar * br + ai * bi;
-        im += ai * br - ar * bi;
+        re[i % REFSTUB_VOLK_LANES] += ar * br + ai * bi;
+        im[i % REFSTUB_VOLK_LANES] += ai * br - ar * bi;
     }
-    *result = lv_32fc_t(re, im);
+    float sr = re[0], si = im[0];
+    for (int l = 1; l < REFSTUB_VOLK_LANES; l++) {
+        sr += re[l];
+        si += im[l];
+    }
+    *result = lv_32fc_t(sr, si);
 }
 
 static inline void volk_32fc_magnitude_squared_32f(float* magnitudeVector, const lv_32fc_t* complexVector, unsigned int num_points)
@@ -39,10 +56,13 @@ static inline void volk_32fc_magnitude_squared_32f(float* magnitudeVector, const
 
 static inline void volk_32f_accumulator_s32f(float* result, const float* inputBuffer, unsigned int num_points)
 {
-    float acc = 0.0f;
+    float acc[REFSTUB_VOLK_LANES] = { 0.0f };
     for (unsigned int i = 0; i < num_points; i++)
-        acc += inputBuffer[i];
-    *result = acc;
+        acc[i % REFSTUB_VOLK_LANES] += inputBuffer[i];
+    float r = acc[0];
+    for (int l = 1; l < REFSTUB_VOLK_LANES; l++)
+        r += acc[l];
+    *result = r;
 }
 
 static inline void volk_32fc_x2_multiply_32fc(lv_32fc_t* cVector, const lv_32fc_t* aVector, const lv_32fc_t* bVector,

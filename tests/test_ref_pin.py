@@ -244,3 +244,39 @@ def test_integer_chain_identical(oracle_mod):
         d = OL.lora_oracle_deshuffle_byte(v)
         nib = ((d >> 1) & 1) | (((d >> 2) & 1) << 1) | (((d >> 3) & 1) << 2) | (((d >> 5) & 1) << 3)
         assert cw == bytes([nib << 4 | nib] * 2 + [nib << 4]) and left == 0     # 5 codewords + the appended 0 (:632)
+
+
+def test_sync_shift_depends_on_volk_summation_order():
+    """How far does the reference pin its own timing decisions?  oracle/_ref/libref_decoder_simd.so is the SAME unmodified
+    lib/decoder_impl.cc with the VOLK stand-in summing in 8 lanes (what an AVX protokernel does) instead of sequentially.
+    Mathematically identical; the published payload bytes are identical too - but the SYNC step's sliding correlation
+    (:399-413) ties between adjacent shifts (1e-6 .. 2e-8 relative for SF8 .. SF12, below the resolution of a float sum of
+    sps terms), so the winning shift, and with it every later position, moves by one sample with the summation order.
+    This is the latitude the device's trace tests grant at those operating points (tests/parity_util.py)."""
+    moved = {}
+    for sf, snr, seeds in ((8, None, 4), (10, 40.0, 6), (12, None, 3), (12, 40.0, 2)):
+        n_sync = n_moved = 0
+        for seed in range(seeds):
+            rng = np.random.default_rng(seed + 10 * sf)
+            cfg = synth.TxConfig(sf=sf, cr=4, reduced_rate=(sf > 10))
+            payloads = [bytes(rng.integers(0, 256, int(rng.integers(2, 12)), dtype=np.uint8)) for _ in range(2)]
+            sigma = synth.awgn_sigma_for_snr(snr, cfg) if snr else 0.0
+            st = synth.build_stream(payloads, cfg, rng=rng, noise_sigma=sigma)
+            runs = []
+            for simd in (False, True):
+                r = R.Reference(sf=sf, cr=4, reduced_rate=(sf > 10), simd=simd)
+                r.enable_trace()
+                r.run(st.iq)
+                runs.append((r.frames(), r.frame_positions(), r.trace()))
+            (f0, p0, t0), (f1, p1, t1) = runs
+            assert [f[15:] for f in f0] == [f[15:] for f in f1]            # identical PHY header + payload bytes
+            assert len(t0) == len(t1) and [a[0] for a in t0] == [b[0] for b in t1]
+            assert all(abs(a[1] - b[1]) <= 1 for a, b in zip(t0, t1))       # never more than one sample apart
+            assert all(abs(a - b) <= 1 for a, b in zip(p0, p1))
+            for a, b in zip(t0, t1):
+                if a[0] == 1:                                               # SYNC
+                    n_sync += 1
+                    n_moved += a[2] != b[2]
+        moved[(sf, snr)] = (n_moved, n_sync)
+    assert moved[(8, None)][0] == 0            # resolvable at SF8 without noise ...
+    assert moved[(12, None)][0] >= 1           # ... rounding decides at SF12 even on a clean signal
