@@ -1,21 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- IQ Msamples/s demodulated on MI355X (BASELINE.json metric).
 
-One "step" = one full pass of the decoder hot path (detect -> sync -> SFD ->
-dechirp x FFT x argmax per symbol -> fine sync -> gray / deinterleave / dewhiten /
-Hamming -> frames) over one batch of synthetic IQ that is already resident in HBM.
-Workload at N=1: BASELINE.json configs[1] -- SF7, CR4/8, BW125k, fs 1 MHz,
-1024 synthetic packets x 32-byte payload.  With N>1 every rank decodes its own
-batch of the same shape (weak scaling; packets/streams are independent, the only
-collective is the RCCL gather of decoded frames).
+One "step" = one full pass of the decoder hot path (detect -> sync -> SFD -> dechirp x FFT x argmax per symbol -> fine
+sync -> gray / deinterleave / dewhiten / Hamming -> frames -> frame gather) over one batch of synthetic IQ.
+
+Workloads (--config):
+  2 (default, the headline)  BASELINE.json configs[1]: SF7 CR4/8 BW125k fs 1 MHz, 1024 packets x 32-byte payload
+  3                          one cell of the SF sweep: --sf S, 256 packets x 32 B (reduced rate for SF > 10)
+  4                          64-channel SF9 gateway: 8 continuous back-to-back streams PER GPU (channel c -> rank c mod N,
+                             gr_lora_amd.gather.shard_streams), random 16-64 B payloads, seed = channel id, >= 2 s per stream
+Paths (--path):
+  device (default)  the IQ is resident in HBM when the timed region starts (`value` as the contract defines it)
+  work              the reference block's own contract: host buffers through lora_hip_work() - PCIe included; reported as
+                    its own metric, never as the headline
+
+`--gpus N` with no launcher around it re-executes itself under torch.distributed.run (one rank per GPU, RCCL); under a
+launcher it reads RANK / LOCAL_RANK / WORLD_SIZE.  Weak scaling: every rank decodes a batch of the same shape; the only
+collective is the frame gather (one all_gather per step, asynchronous, collected one step later).
 
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
 import sys
 import time
 
@@ -27,7 +38,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
+# ------------------------------------------------------------------------------------------------ workloads
 def make_workload(sf, cr, n_packets, payload_len, n_streams, seed):
+    """config 2 / 3: n_packets packets of payload_len bytes in n_streams streams, zero gaps of 2-6 symbols"""
     from gr_lora_amd import synth
     cfg = synth.TxConfig(sf=sf, cr=cr, crc=True, reduced_rate=(sf > 10))
     rng = np.random.default_rng(seed)
@@ -45,48 +58,112 @@ def make_workload(sf, cr, n_packets, payload_len, n_streams, seed):
     return cfg, np.concatenate(pieces), offs, lens, expect
 
 
-def cpu_baseline(cfg, iq, offs, lens, budget_s=15.0):
-    """Times the CPU oracle (restatement of the reference decoder, default gradient
-    demodulator) on a bounded sample of the same workload; 1 thread like the
-    reference's single GNU Radio block thread."""
+def make_gateway_workload(channels, seconds=2.0, sf=9):
+    """config 4: every channel is an independent continuous stream (own decoder state): back-to-back packets, random
+    16-64 byte payloads, seed = channel id, at least `seconds` of signal at fs = 1 MHz"""
+    from gr_lora_amd import synth
+    cfg = synth.TxConfig(sf=sf, cr=4, crc=True)
+    want_items = int(seconds * cfg.samp_rate)
+    pieces, offs, lens, expect = [], [], [], []
+    off = 0
+    for ch in channels:
+        rng = np.random.default_rng(ch)
+        payloads, n = [], 0
+        while n < want_items:
+            p = bytes(rng.integers(0, 256, int(rng.integers(16, 65)), dtype=np.uint8))
+            payloads.append(p)
+            n += (12.25 + 8 + synth.payload_symbol_count(len(p) + 2, sf, 4, False)) * cfg.sps
+        st = synth.build_stream(payloads, cfg, gaps=[2 * cfg.sps] + [0] * (len(payloads) - 1), tail_symbols=2.5)
+        pieces.append(st.iq)
+        offs.append(off)
+        lens.append(st.iq.size)
+        off += st.iq.size
+        expect.append([synth.expected_frame_tail(p, cfg) for p in payloads])
+    return cfg, np.concatenate(pieces), offs, lens, expect
+
+
+# --------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(cfg, iq, offs, lens, budget_s=20.0):
+    """The reference decoder's CPU path timed beside the GPU: the C restatement of lib/decoder_impl.cc (oracle/), built
+    -O3 -march=native on THIS host, same input already in RAM, steady clock around the stream -> frames
+    call, median of 5 runs on a bounded sample; (i) one thread per stream (the reference decoder is one GNU Radio block
+    thread), both demodulators, (ii) every host core at once, one decoder per stream."""
     from oracle import oracle as O
-    O.build()
+    O.lib_fast()
     out = {}
+    sample = min(int(lens[0]), 24_000_000)
+    seg = np.ascontiguousarray(iq[offs[0]:offs[0] + sample])
     for name, mode in (("grad", O.DEMOD_GRAD), ("fft", O.DEMOD_FFT_COMPAT)):
-        done = 0
-        t_used = 0.0
-        frames = 0
-        for o_, l_ in zip(offs, lens):
-            dec = O.Oracle(samp_rate=cfg.samp_rate, bandwidth=cfg.bw, sf=cfg.sf, cr=4, crc=True,
-                           reduced_rate=cfg.reduced_rate, demod=mode)
-            seg = iq[o_:o_ + l_]
-            cap = min(l_, 40_000_000)
+        ts, frames = [], 0
+        t_begin = time.perf_counter()
+        for _ in range(5):
+            dec = O.Oracle(samp_rate=cfg.samp_rate, bandwidth=cfg.bw, sf=cfg.sf, cr=4, crc=True, reduced_rate=cfg.reduced_rate, demod=mode, fast=True)
             t0 = time.perf_counter()
-            dec.run(seg[:cap])
-            t_used += time.perf_counter() - t0
-            done += cap
-            frames += len(dec.frames())
-            if t_used > budget_s / 2:
+            dec.run(seg)
+            ts.append(time.perf_counter() - t0)
+            frames = len(dec.frames())
+            if time.perf_counter() - t_begin > budget_s / 3 and len(ts) >= 3:
                 break
-        out[name] = (done / t_used / 1e6, done, frames)
-    # every host core at once: one decoder instance per stream, as a GNU Radio flowgraph with one block thread per
-    # channel would run (the ctypes calls release the GIL), on a bounded slice of each stream
+        out[name] = (sample / float(np.median(ts)) / 1e6, sample, frames, len(ts))
     import concurrent.futures as cf
     ncores = os.cpu_count() or 1
     nthreads = max(1, min(ncores, len(offs)))
     cap = int(min(min(lens), 12_000_000))
 
     def one(k):
-        dec = O.Oracle(samp_rate=cfg.samp_rate, bandwidth=cfg.bw, sf=cfg.sf, cr=4, crc=True, reduced_rate=cfg.reduced_rate, demod=O.DEMOD_GRAD)
+        dec = O.Oracle(samp_rate=cfg.samp_rate, bandwidth=cfg.bw, sf=cfg.sf, cr=4, crc=True, reduced_rate=cfg.reduced_rate, demod=O.DEMOD_GRAD, fast=True)
         dec.run(iq[offs[k]:offs[k] + cap])
         return len(dec.frames())
 
     t0 = time.perf_counter()
-    with cf.ThreadPoolExecutor(nthreads) as ex:
+    with cf.ThreadPoolExecutor(nthreads) as ex:   # (the ctypes calls release the GIL)
         list(ex.map(one, range(nthreads)))
     dt = time.perf_counter() - t0
     out["all_cores"] = (nthreads * cap / dt / 1e6, nthreads, ncores)
     return out
+
+
+def source_hash():
+    """sha256 over the kernel / runtime sources: ties a quoted PMC figure to the code it was measured on (the GPU box has
+    no .git to ask)"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gr_lora_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def quoted_traffic(workload_key):
+    """HBM bytes per pass from a committed rocprofv3 PMC run of this workload (profiles/*pmc_traffic*.json; separate
+    FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH x2 correction as MI355X_MICROARCH.md prescribes) - only when that run
+    was taken on the sources this process is running; null otherwise"""
+    best = None
+    pd = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(pd)) if os.path.isdir(pd) else []:
+        if "pmc_traffic" not in name or not name.endswith(".json"):
+            continue
+        try:
+            pmc = json.load(open(os.path.join(pd, name)))
+        except (OSError, ValueError):
+            continue
+        if pmc.get("workload_key") == workload_key and pmc.get("source_hash") == source_hash():
+            best = (int(pmc["hbm_bytes_per_pass_corrected"]), name)
+    return best
+
+
+# ------------------------------------------------------------------------------------------------- launcher
+def respawn_under_launcher(n):
+    """`python bench.py --gpus N` on its own: one rank per GPU under torch.distributed.run, rendezvous on 127.0.0.1"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    argv = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execve(sys.executable, argv, env)
 
 
 def main():
@@ -94,17 +171,25 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--sf", type=int, default=7)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4])
+    ap.add_argument("--path", default="device", choices=["device", "work"])
+    ap.add_argument("--sf", type=int, default=None)
     ap.add_argument("--cr", type=int, default=4)
-    ap.add_argument("--packets", type=int, default=1024)
+    ap.add_argument("--packets", type=int, default=None)
     ap.add_argument("--payload", type=int, default=32)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("LORA_BENCH_STREAMS", "8")))
+    ap.add_argument("--seconds", type=float, default=8.0, help="config 4: signal per channel (BASELINE: at least 2 s)")
     ap.add_argument("--demod", type=int, default=2, help="0 grad, 1 fft, 2 fft_compat")
     ap.add_argument("--depth", type=int, default=3, help="pipeline depth: 1 = strictly one pass after the other; 2 = while the device runs "
                     "step k+1 the host stitches step k (decoder handles alternating on one stream; walker kernels never overlap); "
                     "3 = also the envelope pre-pass of step k+2 is issued ahead (it runs in the tail of step k's walker)")
+    ap.add_argument("--chunk", type=int, default=1 << 22, help="--path work: items per lora_hip_work call")
+    ap.add_argument("--batch", type=int, default=1 << 24, help="--path work: items per device pass (lora_hip_config_t.batch_items)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_launcher(args.gpus)
 
     import torch
     import torch.distributed as dist
@@ -121,19 +206,40 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    cfg, iq, offs, lens, expect = make_workload(args.sf, args.cr, args.packets, args.payload, args.streams, seed=2 + 1000 * rank)
+    sf = args.sf if args.sf is not None else (9 if args.config == 4 else 7)
+    if args.config == 4:
+        channels = gather.shard_streams(8 * world, rank, world)         # 8 channels per GPU: 64 on eight
+        cfg, iq, offs, lens, expect = make_gateway_workload(channels, args.seconds, sf)
+        wl = "config 4: %d continuous SF%d channels per GPU (%d in all), back-to-back packets of 16-64 B, %.1f s each" % (len(channels), sf, 8 * world, args.seconds)
+        wkey = "cfg4-sf%d-%gs" % (sf, args.seconds)
+    else:
+        packets = args.packets if args.packets is not None else (1024 if args.config == 2 else 256)
+        cfg, iq, offs, lens, expect = make_workload(sf, args.cr, packets, args.payload, min(args.streams, packets), seed=(2 if args.config == 2 else 100 * sf + 4) + 1000 * rank)
+        wl = "SF%d CR4/%d BW125k fs1M, %d packets x %d B payload per GPU, %d stream(s)" % (sf, 4 + args.cr, packets, args.payload, min(args.streams, packets))
+        wkey = "cfg%d-sf%d-cr%d-%dx%dB-%dstreams" % (args.config, sf, args.cr, packets, args.payload, min(args.streams, packets))
     n_items = int(iq.size)
+    n_frames_expected = sum(len(e) for e in expect)
+    kw = dict(samp_rate=cfg.samp_rate, bandwidth=cfg.bw, sf=cfg.sf, cr=4, crc=True, reduced_rate=cfg.reduced_rate, device=local_rank, demod=args.demod)
+
+    def check(frames_by_stream):
+        return all(frames_by_stream.get(s, []) == expect[s] for s in range(len(offs)))
+
+    if args.path == "work":
+        res = run_work_path(args, torch, capi, cfg, iq, offs, lens, kw, expect, wl)
+        if rank == 0:
+            print(json.dumps(res))
+        return
+
     d_iq = torch.from_numpy(iq.view(np.float32)).to(dev)
     depth = max(1, min(3, args.depth))
-    hs = [capi.Handle(samp_rate=cfg.samp_rate, bandwidth=cfg.bw, sf=cfg.sf, cr=4, crc=True, reduced_rate=cfg.reduced_rate,
-                      device=local_rank, demod=args.demod) for _ in range(depth)]
-    h = hs[0]
+    hs = [capi.Handle(**kw) for _ in range(depth)]
     stream = torch.cuda.current_stream().cuda_stream
-    gather_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    gat = gather.AsyncSlotGather(dev, max(64, 2 * n_frames_expected))
 
-    # One step = one full pass over the batch.  With depth 2 the passes are software-pipelined the way a streaming receiver
-    # runs them: the plan + launch of step k+1 (begin) is issued before the results of step k are collected (finish), on
-    # the same HIP stream, so the device goes from one walker kernel straight to the next while the host stitches.
+    # One step = one full pass over the batch.  With depth >= 2 the passes are software-pipelined the way a streaming
+    # receiver runs them: the plan + launch of step k+1 (begin) is issued before the results of step k are collected, on the
+    # same HIP stream, so the device goes from one walker kernel straight to the next while the host stitches; the frames of
+    # step k go into an asynchronous all_gather that is collected while step k+1 runs.
     def begin(k):   # the IQ is resident and unchanged: the envelope pre-pass need not wait for the stream (IQ_READY)
         hs[k % depth].decode_device_begin(d_iq.data_ptr(), n_items, offs, lens, stream, iq_ready=True)
 
@@ -143,15 +249,11 @@ def main():
     def finish(k):
         hk = hs[k % depth]
         hk.decode_device_end()
-        mine = hk.drain_slots(gather.SLOT_BYTES)             # frames straight into the exchange layout
-        if gather_stream is not None:                        # RCCL all_gather of the frames when N > 1, on a stream of its own:
-            with torch.cuda.stream(gather_stream):           # on the decode stream it would queue behind the next step's kernel
-                slots, counts = gather.gather_slots(mine, dev)
-        else:
-            slots, counts = gather.gather_slots(mine, dev)
-        return slots, counts, hk.timing()
+        done = gat.collect()                                  # step k-1's frames of every rank (None on the first step)
+        gat.submit(hk.drain_slots(gather.SLOT_BYTES))         # step k's frames: one asynchronous all_gather
+        return done, hk.timing()
 
-    def run(n_steps):
+    def run(n_steps, keep=None):
         wk, ln = 0.0, 0
         if n_steps <= 0:
             return wk, ln
@@ -163,26 +265,31 @@ def main():
                 prepass(k + 2)
             if depth > 1 and k + 1 < n_steps:
                 begin(k + 1)
-            _s, _c, tm = finish(k)
+            done, tm = finish(k)
+            if keep is not None and done is not None:
+                keep.append(done)
             wk += tm.walker_ms
             ln += tm.walker_launches
             if depth == 1 and k + 1 < n_steps:
                 begin(k + 1)
+        last = gat.collect()                                  # the final step's gather belongs to the timed region too
+        if keep is not None and last is not None:
+            keep.append(last)
         return wk, ln
 
     # correctness of what is being timed (outside the timed region): frames as gathered, this rank's share, every handle
-    verified = True
-    for j in range(depth):
-        begin(j)
-        slots, counts, _tm = finish(j)
-        mine = gather.unpack_frames(slots[rank if len(counts) > 1 else 0], counts[rank if len(counts) > 1 else 0])
+    kept = []
+    run(depth, kept)
+    verified = len(kept) == depth
+    for slots, counts in kept:
+        r = rank if len(counts) > 1 else 0
         got = {}
-        for b, sid, _hp in mine:
+        for b, sid, _hp in gather.unpack_frames(slots[r], counts[r]):
             got.setdefault(sid, []).append(b[15:])
-        verified = verified and all(got.get(s, []) == expect[s] for s in range(len(offs)))
+        verified = verified and check(got)
 
-    run(40)            # pre-roll, untimed like the check above: ~20 ms of passes bring the device to its sustained clocks
-    run(args.warmup)   # the W warm-up steps proper
+    run(40 if n_items < 4e8 else 4)   # pre-roll, untimed like the check above: brings the device to its sustained clocks
+    run(args.warmup)                  # the W warm-up steps proper
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -210,30 +317,20 @@ def main():
         value = total_items * args.steps / elapsed / 1e6
         kernel_ms = walker_ms / max(1, args.steps)  # walker kernel time per pass (HIP events, launch stream)
         achieved = 8.0 * n_items / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        # HBM bytes per pass from the committed rocprofv3 PMC run of this same workload (separate FETCH_SIZE /
-        # WRITE_SIZE passes, gfx950 FETCH x2 correction as MI355X_MICROARCH.md prescribes); null otherwise
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json")))
-            if pmc.get("workload_items") == n_items and args.demod != 0:
-                traffic = int(pmc["hbm_bytes_per_pass_corrected"])
-        except (OSError, ValueError, KeyError):
-            pass
-        fast = args.sf in (7, 8) and args.demod != 0 and not os.environ.get("LORA_HIP_NO_FAST")
-        kname = ("walker2_kernel_sf%d" % args.sf) if fast else "walker_kernel"
+        fast = args.demod != 0 and not os.environ.get("LORA_HIP_NO_FAST")
+        kname = ("walker2_kernel_sf%d" % sf) if (fast and sf in (7, 8)) else ("walker3_kernel_sf%d" % sf) if (fast and 9 <= sf <= 12) else "walker_kernel"
+        tq = quoted_traffic(wkey)
         res = {
             "metric": "IQ Msamples/s demodulated", "value": round(value, 3), "unit": "Msamples/s",
             "symbols_per_s": round(value * 1e6 / cfg.sps, 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "SF%d CR4/%d BW125k fs1M, %d packets x %d B payload per GPU, %d stream(s)" %
-                                   (args.sf, 4 + args.cr, args.packets, args.payload, args.streams),
-                       "items_per_gpu": n_items, "demod": ["grad", "fft", "fft_compat"][args.demod],
-                       "bit_exact_vs_expected": verified, "parallelism": "streams sharded, dp%d" % world,
-                       "pipeline_depth": depth},
+            "config": {"workload": wl, "workload_key": wkey, "items_per_gpu": n_items, "demod": ["grad", "fft", "fft_compat"][args.demod],
+                       "bit_exact_vs_expected": verified, "parallelism": "streams sharded, dp%d; frame gather: 1 async all_gather per step" % world,
+                       "pipeline_depth": depth, "path": "device (IQ resident in HBM)", "source_hash": source_hash()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "traffic_unit": "HBM bytes per pass (PMC, profiles/r01_f_pmc_traffic.json)",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": tq[0] if tq else None,
+                         "traffic_unit": "HBM bytes per pass (rocprofv3 PMC, %s; null unless measured on these sources)" % (tq[1] if tq else "profiles/*pmc_traffic*.json"),
                          "kernel": kname, "kernel_ms_per_pass": round(kernel_ms, 4),
                          "launches_per_pass": launches / max(1, args.steps),
                          "algorithmic_bytes_per_pass": 8 * n_items},
@@ -241,15 +338,65 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(cfg, iq, offs, lens)
             res["cpu_baseline"] = {"value": round(cb["grad"][0], 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
-                                   "sample": "oracle (C restatement, default gradient demod) over the first %d items of the same workload; "
-                                             "fft demod: %.3f Msamples/s" % (cb["grad"][1], cb["fft"][0]),
+                                   "sample": "oracle/lora_oracle.c (C restatement of lib/decoder_impl.cc) built -O3 -march=native on this host, reference-default gradient "
+                                             "demodulator, median of %d runs over the first %d items of stream 0; fft demodulator: %.3f Msamples/s" % (cb["grad"][3], cb["grad"][1], cb["fft"][0]),
                                    "all_cores": {"value": round(cb["all_cores"][0], 3), "unit": "Msamples/s", "threads": cb["all_cores"][1],
-                                                 "host_cores": cb["all_cores"][2], "sample": "one decoder per stream, gradient demod, 12e6 items each"}}
+                                                 "host_cores": cb["all_cores"][2], "sample": "one decoder per stream, gradient demod, up to 12e6 items each"}}
         print(json.dumps(res))
     for hk in hs:
         hk.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def run_work_path(args, torch, capi, cfg, iq, offs, lens, kw, expect_all, wl):
+    """--path work: ONE long stream (the workload's streams back to back) fed through lora_hip_work() in calls of --chunk
+    items out of page-locked host memory (what a source block's output buffer is to a GNU Radio decoder), device passes
+    of --batch items; PCIe included.  The source's own cost (filling its buffer) is not the decoder's and is not timed."""
+    n = int(iq.size)
+    pinned = torch.empty(2 * n, dtype=torch.float32, pin_memory=True)
+    pinned.numpy()[:] = iq.view(np.float32)
+    src = pinned.numpy().view(np.complex64)
+    expect0 = [f for e in expect_all for f in e]
+
+    def one_pass(collect=False):
+        h = capi.Handle(batch_items=args.batch, **kw)
+        got, pos = [], 0
+        t0 = time.perf_counter()
+        while pos < n:
+            m = min(args.chunk, n - pos)
+            h.work(src[pos:pos + m])
+            if collect:
+                got += h.drain()
+            else:
+                h.drain_slots(296)
+            pos += m
+        h.flush()
+        if collect:
+            got += h.drain()
+        dt = time.perf_counter() - t0
+        h.close()
+        return dt, got
+
+    _dt, got = one_pass(collect=True)
+    verified = [b[15:] for b, _i in got] == expect0
+    # measured H2D bandwidth of this box out of the same memory, same call size: the ceiling of this path
+    d = torch.empty(args.chunk * 2, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = max(1, min(64, n // args.chunk))
+    for r in range(reps):
+        d.copy_(pinned[2 * r * args.chunk:2 * (r + 1) * args.chunk], non_blocking=True)
+    torch.cuda.synchronize()
+    h2d = reps * args.chunk * 8 / (time.perf_counter() - t0) / 1e9
+    times = [one_pass()[0] for _ in range(max(3, min(args.steps, 7)))]
+    dt = float(np.median(times))
+    return {"metric": "IQ Msamples/s demodulated through lora_hip_work (host buffers in, PCIe included)", "value": round(n / dt / 1e6, 3), "unit": "Msamples/s",
+            "n_gpus": 1, "steps": len(times), "warmup": 1, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl + "; as ONE stream of %d items" % n, "path": "work (lora_hip_work out of page-locked host memory, %d items per call, device passes of %d items)" % (args.chunk, args.batch),
+                       "frames": len(got), "bit_exact_vs_expected": verified},
+            "pcie": {"h2d_GBps_measured": round(h2d, 2), "achieved_GBps": round(8 * n / dt / 1e9, 2), "frac_of_h2d": round(8 * n / dt / 1e9 / h2d, 4)}}
 
 
 if __name__ == "__main__":

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "liblora_hip.so")
 
 DEMOD_GRAD, DEMOD_FFT, DEMOD_FFT_COMPAT = 0, 1, 2
 FLAG_TRACE = 1
+FLAG_PIN_HOST = 2
 
 EXPORTS = [
     "lora_hip_abi_version", "lora_hip_strerror", "lora_hip_last_error", "lora_hip_create", "lora_hip_destroy",

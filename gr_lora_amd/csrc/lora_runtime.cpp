@@ -154,12 +154,29 @@ struct lora_hip_decoder {
     std::vector<lora_hip_step_t> trace;
     lora_hip_timing_t timing{};
     std::string err;
-    // streaming state (lora_hip_work)
-    std::vector<float> hostbuf; // interleaved
-    int64_t host_base = 0;      // absolute item index of hostbuf[0]
+    // streaming state (lora_hip_work): see the pipeline description above stream_rotate()
+    struct StreamPipe {
+        DevBuf<float2> dbuf[2];       // [ tail (up to tailcap items, right-aligned) | chunk (batch items) ]
+        size_t tailcap = 0;
+        int cur = 0;                  // buffer whose chunk is being filled
+        size_t fill = 0;              // items of the current chunk uploaded (or queued for upload) so far
+        size_t tail_len = 0;          // items carried over in front of the current chunk
+        hipStream_t copy_st = nullptr, comp_st = nullptr;
+        hipEvent_t up_ev = nullptr, tail_ev = nullptr;
+        bool inflight = false;        // a pass is running on dbuf[cur ^ 1]
+        size_t fl_off = 0, fl_len = 0;
+        PinnedBuf<float2> stage[2];   // bounce buffers for caller memory that is not page-locked
+        hipEvent_t stage_ev[2] = {nullptr, nullptr};
+        bool stage_busy[2] = {false, false};
+        int stage_i = 0;
+        std::vector<std::pair<uintptr_t, uintptr_t>> pinned; // caller ranges registered with hipHostRegister (DMA straight from them)
+        std::vector<std::pair<uintptr_t, uintptr_t>> refused; // ranges the runtime would not register: do not ask again
+        uint64_t bytes_direct = 0, bytes_staged = 0;
+    } sp;
+    int64_t host_base = 0;      // absolute item index of the first item of the stream region of the next pass
     uint32_t stream_cr = 0;
     PwrState stream_pwr;
-    size_t batch_items = 0, batch_need = 0;
+    size_t batch_items = 0;
     uint32_t resident_slots = 0;
     uint32_t eager_recs = 4;
     uint32_t last_plan_burst = 0, last_plan_segments = 0;
@@ -478,6 +495,7 @@ lora_hip_status run_jobs_end(lora_hip_decoder *h, RunOut &out)
                 ms * 1e3, us(hp2, hp3), nj * sizeof(JobResult), (size_t)nj * eager * sizeof(AttemptRec));
     }
     h->timing.walker_ms += ms;
+    h->timing.total_device_ms += ms; // (+ the pre-pass, added where it is timed)
     h->timing.walker_launches++;
     return LORA_HIP_OK;
 }
@@ -585,11 +603,13 @@ lora_hip_status quiet_edges_collect(lora_hip_decoder *h, std::vector<std::vector
     return LORA_HIP_OK;
 }
 
-// (a pre-pass issued ahead for exactly these streams is taken up; anything else is issued now)
+// (a pre-pass issued ahead for exactly these streams is taken up - `allow_reuse`: only by the decode path, where a stale gap list
+// costs speed, never correctness; lora_hip_gap_starts_device REPORTS the positions and always computes them afresh - anything
+// else is issued now)
 lora_hip_status quiet_edges(lora_hip_decoder *h, const float2 *d_iq, const std::vector<StreamDesc> &streams, hipStream_t st,
-                            std::vector<std::vector<int64_t>> &edges)
+                            std::vector<std::vector<int64_t>> &edges, bool allow_reuse = true)
 {
-    if (!(h->pre_issued && h->pre_iq == d_iq && h->pre_sig == streams_signature(streams))) {
+    if (!(allow_reuse && h->pre_issued && h->pre_iq == d_iq && h->pre_sig == streams_signature(streams))) {
         if (h->pre_issued) { (void)hipStreamSynchronize(h->pre_stream); h->pre_issued = false; } // stale: let it finish before its buffers are reused
         const lora_hip_status s = quiet_edges_enqueue(h, d_iq, streams, st);
         if (s != LORA_HIP_OK) return s;
@@ -673,6 +693,8 @@ const char *lora_hip_strerror(lora_hip_status s)
 
 const char *lora_hip_last_error(const lora_hip_decoder_t *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
+static void stream_pipe_release(lora_hip_decoder *h);
+
 lora_hip_status lora_hip_create(const lora_hip_config_t *cfg, lora_hip_decoder_t **out)
 {
     if (!cfg || !out) return LORA_HIP_ERR_ARG;
@@ -700,7 +722,6 @@ lora_hip_status lora_hip_create(const lora_hip_config_t *cfg, lora_hip_decoder_t
     if (s != LORA_HIP_OK) { lora_hip_destroy(h); return s; }
     h->stream_cr = h->P.ctor_cr;
     h->batch_items = cfg->batch_items ? cfg->batch_items : std::max<size_t>(1u << 20, 64ull * h->P.sps);
-    h->batch_need = h->batch_items;
     *out = h;
     return LORA_HIP_OK;
 }
@@ -709,6 +730,7 @@ void lora_hip_destroy(lora_hip_decoder_t *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->sp.comp_st) { (void)hipStreamSynchronize(h->sp.copy_st); (void)hipStreamSynchronize(h->sp.comp_st); } // a streaming pass may be in flight
     if (h->d_down) (void)hipFree(h->d_down);
     if (h->d_twN) (void)hipFree(h->d_twN);
     if (h->d_tws) (void)hipFree(h->d_tws);
@@ -720,6 +742,7 @@ void lora_hip_destroy(lora_hip_decoder_t *h)
     if (h->d_up_ifreq_v) (void)hipFree(h->d_up_ifreq_v);
     h->d_jobs.release(); h->d_results.release(); h->d_recs.release(); h->d_scratch.release();
     h->d_trace.release(); h->d_staging.release(); h->d_offsets.release(); h->d_bins.release();
+    stream_pipe_release(h);
     h->p_jobs.release(); h->p_res.release(); h->p_recs.release();
     h->d_balance.release(); h->d_env_E.release(); h->d_env_buf.release(); h->p_env_streams.release(); h->p_env_buf.release();
     for (hipEvent_t e : {h->ev0, h->ev1, h->ev_done, h->ev_pre0, h->ev_pre1, h->ev_dep})
@@ -765,7 +788,7 @@ lora_hip_status lora_hip_decode_device_begin(lora_hip_decoder_t *h, const void *
     std::vector<StreamDesc> &sds = h->pass_streams;
     sds.assign(n_streams, StreamDesc{});
     for (uint32_t i = 0; i < n_streams; i++) {
-        if (stream_off[i] + stream_len[i] > total_items) return fail(h, LORA_HIP_ERR_ARG, "stream %u exceeds the buffer", i);
+        if (stream_off[i] > total_items || stream_len[i] > total_items - stream_off[i]) return fail(h, LORA_HIP_ERR_ARG, "stream %u exceeds the buffer", i);
         sds[i].off = stream_off[i]; sds[i].len = stream_len[i]; sds[i].id = i;
         sds[i].cr_in = h->P.ctor_cr; sds[i].abs_base = 0;
         h->timing.items += stream_len[i];
@@ -791,7 +814,7 @@ lora_hip_status lora_hip_decode_device_prepass(lora_hip_decoder_t *h, const void
     if (h->cfg.segment_symbols != 0 || h->P.implicit || (h->cfg.flags & LORA_HIP_FLAG_TRACE)) return LORA_HIP_OK;
     std::vector<StreamDesc> sds(n_streams);
     for (uint32_t i = 0; i < n_streams; i++) {
-        if (stream_off[i] + stream_len[i] > total_items) return fail(h, LORA_HIP_ERR_ARG, "stream %u exceeds the buffer", i);
+        if (stream_off[i] > total_items || stream_len[i] > total_items - stream_off[i]) return fail(h, LORA_HIP_ERR_ARG, "stream %u exceeds the buffer", i);
         sds[i].off = stream_off[i]; sds[i].len = stream_len[i]; sds[i].id = i;
     }
     if (h->pre_issued) { HIP_TRY(h, hipStreamSynchronize(h->pre_stream)); h->pre_issued = false; }
@@ -831,12 +854,12 @@ lora_hip_status lora_hip_gap_starts_device(lora_hip_decoder_t *h, const void *d_
     HIP_TRY(h, hipSetDevice(h->device));
     std::vector<StreamDesc> sds(n_streams);
     for (uint32_t i = 0; i < n_streams; i++) {
-        if (stream_off[i] + stream_len[i] > total_items) return fail(h, LORA_HIP_ERR_ARG, "stream %u exceeds the buffer", i);
+        if (stream_off[i] > total_items || stream_len[i] > total_items - stream_off[i]) return fail(h, LORA_HIP_ERR_ARG, "stream %u exceeds the buffer", i);
         sds[i].off = stream_off[i]; sds[i].len = stream_len[i]; sds[i].id = i;
     }
     std::vector<std::vector<int64_t>> edges;
     h->err.clear();
-    const lora_hip_status s = quiet_edges(h, (const float2 *)d_iq, sds, (hipStream_t)hip_stream, edges);
+    const lora_hip_status s = quiet_edges(h, (const float2 *)d_iq, sds, (hipStream_t)hip_stream, edges, /*allow_reuse=*/false);
     if (s != LORA_HIP_OK) return h->err.empty() ? fail(h, LORA_HIP_ERR_BAD_CONFIG, "no envelope for these streams (shorter than a symbol, or fewer than 128 samples per symbol)") : s;
     size_t used = 0;
     for (uint32_t i = 0; i < n_streams; i++) {
@@ -848,45 +871,207 @@ lora_hip_status lora_hip_gap_starts_device(lora_hip_decoder_t *h, const void *d_
     return LORA_HIP_OK;
 }
 
-static lora_hip_status stream_pass(lora_hip_decoder_t *h, bool flushing)
+// ---- lora_hip_work: the reference block's work() contract (host buffers in, frames out), pipelined ------------------
+// The stream is cut into chunks of batch_items.  Samples are uploaded AS THEY ARRIVE (asynchronously, on a copy stream of
+// the handle) into the chunk area of one of two device buffers; when a chunk is full, the pass over the previous chunk is
+// collected (state, frames, the undecoded tail), the tail is copied in front of the new chunk (device to device), and the
+// pass over [tail | chunk] is launched - so the device decodes chunk k while chunk k + 1 is being uploaded and the host
+// only ever waits for a kernel that had a whole chunk's arrival time to finish.  Frames surface one chunk later than in
+// a synchronous pass; lora_hip_flush() drains everything.  Caller memory that is page-locked (or that hipHostRegister
+// accepts: GNU Radio's buffers are long-lived) is DMA'd from directly; anything else goes through two pinned bounce
+// buffers.  Output is what one pass over the whole stream would give (tests/test_gpu_parity.py::test_streaming_*).
+static void stream_pipe_release(lora_hip_decoder *h)
 {
-    const size_t items = h->hostbuf.size() / 2u;
-    if (items < 2u * (size_t)h->P.sps) return LORA_HIP_OK;
+    auto &sp = h->sp;
+    for (auto &r : sp.pinned) (void)hipHostUnregister((void *)r.first);
+    sp.pinned.clear(); sp.refused.clear();
+    for (int i = 0; i < 2; i++) {
+        sp.dbuf[i].release(); sp.stage[i].release();
+        if (sp.stage_ev[i]) { (void)hipEventDestroy(sp.stage_ev[i]); sp.stage_ev[i] = nullptr; }
+    }
+    if (sp.up_ev) { (void)hipEventDestroy(sp.up_ev); sp.up_ev = nullptr; }
+    if (sp.tail_ev) { (void)hipEventDestroy(sp.tail_ev); sp.tail_ev = nullptr; }
+    if (sp.copy_st) { (void)hipStreamDestroy(sp.copy_st); sp.copy_st = nullptr; }
+    if (sp.comp_st) { (void)hipStreamDestroy(sp.comp_st); sp.comp_st = nullptr; }
+}
+
+static lora_hip_status stream_pipe_init(lora_hip_decoder *h)
+{
+    auto &sp = h->sp;
+    if (sp.copy_st) return LORA_HIP_OK;
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, h->d_staging.reserve(items));
-    HIP_TRY(h, hipMemcpy(h->d_staging.p, h->hostbuf.data(), items * sizeof(float2), hipMemcpyHostToDevice));
-    std::vector<StreamDesc> sds(1);
-    sds[0].off = 0; sds[0].len = items; sds[0].id = 0; sds[0].cr_in = h->stream_cr; sds[0].pwr = h->stream_pwr;
-    sds[0].abs_base = h->host_base;
-    h->timing = lora_hip_timing_t{};
-    h->timing.items = items;
-    lora_hip_status s = decode_streams(h, h->d_staging.p, sds, nullptr);
-    if (s != LORA_HIP_OK) return s;
-    h->stream_cr = sds[0].cr_out;
-    h->stream_pwr = sds[0].pwr;
-    const size_t keep_from = (size_t)std::min<int64_t>(std::max<int64_t>(sds[0].final_pos, 0), (int64_t)items);
-    h->hostbuf.erase(h->hostbuf.begin(), h->hostbuf.begin() + 2 * keep_from);
+    HIP_TRY(h, hipStreamCreateWithFlags(&sp.copy_st, hipStreamNonBlocking));
+    HIP_TRY(h, hipStreamCreateWithFlags(&sp.comp_st, hipStreamNonBlocking));
+    HIP_TRY(h, hipEventCreateWithFlags(&sp.up_ev, hipEventDisableTiming));
+    HIP_TRY(h, hipEventCreateWithFlags(&sp.tail_ev, hipEventDisableTiming));
+    for (int i = 0; i < 2; i++) HIP_TRY(h, hipEventCreateWithFlags(&sp.stage_ev[i], hipEventDisableTiming));
+    sp.tailcap = std::max<size_t>(h->batch_items, 4u * (size_t)h->P.sps);
+    for (int i = 0; i < 2; i++) HIP_TRY(h, sp.dbuf[i].reserve(sp.tailcap + h->batch_items));
+    return LORA_HIP_OK;
+}
+
+// is [p, p + bytes) inside memory the device can DMA from?  Tries to page-lock unknown ranges once.
+static bool stream_host_pinned(lora_hip_decoder *h, const void *p, size_t bytes)
+{
+    auto &sp = h->sp;
+    const uintptr_t a = (uintptr_t)p, b = a + bytes;
+    for (auto &r : sp.pinned) if (a >= r.first && b <= r.second) return true;
+    for (auto &r : sp.refused) if (a >= r.first && b <= r.second) return false;
+    { // hipHostMalloc'ed, or registered by the caller: both ends must be (a range registered only in part is not usable)
+        hipPointerAttribute_t a0{}, a1{};
+        const bool h0 = hipPointerGetAttributes(&a0, p) == hipSuccess && a0.type == hipMemoryTypeHost;
+        const bool h1 = bytes && hipPointerGetAttributes(&a1, (const char *)p + bytes - 1) == hipSuccess && a1.type == hipMemoryTypeHost;
+        (void)hipGetLastError();
+        if (h0 && h1) return true;
+        if (h0 || h1) return false; // straddles somebody's registration: registering the rest would overlap it
+    }
+    // Page-locking the caller's memory ourselves is opt-in (LORA_HIP_FLAG_PIN_HOST): a partly registered allocation makes
+    // OTHER HIP copies out of it fail, so it is only safe where the caller hands over long-lived buffers it uses for nothing
+    // else (a GNU Radio block's input buffer).  Without the flag, memory that is not page-locked goes through the bounce buffers.
+    if (!(h->cfg.flags & LORA_HIP_FLAG_PIN_HOST) || bytes < (256u << 10)) return false; // (small calls: the bounce copy is cheaper)
+    const uintptr_t pg = 4096u, ra = a & ~(pg - 1u), rb = (b + pg - 1u) & ~(pg - 1u);
+    if (hipHostRegister((void *)ra, rb - ra, hipHostRegisterDefault) == hipSuccess) { sp.pinned.emplace_back(ra, rb); return true; }
+    (void)hipGetLastError();
+    sp.refused.emplace_back(a, b);
+    return false;
+}
+
+// collects the pass in flight: decoder state, frames, and the undecoded tail moved in front of the chunk being filled
+static lora_hip_status stream_collect(lora_hip_decoder *h)
+{
+    auto &sp = h->sp;
+    if (!sp.inflight) return LORA_HIP_OK;
+    sp.inflight = false;
+    h->pass_open = false;
+    h->err.clear();
+    DeviceEnv env{h, h->pass_iq, h->pass_st};
+    const int rc = lora_hip::decode_end(env, h->pass_streams, h->pass);
+    if (rc != 0) { h->pending.open = false; return h->err.empty() ? fail(h, LORA_HIP_ERR_INTERNAL, "scheduler failed") : LORA_HIP_ERR_HIP; }
+    const StreamDesc &sd = h->pass_streams[0];
+    h->stream_cr = sd.cr_out;
+    h->stream_pwr = sd.pwr;
+    const size_t keep_from = (size_t)std::min<int64_t>(std::max<int64_t>(sd.final_pos, 0), (int64_t)sp.fl_len);
+    const size_t tail = sp.fl_len - keep_from; // an attempt that ran out of data is re-run from its start with the next chunk behind it
     h->host_base += (int64_t)keep_from;
-    // an attempt that ran out of data is re-run from its start once more input has
-    // arrived; wait for twice as much so the total work stays linear
-    if (sds[0].incomplete && !flushing) h->batch_need = std::max(h->batch_items, 2u * (items - keep_from));
-    else h->batch_need = h->batch_items;
+    if (tail > sp.tailcap) { // (a packet longer than the tail area: grow both buffers, keeping what the filling one holds)
+        const size_t ncap = std::max(2u * sp.tailcap, tail + (size_t)h->P.sps);
+        HIP_TRY(h, hipStreamSynchronize(sp.copy_st));
+        for (int i = 0; i < 2; i++) {
+            DevBuf<float2> nb;
+            HIP_TRY(h, nb.reserve(ncap + h->batch_items));
+            HIP_TRY(h, hipMemcpyAsync(nb.p + ncap, sp.dbuf[i].p + sp.tailcap, h->batch_items * sizeof(float2), hipMemcpyDeviceToDevice, sp.comp_st));
+            if (i == (sp.cur ^ 1)) // the buffer the pass ran on: its stream region moves along (it is the source of the tail below)
+                HIP_TRY(h, hipMemcpyAsync(nb.p + ncap - (sp.tailcap - sp.fl_off), sp.dbuf[i].p + sp.fl_off, (sp.tailcap - sp.fl_off) * sizeof(float2), hipMemcpyDeviceToDevice, sp.comp_st));
+            HIP_TRY(h, hipStreamSynchronize(sp.comp_st));
+            std::swap(sp.dbuf[i], nb);
+            nb.release();
+        }
+        sp.fl_off += ncap - sp.tailcap;
+        sp.tailcap = ncap;
+    }
+    if (tail) {
+        HIP_TRY(h, hipMemcpyAsync(sp.dbuf[sp.cur].p + sp.tailcap - tail, sp.dbuf[sp.cur ^ 1].p + sp.fl_off + keep_from, tail * sizeof(float2), hipMemcpyDeviceToDevice, sp.comp_st));
+        // the source sits in the chunk area that the NEXT uploads overwrite: they wait for this copy
+        HIP_TRY(h, hipEventRecord(sp.tail_ev, sp.comp_st));
+        HIP_TRY(h, hipStreamWaitEvent(sp.copy_st, sp.tail_ev, 0));
+    }
+    sp.tail_len = tail;
+    return LORA_HIP_OK;
+}
+
+// the chunk being filled is complete (or the stream is being flushed): collect the previous pass, launch this one
+static lora_hip_status stream_rotate(lora_hip_decoder *h)
+{
+    auto &sp = h->sp;
+    HIP_TRY(h, hipEventRecord(sp.up_ev, sp.copy_st));
+    lora_hip_status s = stream_collect(h);
+    if (s != LORA_HIP_OK) return s;
+    const size_t len = sp.tail_len + sp.fill;
+    if (len >= 2u * (size_t)h->P.sps) {
+        HIP_TRY(h, hipStreamWaitEvent(sp.comp_st, sp.up_ev, 0));
+        std::vector<StreamDesc> &sds = h->pass_streams;
+        sds.assign(1, StreamDesc{});
+        sds[0].off = sp.tailcap - sp.tail_len; sds[0].len = len; sds[0].id = 0;
+        sds[0].cr_in = h->stream_cr; sds[0].pwr = h->stream_pwr; sds[0].abs_base = h->host_base;
+        h->timing = lora_hip_timing_t{};
+        h->timing.items = len;
+        h->pass_iq = sp.dbuf[sp.cur].p; h->pass_st = sp.comp_st;
+        h->err.clear();
+        DeviceEnv env{h, h->pass_iq, h->pass_st};
+        const int rc = lora_hip::decode_begin(env, sds, h->pass);
+        if (rc != 0) { h->pending.open = false; return h->err.empty() ? fail(h, LORA_HIP_ERR_INTERNAL, "scheduler failed") : LORA_HIP_ERR_HIP; }
+        h->pass_open = true;
+        sp.inflight = true; sp.fl_off = sp.tailcap - sp.tail_len; sp.fl_len = len;
+        sp.cur ^= 1; sp.fill = 0; sp.tail_len = 0;
+    }
+    // (shorter than one work() call of the reference, :91: keep filling the same chunk)
     return LORA_HIP_OK;
 }
 
 lora_hip_status lora_hip_work(lora_hip_decoder_t *h, const float *iq, size_t n_items, size_t *consumed)
 {
     if (!h || (!iq && n_items)) return LORA_HIP_ERR_ARG;
-    h->hostbuf.insert(h->hostbuf.end(), iq, iq + 2 * n_items);
+    if (h->pass_open && !h->sp.inflight) return fail(h, LORA_HIP_ERR_ARG, "lora_hip_work: a lora_hip_decode_device_begin pass is open on this handle");
+    lora_hip_status s = stream_pipe_init(h);
+    if (s != LORA_HIP_OK) return s;
+    HIP_TRY(h, hipSetDevice(h->device));
+    auto &sp = h->sp;
+    const float2 *src = reinterpret_cast<const float2 *>(iq);
+    size_t left = n_items;
+    bool direct_pending = false;
+    const bool direct = n_items != 0 && stream_host_pinned(h, iq, n_items * sizeof(float2)); // (the whole call's range, once)
+    while (left) {
+        if (sp.fill == h->batch_items) { // (a chunk that could not be launched yet because the stream was shorter than 2 sps)
+            s = stream_rotate(h);
+            if (s != LORA_HIP_OK) return s;
+            if (sp.fill == h->batch_items) return fail(h, LORA_HIP_ERR_BAD_CONFIG, "batch_items is smaller than two symbols");
+        }
+        const size_t m = std::min(left, h->batch_items - sp.fill);
+        float2 *dst = sp.dbuf[sp.cur].p + sp.tailcap + sp.fill;
+        if (direct) {
+            HIP_TRY(h, hipMemcpyAsync(dst, src, m * sizeof(float2), hipMemcpyHostToDevice, sp.copy_st));
+            direct_pending = true;
+            sp.bytes_direct += m * sizeof(float2);
+        } else { // through a pinned bounce buffer, in pieces, two in flight
+            size_t done = 0;
+            const size_t piece = std::max<size_t>(h->batch_items / 4u, 16384u);
+            while (done < m) {
+                const size_t q = std::min(piece, m - done);
+                const int k = sp.stage_i;
+                if (sp.stage_busy[k]) { HIP_TRY(h, hipEventSynchronize(sp.stage_ev[k])); sp.stage_busy[k] = false; }
+                HIP_TRY(h, sp.stage[k].reserve(piece));
+                std::memcpy(sp.stage[k].p, src + done, q * sizeof(float2));
+                HIP_TRY(h, hipMemcpyAsync(dst + done, sp.stage[k].p, q * sizeof(float2), hipMemcpyHostToDevice, sp.copy_st));
+                HIP_TRY(h, hipEventRecord(sp.stage_ev[k], sp.copy_st));
+                sp.stage_busy[k] = true;
+                sp.stage_i ^= 1;
+                done += q;
+            }
+            sp.bytes_staged += m * sizeof(float2);
+        }
+        sp.fill += m; src += m; left -= m;
+        if (sp.fill == h->batch_items) {
+            s = stream_rotate(h);
+            if (s != LORA_HIP_OK) return s;
+        }
+    }
+    // the caller may reuse its buffer as soon as we return (the scheduler's contract): the DMA out of it must be done
+    if (direct_pending) HIP_TRY(h, hipStreamSynchronize(sp.copy_st));
     if (consumed) *consumed = n_items;
-    if (h->hostbuf.size() / 2u >= h->batch_need) return stream_pass(h, false);
     return LORA_HIP_OK;
 }
 
 lora_hip_status lora_hip_flush(lora_hip_decoder_t *h)
 {
     if (!h) return LORA_HIP_ERR_ARG;
-    return stream_pass(h, true);
+    if (!h->sp.copy_st) return LORA_HIP_OK; // nothing was ever fed
+    HIP_TRY(h, hipSetDevice(h->device));
+    lora_hip_status s = stream_rotate(h); // launches what is buffered (collecting the pass before it)
+    if (s != LORA_HIP_OK) return s;
+    s = stream_collect(h);                // ... and collects that one as well; its tail waits in front of the next chunk
+    if (s != LORA_HIP_OK) return s;
+    HIP_TRY(h, hipStreamSynchronize(h->sp.comp_st));
+    return LORA_HIP_OK;
 }
 
 size_t lora_hip_frames_available(const lora_hip_decoder_t *h) { return h ? h->frames.size() : 0; }

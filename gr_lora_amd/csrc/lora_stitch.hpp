@@ -505,7 +505,12 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
                 for (uint32_t a = 0; a < nall; a++) {
                     const AttemptRec &r = R1.rec(k, a);
                     if (r.hdr_pos != L.hdr_pos || (r.status != kAttemptFrame && r.status != kAttemptOutOfData)) continue;
-                    if (r.hdr_ambig && cr_class(r.cr_prev) != cr_class(L.cr_prev)) continue;
+                    { // the header FEC branch follows the carried-in d_phdr.cr (:655): the job's speculative decode only stands
+                      // if its branch is the true one, or the two Hamming branches agree on this header - and class 0
+                      // (no switch case upstream: the header reads as zeros) never agrees with either
+                        const int cj = cr_class(r.cr_prev), cl = cr_class(L.cr_prev);
+                        if (cj != cl && (r.hdr_ambig || cj == 0 || cl == 0)) continue;
+                    }
                     match = (int)a; mk = k;
                     break;
                 }

@@ -114,6 +114,80 @@ def gather_slots(mine: np.ndarray, device: torch.device, group=None):
     return torch.stack(slots).cpu().numpy(), counts
 
 
+class AsyncSlotGather:
+    """The frame gather of a pipelined pass loop, off the critical path: ONE collective per step - an all_gather of a
+    fixed-capacity block whose row 0 carries the count - issued asynchronously on a stream of its own and collected one
+    step later; no count exchange, no `.item()`, nothing the decode stream waits for.
+
+        g = AsyncSlotGather(device, capacity)
+        g.submit(slots_k)          # uint8 [n_k, SLOT_BYTES] (Handle.drain_slots); returns at once
+        ... next step's decode ...
+        slots, counts = g.collect()   # step k's frames of every rank: uint8 [world, capacity, SLOT_BYTES], [n_r]
+
+    Without torch.distributed it degenerates to handing the block back."""
+
+    def __init__(self, device: torch.device, capacity: int, group=None):
+        self.device, self.cap, self.group = device, int(capacity), group
+        self.dist = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.dist else 1
+        self.cuda = device.type == "cuda"
+        self.stream = torch.cuda.Stream(device=device) if (self.cuda and self.dist) else None
+        pin = self.cuda
+        self.h_in = [torch.zeros((self.cap + 1, SLOT_BYTES), dtype=torch.uint8, pin_memory=pin) for _ in range(2)]
+        self.h_out = [torch.zeros((self.world, self.cap + 1, SLOT_BYTES), dtype=torch.uint8, pin_memory=pin) for _ in range(2)]
+        if self.dist:
+            self.d_in = [torch.zeros((self.cap + 1, SLOT_BYTES), dtype=torch.uint8, device=device) for _ in range(2)]
+            self.d_out = [torch.zeros((self.world, self.cap + 1, SLOT_BYTES), dtype=torch.uint8, device=device) for _ in range(2)]
+        self.k = 0
+        self.pending = None   # (buffer index, work handle, copy-done event)
+
+    def submit(self, mine: np.ndarray):
+        if self.pending is not None:
+            raise RuntimeError("collect() the previous step first")
+        n = int(mine.shape[0])
+        if n > self.cap:
+            raise ValueError("frame slot capacity exceeded (%d > %d)" % (n, self.cap))
+        b = self.k & 1
+        self.k += 1
+        hin = self.h_in[b].numpy()
+        hin[0, 0:8] = np.array([n], dtype=np.int64).view(np.uint8)
+        if n:
+            hin[1:1 + n] = mine
+        if not self.dist:
+            self.pending = (b, None, None)
+            return
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                self.d_in[b].copy_(self.h_in[b], non_blocking=True)
+                work = dist.all_gather_into_tensor(self.d_out[b].view(-1), self.d_in[b].view(-1), group=self.group, async_op=True)
+                work.wait()                                  # (orders the copy below behind the collective on this stream; the host does not block)
+                self.h_out[b].copy_(self.d_out[b], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+            self.pending = (b, None, ev)
+        else:                                                # CPU / gloo
+            self.d_in[b].copy_(self.h_in[b])
+            work = dist.all_gather_into_tensor(self.d_out[b].view(-1), self.d_in[b].view(-1), group=self.group, async_op=True)
+            self.pending = (b, work, None)
+
+    def collect(self):
+        if self.pending is None:
+            return None
+        b, work, ev = self.pending
+        self.pending = None
+        if not self.dist:
+            blk = self.h_in[b].numpy()[None]
+        else:
+            if work is not None:
+                work.wait()
+                self.h_out[b].copy_(self.d_out[b])
+            if ev is not None:
+                ev.synchronize()
+            blk = self.h_out[b].numpy()
+        counts = [int(blk[r, 0, 0:8].view(np.int64)[0]) for r in range(blk.shape[0])]
+        return blk[:, 1:], counts
+
+
 def shard_streams(n_streams: int, rank: int, world: int) -> List[int]:
     """Static partition: stream c -> rank c mod world."""
     return [c for c in range(n_streams) if c % world == rank]

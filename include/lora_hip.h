@@ -46,6 +46,9 @@ typedef enum lora_hip_demod {
 } lora_hip_demod;
 
 #define LORA_HIP_FLAG_TRACE 0x1u    /* record one lora_hip_step_t per state-machine step (tests / debugging) */
+#define LORA_HIP_FLAG_PIN_HOST 2u  /* lora_hip_work may page-lock (hipHostRegister) the caller's buffers to DMA straight from them;
+                                      only for long-lived buffers the caller uses for nothing else.  Memory that is already
+                                      page-locked (hipHostMalloc / registered by the caller) is always used directly. */
 
 /* Constructor arguments of gr::lora::decoder::make (include/lora/decoder.h:705;
  * python/bindings/decoder_python.cc:36-66), plus the device-side knobs.        */
@@ -92,7 +95,7 @@ typedef struct lora_hip_step {
  * measured with HIP events on the launch stream.                                                               */
 typedef struct lora_hip_timing {
     float    walker_ms;              /* sum over the walker (decoder state-machine) kernel launches          */
-    float    total_device_ms;        /* first launch -> last device op of the pass                           */
+    float    total_device_ms;        /* device time of the pass: the walker launches (HIP events around each)   */
     uint32_t walker_launches;
     uint32_t jobs;                   /* workgroups launched in the main pass                                  */
     uint32_t probes;                 /* stitch probes launched                                                */

@@ -31,13 +31,30 @@ def build(force: bool = False) -> str:
 
 
 _lib = None
+_lib_fast = None
+_FAST_PATH = os.path.join(_HERE, "liblora_oracle_fast.so")
+
+
+def lib_fast():
+    """The CPU-BASELINE build (-O3 -march=native): rebuilt on the machine that runs it (the flags are
+    host-specific), used by bench.py's cpu_baseline leg only - never for parity."""
+    global _lib_fast
+    if _lib_fast is None:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liblora_oracle_fast.so"])
+        _lib_fast = _bind(C.CDLL(_FAST_PATH))
+    return _lib_fast
 
 
 def lib():
     global _lib
     if _lib is None:
         build()
-        L = C.CDLL(_LIB_PATH)
+        _lib = _bind(C.CDLL(_LIB_PATH))
+    return _lib
+
+
+def _bind(L):
+    if True:
         fp = C.POINTER(C.c_float)
         L.lora_oracle_create.restype = C.c_void_p
         L.lora_oracle_create.argtypes = [C.c_float, C.c_uint32, C.c_uint8, C.c_int, C.c_uint8, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -83,8 +100,7 @@ def lib():
         L.lora_oracle_deshuffle_byte.argtypes = [C.c_uint8]
         L.lora_oracle_snr_byte.restype = C.c_uint8
         L.lora_oracle_snr_byte.argtypes = [C.c_float]
-        _lib = L
-    return _lib
+    return L
 
 
 def _iq(a) -> np.ndarray:
@@ -97,8 +113,8 @@ class Oracle:
     gr::lora::decoder::make, include/lora/decoder.h:705)."""
 
     def __init__(self, samp_rate=1e6, bandwidth=125000, sf=7, implicit=False, cr=4, crc=True,
-                 reduced_rate=False, disable_drift_correction=False, demod=DEMOD_GRAD):
-        self.L = lib()
+                 reduced_rate=False, disable_drift_correction=False, demod=DEMOD_GRAD, fast=False):
+        self.L = lib_fast() if fast else lib()
         self.h = self.L.lora_oracle_create(samp_rate, int(bandwidth), int(sf), int(implicit), int(cr), int(crc),
                                            int(reduced_rate), int(disable_drift_correction), int(demod))
         if not self.h:

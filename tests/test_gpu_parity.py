@@ -224,6 +224,37 @@ def test_streaming_chunks_equal_batch(torch_cuda, oracle_mod):
     h.close()
 
 
+@pytest.mark.parametrize("sf,batch,chunk", [(7, 1 << 18, 1 << 20), (9, 40000, 300000), (8, 1 << 16, 50000), (10, 1 << 17, 1 << 17)])
+def test_streaming_pipeline_equals_batch(torch_cuda, oracle_mod, sf, batch, chunk):
+    """The pipelined lora_hip_work path (uploads as the samples arrive, pass k decoding while chunk k + 1 uploads, tails
+    carried on the device): large calls (DMA straight from the caller's page-locked or registered memory) and small ones
+    (bounce buffers), batches shorter than a packet (the undecoded tail grows past its area), flush in mid-stream and more
+    input afterwards - always the frames and header positions of one pass over the whole stream."""
+    from gr_lora_amd import capi
+    cfg = synth.TxConfig(sf=sf, cr=4)
+    rng = np.random.default_rng(50 + sf)
+    payloads = [bytes(rng.integers(0, 256, int(rng.integers(8, 60)), dtype=np.uint8)) for _ in range(14 if sf < 9 else 7)]
+    st = synth.build_stream(payloads, cfg, rng=rng)
+    want = oracle_mod.decode_stream(st.iq, demod=2, sf=sf, cr=4)
+    assert len(want) == len(payloads)
+    h = capi.Handle(sf=sf, cr=4, demod=capi.DEMOD_FFT_COMPAT, batch_items=batch)
+    pos, k = 0, 0
+    got = []
+    while pos < st.iq.size:
+        n = chunk if k % 3 else int(rng.integers(1, 5000))
+        h.work(st.iq[pos:pos + n])
+        pos += n
+        k += 1
+        if k == 5:
+            h.flush()                      # mid-stream: everything complete so far comes out, the rest carries on
+        got += h.drain()
+    h.flush()
+    got += h.drain()
+    assert [g for g, _ in got] == want
+    assert [i.header_pos for _, i in got] == st.header_starts
+    h.close()
+
+
 @pytest.mark.parametrize("seg_symbols", [16, 23, 40, 64, 150])
 def test_segment_speculation_equals_serial(torch_cuda, oracle_mod, seg_symbols):
     """One long multi-packet stream cut into speculative segments must publish exactly

@@ -189,3 +189,22 @@ def test_burst_plan_properties(sim):
     edges = [[50 * sps * k for k in range(1, 21)] + [3990 * sps]]
     rc, cuts = _plan(sim, lens, edges, sps, 16, 200 * sps)
     assert rc == 1 and max(b - a for a, b in zip([0] + cuts[0], cuts[0] + lens)) <= 3 * 200 * sps
+
+
+@pytest.mark.parametrize("seg", [20, 33, 57])
+def test_header_with_cr_zero_ahead_of_a_cut(sim, oracle_mod, seg):
+    """A header whose CR field is 0 leaves d_phdr.cr = 0 behind: the NEXT header then decodes through neither Hamming
+    branch (no switch case, lib/decoder_impl.cc:655-675) and reads as zeros.  A segment job that speculated the
+    constructor's CR on that next header must not be merged, wherever the cut falls: segmented == serial."""
+    rng = np.random.default_rng(77 + seg)
+    pieces = []
+    for cr in (4, 0, 4, 2, 0, 0, 3, 4):
+        cfg = synth.TxConfig(sf=7, cr=cr)
+        p = bytes(rng.integers(0, 256, int(rng.integers(4, 20)), dtype=np.uint8))
+        pieces.append(synth.build_stream([p], cfg, rng=rng, tail_symbols=0.0).iq)
+    iq = np.concatenate(pieces + [np.zeros(4096, np.complex64)])
+    for ctor_cr in (4, 1):
+        want, wpos = _serial(oracle_mod, iq, 7, ctor_cr=ctor_cr)
+        for tails in (True, False):
+            got, gpos, stats = sim(iq, 7, ctor_cr=ctor_cr, seg=seg, slots=64, tails=tails)
+            assert got == want and gpos == wpos, (seg, ctor_cr, tails)
