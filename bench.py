@@ -236,46 +236,11 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     gat = gather.AsyncSlotGather(dev, max(64, 2 * n_frames_expected))
 
-    # One step = one full pass over the batch.  With depth >= 2 the passes are software-pipelined the way a streaming
-    # receiver runs them: the plan + launch of step k+1 (begin) is issued before the results of step k are collected, on the
-    # same HIP stream, so the device goes from one walker kernel straight to the next while the host stitches; the frames of
-    # step k go into an asynchronous all_gather that is collected while step k+1 runs.
-    def begin(k):   # the IQ is resident and unchanged: the envelope pre-pass need not wait for the stream (IQ_READY)
-        hs[k % depth].decode_device_begin(d_iq.data_ptr(), n_items, offs, lens, stream, iq_ready=True)
-
-    def prepass(k):
-        hs[k % depth].decode_device_prepass(d_iq.data_ptr(), n_items, offs, lens, stream, iq_ready=True)
-
-    def finish(k):
-        hk = hs[k % depth]
-        hk.decode_device_end()
-        done = gat.collect()                                  # step k-1's frames of every rank (None on the first step)
-        gat.submit(hk.drain_slots(gather.SLOT_BYTES))         # step k's frames: one asynchronous all_gather
-        return done, hk.timing()
-
-    def run(n_steps, keep=None):
-        wk, ln = 0.0, 0
-        if n_steps <= 0:
-            return wk, ln
-        begin(0)
-        if depth > 2 and n_steps > 1:
-            prepass(1)
-        for k in range(n_steps):
-            if depth > 2 and k + 2 < n_steps:
-                prepass(k + 2)
-            if depth > 1 and k + 1 < n_steps:
-                begin(k + 1)
-            done, tm = finish(k)
-            if keep is not None and done is not None:
-                keep.append(done)
-            wk += tm.walker_ms
-            ln += tm.walker_launches
-            if depth == 1 and k + 1 < n_steps:
-                begin(k + 1)
-        last = gat.collect()                                  # the final step's gather belongs to the timed region too
-        if keep is not None and last is not None:
-            keep.append(last)
-        return wk, ln
+    # One step = one full pass over the batch, software-pipelined the way a streaming receiver runs them
+    # (gr_lora_amd.gather.PassPipeline: begin(k+1) before end(k) on one HIP stream, the frames of step k in an asynchronous
+    # all_gather that is collected while step k+1 runs).
+    pipe = gather.PassPipeline(hs, gat, d_iq.data_ptr(), n_items, offs, lens, stream)
+    run = pipe.run
 
     # correctness of what is being timed (outside the timed region): frames as gathered, this rank's share, every handle
     kept = []

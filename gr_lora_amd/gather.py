@@ -185,7 +185,59 @@ class AsyncSlotGather:
                 ev.synchronize()
             blk = self.h_out[b].numpy()
         counts = [int(blk[r, 0, 0:8].view(np.int64)[0]) for r in range(blk.shape[0])]
-        return blk[:, 1:], counts
+        return blk[:, 1:].copy(), counts   # (a copy: the internal double buffers are reused two steps on)
+
+
+class PassPipeline:
+    """The software-pipelined pass loop bench.py times (and a streaming receiver runs): `depth` decoder handles alternate
+    on one HIP stream - begin(k+1) (plan + launch) is issued before end(k) (wait, stitch, frames), with depth 3 the
+    envelope pre-pass of k+2 ahead of that - and the frames of step k go into an AsyncSlotGather that is collected
+    while step k+1 runs.  `handles` need decode_device_begin / _prepass / _end, drain_slots and timing (gr_lora_amd.capi.Handle;
+    the CPU tests use a stub)."""
+
+    def __init__(self, handles, gatherer: AsyncSlotGather, dev_ptr: int, n_items: int, offs, lens, stream: int = 0):
+        self.hs, self.gat, self.depth = list(handles), gatherer, len(handles)
+        self.args = (dev_ptr, n_items, offs, lens, stream)
+
+    def _begin(self, k):   # the IQ is resident and unchanged: the envelope pre-pass need not wait for the stream (IQ_READY)
+        self.hs[k % self.depth].decode_device_begin(*self.args, iq_ready=True)
+
+    def _prepass(self, k):
+        self.hs[k % self.depth].decode_device_prepass(*self.args, iq_ready=True)
+
+    def _finish(self, k):
+        hk = self.hs[k % self.depth]
+        hk.decode_device_end()
+        done = self.gat.collect()                             # step k-1's frames of every rank (None on the first step)
+        self.gat.submit(hk.drain_slots(SLOT_BYTES))           # step k's frames: one asynchronous all_gather
+        return done, hk.timing()
+
+    def run(self, n_steps: int, keep=None):
+        """n_steps passes; returns (sum of walker kernel ms, walker launches).  `keep` (a list) receives every step's
+        gathered (slots, counts)."""
+        wk, ln = 0.0, 0
+        if n_steps <= 0:
+            return wk, ln
+        depth = self.depth
+        self._begin(0)
+        if depth > 2 and n_steps > 1:
+            self._prepass(1)
+        for k in range(n_steps):
+            if depth > 2 and k + 2 < n_steps:
+                self._prepass(k + 2)
+            if depth > 1 and k + 1 < n_steps:
+                self._begin(k + 1)
+            done, tm = self._finish(k)
+            if keep is not None and done is not None:
+                keep.append(done)
+            wk += tm.walker_ms
+            ln += tm.walker_launches
+            if depth == 1 and k + 1 < n_steps:
+                self._begin(k + 1)
+        last = self.gat.collect()                             # the final step's gather belongs to the run too
+        if keep is not None and last is not None:
+            keep.append(last)
+        return wk, ln
 
 
 def shard_streams(n_streams: int, rank: int, world: int) -> List[int]:

@@ -81,3 +81,98 @@ def test_gather_slots_single_process():
     mine = gather.pack_frames(frames, len(frames))
     slots, counts = gather.gather_slots(mine, torch.device("cpu"))
     assert counts == [11] and gather.unpack_frames(slots[0], 11) == frames
+
+
+class _StubTiming:
+    walker_ms = 0.25
+    walker_launches = 1
+
+
+class _StubHandle:
+    """Stands in for gr_lora_amd.capi.Handle on a machine without a GPU: `decode` of pass k yields frames that encode
+    (rank, handle, pass) so that the test can tell which pass every gathered block came from."""
+
+    def __init__(self, rank, idx, log):
+        self.rank, self.idx, self.log, self.n = rank, idx, log, 0
+        self.open = False
+
+    def decode_device_prepass(self, *a, **k):
+        self.log.append(("pre", self.idx))
+
+    def decode_device_begin(self, *a, **k):
+        assert not self.open
+        self.open = True
+        self.log.append(("begin", self.idx))
+
+    def decode_device_end(self):
+        assert self.open
+        self.open = False
+        self.log.append(("end", self.idx))
+
+    def drain_slots(self, slot_bytes):
+        assert slot_bytes == gather.SLOT_BYTES
+        k = self.n
+        self.n += 1
+        frames = [(bytes([self.rank, self.idx, k, j]) * 5, 10 * self.rank + j, 1000 * k + j) for j in range(1 + (self.rank + k) % 3)]
+        return gather.pack_frames(frames, len(frames))
+
+    def timing(self):
+        return _StubTiming()
+
+
+def _pipeline_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = {}
+    for depth in (1, 2, 3):
+        log = []
+        hs = [_StubHandle(rank, i, log) for i in range(depth)]
+        gat = gather.AsyncSlotGather(torch.device("cpu"), 8)
+        pipe = gather.PassPipeline(hs, gat, 0, 0, [0], [0], 0)
+        kept = []
+        wk, ln = pipe.run(5, kept)
+        assert (round(wk, 6), ln) == (1.25, 5) and len(kept) == 5
+        steps = []
+        for slots, counts in kept:
+            assert len(counts) == world
+            steps.append([gather.unpack_frames(slots[r], counts[r]) for r in range(world)])
+        if depth > 1: # pipelined: pass k + 1 is begun before pass k is ended
+            assert log.index(("begin", 1)) < log.index(("end", 0))
+        out[depth] = steps
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_bench_pass_pipeline_world2_gloo():
+    """The bench's step loop (PassPipeline + AsyncSlotGather: one asynchronous all_gather per step, collected a step
+    later) on two ranks over gloo with stub decoder handles: every step's gathered block holds exactly what each rank
+    produced in THAT step, in order, for every pipeline depth."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == res[1]                                   # every rank sees the same gathered frames
+    for depth in (1, 2, 3):
+        for k, step in enumerate(res[0][depth]):
+            for r in range(2):
+                n_pass = k // depth                           # the k-th pass overall is pass k // depth of handle k % depth
+                want = [(bytes([r, k % depth, n_pass, j]) * 5, 10 * r + j, 1000 * n_pass + j) for j in range(1 + (r + n_pass) % 3)]
+                assert step[r] == want, (depth, k, r)
+
+
+def test_async_gather_single_process():
+    g = gather.AsyncSlotGather(torch.device("cpu"), 4)
+    frames = [(b"abc" * 7, 3, 12345), (b"z" * 30, 1, 7)]
+    g.submit(gather.pack_frames(frames, 2))
+    slots, counts = g.collect()
+    assert counts == [2] and gather.unpack_frames(slots[0], 2) == frames
+    assert g.collect() is None
+    with pytest.raises(ValueError):
+        g.submit(gather.pack_frames(frames * 3, 6))
