@@ -1,18 +1,22 @@
 #!/usr/bin/env python3
 """Turns gpurun_out/prof_<tag>/ (tools/profile_round.sh) into the files committed under profiles/:
    profiles/<round>_<tag>_kernel_stats.csv   per-kernel stats (rocprofv3 --stats)
-   profiles/<round>_<tag>_pmc_traffic.json   HBM bytes per pass of the walker kernel (FETCH_SIZE / WRITE_SIZE)"""
+   profiles/<round>_<tag>_pmc_traffic.json   HBM bytes per pass of the walker kernel (FETCH_SIZE / WRITE_SIZE), keyed by the
+                                             workload and by the hash of the sources it was measured on (bench.py quotes it
+                                             as roofline.traffic only when both match)
+   profiles/<round>_<tag>_bench_line.json    the unprofiled bench line of the same command
+usage: tools/profile_summary.py <tag> <round>"""
 import collections, csv, glob, json, os, shutil, sys
 
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
 src = os.path.join("gpurun_out", "prof_" + tag)
 stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
 assert stats, "no kernel_stats.csv"
-shutil.copy(stats[0], os.path.join("profiles", "%s_%s_sf7_1024pkt_kernel_stats.csv" % (rnd, tag)))
+shutil.copy(stats[0], os.path.join("profiles", "%s_%s_kernel_stats.csv" % (rnd, tag)))
 
 def per_dispatch(kind, counter):
-    out = collections.defaultdict(list)  # grid size -> values
+    out = collections.defaultdict(list)  # (kernel, grid) -> values
     for path in glob.glob(os.path.join(src, kind, "**", "*counter_collection.csv"), recursive=True):
         acc, meta = collections.defaultdict(float), {}
         for row in csv.DictReader(open(path)):
@@ -26,31 +30,39 @@ def per_dispatch(kind, counter):
 
 fetch, write = per_dispatch("fetch", "FETCH_SIZE"), per_dispatch("write", "WRITE_SIZE")
 line = json.loads([l for l in open(os.path.join(src, "stats.log")).read().splitlines() if l.startswith("{\"metric\"")][-1])
+launches = max(1.0, float(line["roofline"].get("launches_per_pass", 1.0)))
 disp = {}
 fetch_raw = write_raw = pre_fetch = pre_write = 0.0
+walker_keys = [k for k in sorted(set(fetch) | set(write)) if "walker" in k[0]]
 for key in sorted(set(fetch) | set(write)):
     f = sum(fetch.get(key, [0])) / max(1, len(fetch.get(key, [])))
     w = sum(write.get(key, [0])) / max(1, len(write.get(key, [])))
     disp["%s grid %s" % key] = {"fetch_kb_avg": f, "write_kb_avg": w, "dispatches_fetch_pass": len(fetch.get(key, []))}
-    if "walker" in key[0]:
+    if "walker" in key[0]:   # (a pass may launch the walker more than once - probe jobs - with another grid size: every grid counts once per pass)
         fetch_raw += f * 1024.0
         write_raw += w * 1024.0
     else: # the segment-planning pre-pass (envelope_kernel, edges_kernel)
         pre_fetch += f * 1024.0
         pre_write += w * 1024.0
 res = {
-    "command": "tools/profile_round.sh %s: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline" % tag,
+    "command": "tools/profile_round.sh %s: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline <workload arguments>" % tag,
+    "workload": line["config"]["workload"],
+    "workload_key": line["config"].get("workload_key"),
+    "source_hash": line["config"].get("source_hash"),
     "workload_items": line["config"]["items_per_gpu"],
-    "units": "FETCH_SIZE / WRITE_SIZE are KB per dispatch (rocprofv3); one pass = one dispatch of each grid size listed",
+    "units": "FETCH_SIZE / WRITE_SIZE are KB per dispatch (rocprofv3); one pass = one dispatch of each walker grid size listed",
     "dispatches": disp,
     "fetch_bytes_per_pass_raw": fetch_raw,
     "write_bytes_per_pass_raw": write_raw,
-    "gfx950_fetch_correction": "x2 (MI355X_MICROARCH.md, HBM section: FETCH_SIZE tallies 128-B requests at 64 B); calibrated for this kernel's access "
-                               "pattern (8 B per lane, 512 contiguous bytes per wave instruction) with tools/calib_fetch.hip: FETCH_SIZE = 0.500 x bytes read; "
-                               "WRITE_SIZE is uncalibrated",
+    "gfx950_fetch_correction": "x2 (MI355X_MICROARCH.md, HBM section: FETCH_SIZE tallies 128-B requests at 64 B); calibrated for 8-byte-per-lane coalesced reads "
+                               "(512 contiguous bytes per wave instruction) with tools/calib_fetch.hip: FETCH_SIZE = 0.500 x bytes read; WRITE_SIZE is uncalibrated",
     "hbm_bytes_per_pass_corrected": 2.0 * fetch_raw + write_raw,
     "prepass_hbm_bytes_per_pass_corrected": 2.0 * pre_fetch + pre_write,
     "algorithmic_bytes_per_pass": 8 * line["config"]["items_per_gpu"],
+    "traffic_over_algorithmic": (2.0 * fetch_raw + write_raw) / (8.0 * line["config"]["items_per_gpu"]),
 }
 json.dump(res, open(os.path.join("profiles", "%s_%s_pmc_traffic.json" % (rnd, tag)), "w"), indent=1)
-print(json.dumps(res, indent=1)[:1500])
+lj = os.path.join(src, "line.json")
+if os.path.exists(lj) and os.path.getsize(lj) > 10:
+    shutil.copy(lj, os.path.join("profiles", "%s_%s_bench_line.json" % (rnd, tag)))
+print(json.dumps({k: res[k] for k in ("workload_key", "hbm_bytes_per_pass_corrected", "algorithmic_bytes_per_pass", "traffic_over_algorithmic")}))
