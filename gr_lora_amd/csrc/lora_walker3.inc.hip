@@ -158,9 +158,10 @@ __device__ __forceinline__ float w3_uni(float v) { return __builtin_bit_cast(flo
 // on it - the whole replicated state machine - stays in scalar registers
 __device__ __forceinline__ bool w3_ub(bool b) { return __builtin_amdgcn_readfirstlane(b ? 1 : 0) != 0; }
 
-// ---- group reductions: every thread gets the totals of EVERY group (uniform); one barrier; slots alternate --------
+// ---- group reductions: one barrier; slots alternate.  Every thread gets the totals of its OWN group (uniform); with `all`
+// (wave-uniform) the totals of EVERY group - what thread 0's replay consumes, so only its wavefront pays for them --------
 template <int SF, int K>
-__device__ __forceinline__ void w3_group_sums(float (&v)[K], W3Shared &ws, int &slot, int grp, int gwave, float (&out)[W3Geom<SF>::NG][K])
+__device__ __forceinline__ void w3_group_sums(float (&v)[K], W3Shared &ws, int &slot, int grp, int gwave, float (&out)[W3Geom<SF>::NG][K], bool all = true)
 {
     using G = W3Geom<SF>;
     const int lane = threadIdx.x & 63;
@@ -174,7 +175,12 @@ __device__ __forceinline__ void w3_group_sums(float (&v)[K], W3Shared &ws, int &
     }
     __syncthreads();
 #pragma unroll
-    for (int g = 0; g < G::NG; g++)
+    for (int g = 0; g < G::NG; g++) {
+        if (!all && g != grp) {
+#pragma unroll
+            for (int k = 0; k < K; k++) out[g][k] = 0.0f;
+            continue;
+        }
 #pragma unroll
         for (int k = 0; k < K; k++) {
             float s = 0.0f;
@@ -182,11 +188,12 @@ __device__ __forceinline__ void w3_group_sums(float (&v)[K], W3Shared &ws, int &
             for (int w = 0; w < G::GW; w++) s += red[g][w * K + k];
             out[g][k] = w3_uni(s);
         }
+    }
 }
 
 template <int SF>
 __device__ __forceinline__ void w3_group_argmax_first(float v, int idx, W3Shared &ws, int &slot, int grp, int gwave, float (&bv_out)[W3Geom<SF>::NG],
-                                                      int (&bi_out)[W3Geom<SF>::NG])
+                                                      int (&bi_out)[W3Geom<SF>::NG], bool all = true)
 {
     using G = W3Geom<SF>;
     const int lane = threadIdx.x & 63;
@@ -202,6 +209,7 @@ __device__ __forceinline__ void w3_group_argmax_first(float v, int idx, W3Shared
     __syncthreads();
 #pragma unroll
     for (int g = 0; g < G::NG; g++) {
+        if (!all && g != grp) { bv_out[g] = 0.0f; bi_out[g] = 0; continue; }
         float bv = red[g][0];
         int bi = ((int *)red[g])[32];
 #pragma unroll
@@ -288,8 +296,11 @@ struct W3DemodOut { uint32_t s[4]; int32_t fine[4]; float en[4]; int slot; };
 struct W3DemodArgs { const float2 *down, *ctab; const float *up_ifreq_v; uint32_t enable_fine_sync, demod_mode; };
 template <int SF>
 __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds<SF> &L, const float2 *__restrict__ x, bool valid, bool want_energy, int &slot,
-                                               uint32_t (&s_out)[W3Geom<SF>::NG], int32_t (&fine_out)[W3Geom<SF>::NG], float (&en_out)[W3Geom<SF>::NG])
+                                               uint32_t (&s_out)[W3Geom<SF>::NG], int32_t (&fine_out)[W3Geom<SF>::NG], float (&en_out)[W3Geom<SF>::NG],
+                                               long long *stamps = nullptr /* tools/demod_bench.py --stamps: clock per phase */)
 {
+#define LORA_W3STAMP(i) do { if (stamps) stamps[i] = clock64(); } while (0)
+    LORA_W3STAMP(0);
     using G = W3Geom<SF>;
     constexpr int N = G::N, SPS = G::SPS, TG = G::TG, CH = G::CH, M2 = G::M2, AR = G::AR, SA = G::SA, PAIRS = G::PAIRS, ROUNDS = G::ROUNDS, NG = G::NG;
     int tt = threadIdx.x;
@@ -313,8 +324,13 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
             const int base = p * TG + t;
             const uint32_t ob = 8u * ((uint32_t)(p * TG) + tu); // byte offset of this thread's sample inside a chunk
             v2f a[16];
+#ifdef LORA_W3_SYNTH_X // experiment: no HBM read
+#pragma unroll
+            for (int c = 0; c < 16; c++) a[c] = (v2f){(float)(t + c), (float)(t ^ c)};
+#else
 #pragma unroll
             for (int c = 0; c < 16; c++) a[c] = w3_ld2(xb, ob, (uint32_t)(c * CH * 8));
+#endif
             if (want_energy) {
 #pragma unroll
                 for (int c = 0; c < 16; c++) en += a[c].x * a[c].x + a[c].y * a[c].y;
@@ -375,6 +391,7 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
         }
     }
 
+    LORA_W3STAMP(1);
     float bv = -1.0f;
     int bi = 0x7fffffff;
 #pragma unroll
@@ -393,6 +410,7 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
             }
         }
         __syncthreads();
+        if (g == 0) LORA_W3STAMP(2);
         // ---- pass 2 (in place) ----
         if (valid) {
             const int row = (t >> 3) % AR, q1 = __builtin_amdgcn_readfirstlane(t / (8 * AR)); // (8 AR >= 64: the same in all lanes)
@@ -413,7 +431,9 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
 #pragma unroll
             for (int m = 0; m < 16; m++) pe[M2 * 8 * m] = a[m];
         }
+        if (g == 0) LORA_W3STAMP(3);
         __syncthreads();
+        if (g == 0) LORA_W3STAMP(4);
         // ---- pass 3 + combine ----
         if (valid) {
             const int w = t >> 3, row = w % AR, wl = w / AR;
@@ -457,14 +477,17 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
             bi = better ? k1 : bi;
         }
     }
+    LORA_W3STAMP(5);
+    const bool all = grp == 0 && gwave == 0; // thread 0's wavefront: the replay needs every group's results
     float bvs[NG];
     int bis[NG];
-    w3_group_argmax_first<SF>(bv, bi, ws, slot, grp, gwave, bvs, bis);
+    w3_group_argmax_first<SF>(bv, bi, ws, slot, grp, gwave, bvs, bis, all);
+    LORA_W3STAMP(6);
 #pragma unroll
     for (int g = 0; g < NG; g++) { s_out[g] = (uint32_t)bis[g]; fine_out[g] = 0; en_out[g] = 0.0f; }
     if (want_energy) {
         float e1[1] = {en}, eo[NG][1];
-        w3_group_sums<SF, 1>(e1, ws, slot, grp, gwave, eo);
+        w3_group_sums<SF, 1>(e1, ws, slot, grp, gwave, eo, all);
 #pragma unroll
         for (int g = 0; g < NG; g++) en_out[g] = eo[g][0];
     }
@@ -512,8 +535,11 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
             }
         }
     }
+    LORA_W3STAMP(7);
     float co[NG][3];
-    w3_group_sums<SF, 3>(cs, ws, slot, grp, gwave, co);
+    w3_group_sums<SF, 3>(cs, ws, slot, grp, gwave, co, all);
+    LORA_W3STAMP(8);
+#undef LORA_W3STAMP
 #pragma unroll
     for (int g = 0; g < NG; g++) {
         float mx = 0.0f;
@@ -560,7 +586,7 @@ __device__ __forceinline__ void w3_detect_round(const float2 *__restrict__ x, bo
             }
         }
     }
-    w3_group_sums<SF, 4>(a, ws, slot, grp, gwave, out);
+    w3_group_sums<SF, 4>(a, ws, slot, grp, gwave, out, grp == 0 && gwave == 0);
 }
 
 // ---- SYNC (:770-783, detect_upchirp :392-413), all threads of the workgroup together --------------------------
@@ -1158,7 +1184,7 @@ __global__ __launch_bounds__(1024, 4) void walker3_kernel_sf12(DevParams P, Laun
 // ---- symbol-level kernel: one group per symbol, for lora_hip_demod_symbols_device ------------------------------
 template <int SF>
 __global__ __launch_bounds__(1024, 4) void demod_symbols_w3_kernel(DevParams P, const float2 *iq, const int64_t *offsets, uint32_t n,
-                                                                    uint32_t *bins, int32_t *fine)
+                                                                    uint32_t *bins, int32_t *fine, long long *stamps_out)
 {
     using G = W3Geom<SF>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1172,7 +1198,11 @@ __global__ __launch_bounds__(1024, 4) void demod_symbols_w3_kernel(DevParams P, 
         uint32_t b[G::NG];
         int32_t fs[G::NG];
         float en[G::NG];
-        w3_demod_round<SF>(W3DemodArgs{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode}, L, iq + offsets[valid ? s0 + grp : s0], valid, false, slot, b, fs, en);
+        long long stamps[9];
+        w3_demod_round<SF>(W3DemodArgs{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode}, L, iq + offsets[valid ? s0 + grp : s0], valid, false, slot, b, fs, en,
+                           stamps_out ? stamps : nullptr);
+        if (stamps_out && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && s0 == blockIdx.x * G::NG + gridDim.x * G::NG) // (second round of block 0: every wavefront's stamps)
+            for (int i = 0; i < 9; i++) stamps_out[(threadIdx.x >> 6) * 9 + i] = stamps[i];
         if (threadIdx.x == 0) {
             for (int g = 0; g < G::NG; g++)
                 if (s0 + (uint32_t)g < n) { bins[s0 + g] = b[g]; if (fine) fine[s0 + g] = fs[g]; }
