@@ -7,6 +7,7 @@
 
 #include <cstdlib>
 #include <iostream>
+#include <string>
 
 namespace gr {
 namespace lora {
@@ -25,8 +26,19 @@ decoder_impl::decoder_impl(float samp_rate, uint32_t bandwidth, uint8_t sf, bool
     c.struct_size = sizeof c;
     c.samp_rate = samp_rate; c.bandwidth = bandwidth; c.sf = sf; c.implicit = implicit; c.cr = cr; c.crc = crc;
     c.reduced_rate = reduced_rate; c.disable_drift_correction = disable_drift_correction;
+    /* make() has no argument for these (its signature is the reference's): process-wide settings from the environment */
     c.device = 0;
+    if (const char *e = std::getenv("LORA_HIP_DEVICE")) c.device = std::atoi(e);
     c.demod = LORA_HIP_DEMOD_FFT_COMPAT; /* LORA_HIP_DEMOD_GRAD selects the upstream default estimator */
+    if (const char *e = std::getenv("LORA_HIP_DEMOD")) {
+        const std::string v(e);
+        if (v == "grad") c.demod = LORA_HIP_DEMOD_GRAD;
+        else if (v == "fft") c.demod = LORA_HIP_DEMOD_FFT;
+        else if (v != "fft_compat") {
+            std::cerr << "[LoRa Decoder] ERROR : LORA_HIP_DEMOD must be one of grad, fft, fft_compat" << std::endl;
+            exit(1);
+        }
+    }
     const lora_hip_status s = lora_hip_create(&c, &d_h);
     if (s != LORA_HIP_OK) { /* the reference prints and exit(1)s on a bad configuration (decoder_impl.cc:57-61) */
         std::cerr << "[LoRa Decoder] ERROR : " << lora_hip_strerror(s) << ": " << lora_hip_last_error(nullptr) << std::endl;

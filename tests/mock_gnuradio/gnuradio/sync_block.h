@@ -16,7 +16,9 @@ typedef std::vector<const void *> gr_vector_const_void_star;
 typedef std::vector<void *> gr_vector_void_star;
 
 namespace gr {
-class sync_block {
+class basic_block { public: virtual ~basic_block() {} };   // (the binding names the three base types, decoder_python.cc:36)
+class block : public basic_block {};
+class sync_block : public block {
 public:
     // what the mock runtime records
     std::string mock_name;
