@@ -736,6 +736,14 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                     w2_end_step(L, job, C, recs, trace, kFindSfd, (int32_t)sps + fw, -1, fw, cw, t_start, t0);
                     if (L.state != kFindSfd || L.done || fw != 0) break;
                 }
+                // PAUSE (:820-824) looks at no sample: the step is taken here, behind its own loop-top checks, instead of
+                // in a round of its own (a barrier, a plan hand-over and ~4 k clocks per packet)
+                if (L.state == kPause && !L.done && w2_pre_step(L, job, rec_cap, sps)) {
+                    L.state = kDecodeHeader;
+                    const int32_t consumed = (int32_t)(sps + sps / 4u);
+                    L.att_hdr = L.pos + consumed;
+                    w2_end_step(L, job, C, recs, trace, kPause, consumed, -1, 0, 0.0f, t_start, t0);
+                }
                 W2Plan np;
                 plan_from(L, np);
                 if (t0) { next = np; S = L; }

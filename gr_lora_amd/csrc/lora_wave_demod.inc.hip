@@ -172,8 +172,12 @@ __device__ __forceinline__ v2f lean_atan2_pk(v2f y, v2f x)
     const float ax0 = fabsf(x.x), ay0 = fabsf(y.x), ax1 = fabsf(x.y), ay1 = fabsf(y.y);
     const float mx0 = fmaxf(fmaxf(ax0, ay0), 1.0e-37f), mx1 = fmaxf(fmaxf(ax1, ay1), 1.0e-37f); // atan2(0, 0) = 0
     v2f a;
-    a.x = fminf(ax0, ay0) * __builtin_amdgcn_rcpf(mx0);
-    a.y = fminf(ax1, ay1) * __builtin_amdgcn_rcpf(mx1);
+    // (written out: behind inline-asm producers the compiler canonicalises both fminf operands with a v_max x, x each)
+    float mn0, mn1;
+    asm("v_min_f32_e64 %0, |%1|, |%2|" : "=v"(mn0) : "v"(x.x), "v"(y.x));
+    asm("v_min_f32_e64 %0, |%1|, |%2|" : "=v"(mn1) : "v"(x.y), "v"(y.y));
+    a.x = mn0 * __builtin_amdgcn_rcpf(mx0);
+    a.y = mn1 * __builtin_amdgcn_rcpf(mx1);
     const v2f s = a * a;
     v2f p = (v2f){-0.0040545230731368065f, -0.0040545230731368065f};
     p = __builtin_elementwise_fma(p, s, (v2f){0.02186279185116291f, 0.02186279185116291f});
@@ -192,12 +196,21 @@ __device__ __forceinline__ v2f lean_atan2_pk(v2f y, v2f x)
     return (v2f){copysignf(r0, y.x), copysignf(r1, y.y)};
 }
 
-// instantaneous frequency (:231-240) of two adjacent-sample pairs: arg(cur * conj(prev))
+// instantaneous frequency (:231-240) of two adjacent-sample pairs: arg(cur * conj(prev)).  The products are written out
+// (cur * conj(prev) = cur.xx * (prev.x, -prev.y) + cur.yy * (prev.y, prev.x): two packed instructions on the registers
+// the samples are in; from vector code the compiler first gathers (c0.y, c1.y), (p0.x, p1.x), ... with four v_mov per pair)
+__device__ __forceinline__ v2f cmul_conj(v2f c, v2f p)
+{
+    v2f t, z;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(c), "v"(p));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(z) : "v"(c), "v"(p), "v"(t));
+    return z; // (re, im)
+}
 __device__ __forceinline__ v2f ifreq_prod_pk(v2f p0, v2f c0, v2f p1, v2f c1)
 {
-    const v2f im = (v2f){c0.y * p0.x - c0.x * p0.y, c1.y * p1.x - c1.x * p1.y};
-    const v2f re = (v2f){c0.x * p0.x + c0.y * p0.y, c1.x * p1.x + c1.y * p1.y};
-    return lean_atan2_pk(im, re);
+    const v2f z0 = cmul_conj(c0, p0), z1 = cmul_conj(c1, p1);
+    const float y0 = z0.y, y1 = z1.y, x0 = z0.x, x1 = z1.x;
+    return lean_atan2_pk((v2f){y0, y1}, (v2f){x0, x1});
 }
 
 // Demodulates the symbol window x[0 .. sps): s_out = get_shift_fft's return value, fine_out = d_fine_sync after
@@ -230,7 +243,9 @@ __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const Wave
 #endif
     if (EARLY_F && want_fine) {
         // sample n - 1 of this lane's n = 64 j + lane sits in the neighbouring lane (lane 0: lane 63 of the previous
-        // register): one wave rotate per register instead of a second, dependent round of loads
+        // register): one wave rotate per register instead of a second, dependent round of loads.  (A second batch of
+        // loads one item down saves 8 VALU slots per sample pair and was measured 8 % SLOWER in the walker: the round's
+        // first-touch loads queue behind twice as many requests.)
         v2f bprev = (v2f){0.0f, 0.0f};
 #pragma unroll
         for (int j = 0; j < J; j += 2) {
@@ -284,6 +299,8 @@ __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const Wave
 #pragma unroll
     for (int m = 0; m < J; m++) a[m] = cmulw(a[m], LORA_WD_TAB(T.tws4[m * 64 + lane], lane)); // W_sps^{k r} (+ fold)
     // reduce-scatter over r = lane bits 2, 1, 0: lanes with the bit clear keep the first half of the registers
+    // (Measured and dropped: the same steps as v_add_f32 with a DPP operand written out in asm - fewer issue slots on paper,
+    // 13 % slower in the walker: the volatile sequence no longer interleaves with the table loads around it.)
     v2f b4[J / 2], b2[J / 4], b1[J / 8];
 #pragma unroll
     for (int i = 0; i < J / 2; i++) { // lane bit 2: row_shr:4 into banks 1,3 / row_shl:4 into banks 0,2
@@ -345,16 +362,17 @@ __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const Wave
     // fine_sync (:300-338) with search = max(D/4, 2) = 2 -> lags -1, 0, +1
     const uint32_t bin_idx = (s == 0u && P.demod_mode == 2u) ? 0u : (s + (uint32_t)N - 1u) % (uint32_t)N;
     const float *__restrict__ v = T.v + ((int)(bin_idx + 1u) * 8 + SPS);
+    // sample n = 64 j + lane carries ifreq[k], k = n - 1, against v[k - 1], v[k], v[k + 1]: one lane-dependent base and
+    // immediate offsets.  (Lane 0, j = 0 has no k: its f is 0 and it reads the finite table entries in front of v.)
+    const float *__restrict__ vp = v + (nl - 2);
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
 #pragma unroll
     for (int j = 0; j < J; j++) {
-        const int n = j * 64 + nl;
-        const int k = (n >= 1) ? n - 1 : 1; // f[j] is 0 for the non-existent k = -1
         const float fj = f[j];
-        c0 += fj * v[k - 1]; c1 += fj * v[k]; c2 += fj * v[k + 1];
+        c0 += fj * vp[64 * j]; c1 += fj * vp[64 * j + 1]; c2 += fj * vp[64 * j + 2];
         if (j == J - 1) { // ifreq[sps-1] = ifreq[sps-2] (:243): the lane that owns n = sps-1 adds the duplicated tap
             const float fl = (nl == 63) ? fj : 0.0f;
-            c0 += fl * v[k]; c1 += fl * v[k + 1]; c2 += fl * v[k + 2];
+            c0 += fl * vp[64 * j + 1]; c1 += fl * vp[64 * j + 2]; c2 += fl * vp[64 * j + 3];
         }
     }
     c0 = wave_sum_u(c0); c1 = wave_sum_u(c1); c2 = wave_sum_u(c2);
