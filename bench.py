@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import argparse
 import hashlib
+import re
 import json
 import os
 import socket
@@ -123,14 +124,21 @@ def cpu_baseline(cfg, iq, offs, lens, budget_s=20.0):
     return out
 
 
-def source_hash():
+def _strip_comments(text):
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    return re.sub(r"\s+", "", text)
+
+
+def source_hash(raw=False):
     """sha256 over the kernel / runtime sources: ties a quoted PMC figure to the code it was measured on (the GPU box has
-    no .git to ask)"""
+    no .git to ask).  Comments and white space do not count (raw=True: the files byte for byte)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "gr_lora_amd", "csrc")
     for name in sorted(os.listdir(d)):
         with open(os.path.join(d, name), "rb") as f:
-            h.update(name.encode() + b"\0" + f.read())
+            data = f.read()
+        h.update(name.encode() + b"\0" + (data if raw else _strip_comments(data.decode("utf-8", "replace")).encode()))
     return h.hexdigest()[:16]
 
 

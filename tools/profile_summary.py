@@ -29,6 +29,13 @@ def per_dispatch(kind, counter):
     return out
 
 fetch, write = per_dispatch("fetch", "FETCH_SIZE"), per_dispatch("write", "WRITE_SIZE")
+# the hash bench.py compares is over the sources without comments and white space; it is computed HERE, after checking that the
+# box ran exactly these files (the profiled bench line carries the hash it computed there)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+_line0 = json.loads([l for l in open(os.path.join(src, "stats.log")).read().splitlines() if l.startswith("{\"metric\"")][-1])
+assert _line0["config"].get("source_hash") in (bench.source_hash(), bench.source_hash(raw=True)), "profile taken on other sources than the working tree"
+code_hash = bench.source_hash()
 line = json.loads([l for l in open(os.path.join(src, "stats.log")).read().splitlines() if l.startswith("{\"metric\"")][-1])
 launches = max(1.0, float(line["roofline"].get("launches_per_pass", 1.0)))
 disp = {}
@@ -48,7 +55,7 @@ res = {
     "command": "tools/profile_round.sh %s: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline <workload arguments>" % tag,
     "workload": line["config"]["workload"],
     "workload_key": line["config"].get("workload_key"),
-    "source_hash": line["config"].get("source_hash"),
+    "source_hash": code_hash,
     "workload_items": line["config"]["items_per_gpu"],
     "units": "FETCH_SIZE / WRITE_SIZE are KB per dispatch (rocprofv3); one pass = one dispatch of each walker grid size listed",
     "dispatches": disp,
