@@ -2,8 +2,8 @@
 // Included by lora_kernels.hip.
 //
 // Same state machine as walker_body (decoder_impl::work, lib/decoder_impl.cc:740-903), organised in
-// ROUNDS: WAVES wavefronts = WAVES-1 workers + 1 control wavefront (SF7: one 1024-thread workgroup per CU,
-// 15 workers; SF8: 512 threads, 7 workers).  In DETECT, FIND_SFD and DECODE_*
+// ROUNDS: WAVES wavefronts = WAVES-1 workers + 1 control wavefront (512 threads: 7 workers; two workgroups per CU
+// at SF7.  A 16-wavefront workgroup with 15 workers was built and measured 30 % slower).  In DETECT, FIND_SFD and DECODE_*
 // every worker evaluates one upcoming symbol window at pos + w*sps (zero drift assumed); the control
 // thread then replays the reference's per-call logic over the results in order and stops at the first
 // one whose outcome invalidates the later windows (a trigger, a state change, d_fine_sync != 0, end of

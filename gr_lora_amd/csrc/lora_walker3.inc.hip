@@ -22,14 +22,20 @@
 // (8 r x 2 rows) always cover distinct banks.
 //
 // fine_sync (:300-338) for the three lags of a payload symbol uses the window's instantaneous frequency, computed from
-// the samples while they are in registers for the dechirp (x[n-1] is the neighbouring lane's sample: one DPP wave
-// rotate; lane 0 takes it from one extra load per wavefront that fetches all 16 chunk-boundary samples at once).
+// the samples while they are in registers for the dechirp (x[n-1] by a second buffer load one item down: the same
+// cache lines); at SF12, where the sixteen samples of both pairs do not fit beside the held rows, from a second read of
+// the window behind the arg-max (LATE_F).
 //
-// The state machine is the reference's work() (:740-903), replicated uniformly in every thread like the generic
-// walker's; the symbol clock's serial dependency (d_fine_sync, :321,:856,:883) therefore needs no speculation.
-// DETECT, SYNC (closed form over block-wide prefix sums) and FIND_SFD (one-pass Pearson, closed-form 63-lag
-// fine_sync) are workgroup-cooperative too.  Latency is covered by the other workgroups of the CU (SF9: 4 x 256
-// threads, SF10: 2 x 512, SF11 / SF12: 1 x 1024 - 16 wavefronts per CU in every case).
+// A workgroup is 1024 threads = NG groups of TG threads (SF9: 4 x 256, SF10: 2 x 512, SF11 / SF12: 1 x 1024), one
+// workgroup per CU; every group demodulates ONE symbol window, so a round evaluates NG consecutive windows speculatively
+// (zero drift assumed), as walker2's workers do.  The state machine is the reference's work() (:740-903): the decoder
+// state lives in LDS (W3Shared::st) and thread 0 replays the round's results over a register copy of it, in order,
+// stopping at the first window whose outcome invalidates the later ones (a state change, d_fine_sync != 0 :321,:856,
+// :883, the scan limit, the end of the data); every thread reads the next round's plan from LDS (double-buffered) into
+// scalar registers.  DETECT (NG groups x 4 windows), SYNC (closed form over block-wide prefix sums in double, all 1024
+// threads), FIND_SFD (one-pass Pearson + closed-form 63-lag fine_sync per group) and the finalisation of a frame are
+// rounds of the same loop; a job that reaches its scan limit carries on as the next segment's tail probe (second phase,
+// as in walker2).
 
 template <int SF> struct W3Geom {
     static constexpr int N = 1 << SF, SPS = 8 * N;
