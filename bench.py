@@ -130,12 +130,17 @@ def _strip_comments(text):
     return re.sub(r"\s+", "", text)
 
 
+# what a decode pass is made of: the kernels, the device structs, the scheduler and the runtime that plans and launches
+HASHED_SOURCES = ("lora_device.h", "lora_kernels.hip", "lora_runtime.cpp", "lora_stitch.hpp", "lora_walker2.inc.hip",
+                  "lora_walker3.inc.hip", "lora_wave_demod.inc.hip", "whitening_data.inc")
+
+
 def source_hash(raw=False):
-    """sha256 over the kernel / runtime sources: ties a quoted PMC figure to the code it was measured on (the GPU box has
-    no .git to ask).  Comments and white space do not count (raw=True: the files byte for byte)."""
+    """sha256 over the sources of the decode pass: ties a quoted PMC figure to the code it was measured on (the GPU box
+    has no .git to ask).  Comments and white space do not count (raw=True: the files byte for byte)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "gr_lora_amd", "csrc")
-    for name in sorted(os.listdir(d)):
+    for name in HASHED_SOURCES:
         with open(os.path.join(d, name), "rb") as f:
             data = f.read()
         h.update(name.encode() + b"\0" + (data if raw else _strip_comments(data.decode("utf-8", "replace")).encode()))

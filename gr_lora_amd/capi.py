@@ -22,7 +22,7 @@ EXPORTS = [
     "lora_hip_abi_version", "lora_hip_strerror", "lora_hip_last_error", "lora_hip_create", "lora_hip_destroy",
     "lora_hip_get_geometry", "lora_hip_set_sf", "lora_hip_set_samp_rate", "lora_hip_work", "lora_hip_flush",
     "lora_hip_decode_device", "lora_hip_frames_available", "lora_hip_poll_frame", "lora_hip_drain_frames", "lora_hip_drain_slots", "lora_hip_demod_symbols_device", "lora_hip_demod_symbols_ex_device",
-    "lora_hip_last_timing", "lora_hip_last_plan", "lora_hip_gap_starts_device", "lora_hip_decode_device_begin", "lora_hip_decode_device_end", "lora_hip_decode_device_prepass", "lora_hip_trace", "lora_hip_trace_clear",
+    "lora_hip_last_timing", "lora_hip_last_plan", "lora_hip_gap_starts_device", "lora_hip_decode_device_begin", "lora_hip_decode_device_end", "lora_hip_decode_device_prepass", "lora_hip_trace", "lora_hip_trace_clear", "lora_hip_check_frame", "lora_hip_estimate_cfo_device",
 ]
 
 
@@ -60,6 +60,12 @@ class Timing(C.Structure):
     _fields_ = [("walker_ms", C.c_float), ("total_device_ms", C.c_float), ("walker_launches", C.c_uint32),
                 ("jobs", C.c_uint32), ("probes", C.c_uint32), ("slow_path_relaunches", C.c_uint32),
                 ("items", C.c_uint64)]
+
+
+class FrameCheck(C.Structure):
+    _fields_ = [("has_header", C.c_uint8), ("header_checksum_ok", C.c_uint8), ("has_crc", C.c_uint8), ("crc_ok", C.c_uint8),
+                ("header_checksum_rx", C.c_uint8), ("header_checksum_calc", C.c_uint8), ("crc_rx", C.c_uint16), ("crc_calc", C.c_uint16),
+                ("reserved", C.c_uint16)]
 
 
 class LoraHipError(RuntimeError):
@@ -120,6 +126,10 @@ def load():
     L.lora_hip_trace.argtypes = [vp, C.POINTER(C.POINTER(Step))]
     L.lora_hip_trace_clear.argtypes = [vp]
     L.lora_hip_trace_clear.restype = None
+    L.lora_hip_estimate_cfo_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_int64), C.c_size_t, C.c_int, C.POINTER(C.c_float), vp]
+    L.lora_hip_estimate_cfo_device.restype = C.c_int
+    L.lora_hip_check_frame.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(FrameCheck)]
+    L.lora_hip_check_frame.restype = C.c_int
     L.lora_hip_channelizer_create.argtypes = [C.POINTER(ChannelizerConfig), C.POINTER(vp)]
     L.lora_hip_channelizer_destroy.argtypes = [vp]
     L.lora_hip_channelizer_destroy.restype = None
@@ -135,6 +145,15 @@ def load():
     L.lora_hip_channelizer_last_kernel_ms.restype = C.c_float
     _lib = L
     return L
+
+
+def check_frame(blob: bytes) -> FrameCheck:
+    """Header checksum and payload CRC of a published frame blob (lora_hip_check_frame: host only, no GPU needed)."""
+    out = FrameCheck()
+    st = load().lora_hip_check_frame(bytes(blob), len(blob), C.byref(out))
+    if st != 0:
+        raise LoraHipError(st, "lora_hip_check_frame: blob too short")
+    return out
 
 
 class Handle:
@@ -156,6 +175,7 @@ class Handle:
         a, b, d = C.c_uint32(), C.c_uint32(), C.c_uint32()
         self.L.lora_hip_get_geometry(self.h, C.byref(a), C.byref(b), C.byref(d))
         self.sps, self.nbins, self.decim = a.value, b.value, d.value
+        self.device, self.batch_items = int(device), int(batch_items)
 
     def close(self):
         if getattr(self, "h", None):
@@ -227,6 +247,14 @@ class Handle:
         self._check(self.L.lora_hip_demod_symbols_ex_device(self.h, dev_ptr, total_items, off.ctypes.data, off.size, demod, out.ctypes.data,
                                                             fine.ctypes.data, stream))
         return out, fine
+
+    def estimate_cfo_device(self, dev_ptr: int, total_items: int, offsets: Sequence[int], mode: int = 1, stream: int = 0) -> np.ndarray:
+        """CFO in Hz of the windows at `offsets` (experimental_determine_cfo, decoder_impl.cc:730-738; mode 1: mean over the window)."""
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        out = np.zeros(off.size, dtype=np.float32)
+        self._check(self.L.lora_hip_estimate_cfo_device(self.h, C.c_void_p(dev_ptr), total_items, off.ctypes.data_as(C.POINTER(C.c_int64)), off.size, mode,
+                                                        out.ctypes.data_as(C.POINTER(C.c_float)), C.c_void_p(stream)))
+        return out
 
     def frames_available(self) -> int:
         return self.L.lora_hip_frames_available(self.h)

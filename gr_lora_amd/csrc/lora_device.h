@@ -47,7 +47,7 @@ struct DevParams {
     float    down_ifreq_dsum;   // sum over sps-1 points of (down_ifreq - down_ifreq_avg): float residue
     double   sync_a, sync_b;    // least-squares line a + b*k through d_upchirp_ifreq[0 .. sps-2] (closed-form SYNC)
     uint32_t sync_closed_form;  // use the O(sps) SYNC (sps >= 4096)
-    uint32_t pad0;
+    uint32_t samples_per_second; // d_samples_per_second (:74), for the CFO estimate's Hz scale
     const float2 *down;         // d_downchirp
     const float  *up_ifreq;     // d_upchirp_ifreq
     const float  *down_ifreq;   // d_downchirp_ifreq
@@ -144,6 +144,7 @@ int launch_envelope(const float2 *iq, const EnvStream *streams /* host table; fi
 int launch_walker(const DevParams &p, const LaunchCfg &c, void *stream);
 int launch_demod_symbols(const DevParams &p, const float2 *iq, const int64_t *d_offsets, uint32_t n,
                          int demod, uint32_t *d_bins, int32_t *d_fine, float *scratch, void *stream);
+int launch_cfo(const DevParams &p, const float2 *iq, const int64_t *d_offsets, uint32_t n, int mode, float *d_out, void *stream); // N4: explicit CFO estimate
 bool walker3_covers(uint32_t sf);                                          // SF9-12: lora_walker3.inc.hip
 uint32_t w3_tw_entries(uint32_t sf);
 void build_w3_tables(uint32_t sf, float2 *tw, float2 *ctab /* sps entries */);

@@ -239,7 +239,7 @@ lora_hip_status build_tables(lora_hip_decoder *h)
         return fail(h, LORA_HIP_ERR_BAD_CONFIG, "samples per symbol (%u) must be a power-of-two multiple of 2^sf (%u)", sps, N);
     const uint32_t D = sps / N;
     if (D > 16u) return fail(h, LORA_HIP_ERR_BAD_CONFIG, "decimation %u > 16 is not supported", D);
-    P.sf = c.sf; P.nbins = N; P.nbins_hdr = 1u << (c.sf - 2); P.sps = sps; P.decim = D;
+    P.sf = c.sf; P.nbins = N; P.nbins_hdr = 1u << (c.sf - 2); P.sps = sps; P.decim = D; P.samples_per_second = samples_per_second;
     P.log_nbins = c.sf; P.delay_after_sync = sps / 4u;
     P.implicit = c.implicit ? 1u : 0u; P.reduced_rate = c.reduced_rate ? 1u : 0u;
     P.enable_fine_sync = c.disable_drift_correction ? 0u : 1u;
@@ -1160,6 +1160,26 @@ lora_hip_status lora_hip_demod_symbols_device(lora_hip_decoder_t *h, const void 
                                               void *hip_stream)
 {
     return lora_hip_demod_symbols_ex_device(h, d_iq, total_items, offsets, n, demod, bins_out, nullptr, hip_stream);
+}
+
+lora_hip_status lora_hip_estimate_cfo_device(lora_hip_decoder_t *h, const void *d_iq, size_t total_items, const int64_t *offsets, size_t n,
+                                             int mode, float *cfo_hz_out, void *hip_stream)
+{
+    if (!h || !d_iq || (n && (!offsets || !cfo_hz_out)) || mode < 0 || mode > 1) return LORA_HIP_ERR_ARG;
+    if (n == 0) return LORA_HIP_OK;
+    if (h->P.sps < 258u) return fail(h, LORA_HIP_ERR_BAD_CONFIG, "the estimate reads sample 257 of the window: %u samples per symbol", h->P.sps);
+    for (size_t i = 0; i < n; i++)
+        if (offsets[i] < 0 || (uint64_t)offsets[i] + h->P.sps > total_items) return fail(h, LORA_HIP_ERR_ARG, "window %zu out of range", i);
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, h->d_offsets.reserve(n));
+    HIP_TRY(h, h->d_bins.reserve(n)); // one float per window
+    HIP_TRY(h, hipMemcpyAsync(h->d_offsets.p, offsets, n * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    if (launch_cfo(h->P, (const float2 *)d_iq, h->d_offsets.p, (uint32_t)n, mode, reinterpret_cast<float *>(h->d_bins.p), st) != 0)
+        return fail(h, LORA_HIP_ERR_HIP, "cfo launch failed: %s", hipGetErrorString(hipGetLastError()));
+    HIP_TRY(h, hipMemcpyAsync(cfo_hz_out, h->d_bins.p, n * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    return LORA_HIP_OK;
 }
 
 lora_hip_status lora_hip_last_plan(const lora_hip_decoder_t *h, uint32_t *burst_aware, uint32_t *segments)

@@ -78,8 +78,11 @@ class decoder(_MsgBlock):
 
     def __init__(self, samp_rate, bandwidth, sf, implicit, cr, crc, reduced_rate=False,
                  disable_drift_correction=False, *, device=0, demod=capi.DEMOD_FFT_COMPAT, verbose=True,
-                 batch_items=0, segment_symbols=0):
+                 batch_items=0, segment_symbols=0, cfo_estimates=False):
         super().__init__()
+        self._cfo = bool(cfo_estimates)
+        self._hist = np.zeros(0, dtype=np.complex64)   # cfo_estimates: the most recent input, for the preamble windows
+        self._hist_base = 0                            # absolute item index of _hist[0]
         if sf < 6 or sf > 12:  # decoder_impl.cc:57-61 -- the reference prints this and exit(1)s
             sys.stderr.write("[LoRa Decoder] ERROR : Spreading factor should be between 6 and 12 (inclusive)!\n"
                              "                       Other values are currently not supported.\n")
@@ -111,7 +114,14 @@ class decoder(_MsgBlock):
 
     def work(self, input_items) -> int:
         """Consumes every item handed in (buffers internally); publishes finished frames."""
-        n = self._h.work(np.asarray(input_items))
+        x = np.asarray(input_items)
+        if self._cfo:   # frames come out one chunk late (the passes are pipelined): keep three chunks of input
+            keep = 3 * max(int(self._h.batch_items), 1 << 20)
+            self._hist = np.concatenate([self._hist, x.astype(np.complex64, copy=False)])
+            if self._hist.size > keep:
+                self._hist_base += self._hist.size - keep
+                self._hist = self._hist[-keep:]
+        n = self._h.work(x)
         self._publish()
         return n
 
@@ -126,6 +136,22 @@ class decoder(_MsgBlock):
                 sys.stdout.write(_hex_line(blob[LORATAP_LEN:LORATAP_LEN + LORAPHY_LEN], False, False))
                 sys.stdout.write(_hex_line(blob[LORATAP_LEN + LORAPHY_LEN:], True, True))
             self.message_port_pub("frames", blob)
+            if self._cfo:
+                self._publish_cfo(_info)
+
+    def _publish_cfo(self, info):
+        """What decoder_impl.cc:774-776 (commented out upstream) would publish: ("cfo", Hz) on the "control" port, from
+        experimental_determine_cfo (:730-738) over a preamble upchirp.  The window is the last unmodulated upchirp but one
+        in front of the frame (header - 6.25 symbols: 2.25 SFD + 2 sync words + 2), on the symbol clock the SFD search
+        settled; the estimate is the mean over the window (mode 1), not upstream's single sample."""
+        import torch
+        sps = self.samples_per_symbol
+        w0 = int(info.header_pos) - (25 * sps) // 4 - self._hist_base
+        if w0 < 0 or w0 + sps > self._hist.size:
+            return
+        d = torch.from_numpy(np.ascontiguousarray(self._hist[w0:w0 + sps]).view(np.float32)).to("cuda:%d" % self._h.device)
+        hz = float(self._h.estimate_cfo_device(d.data_ptr(), sps, [0], mode=1)[0])
+        self.message_port_pub("control", ("cfo", hz, w0 + self._hist_base))   # (the window's position lets a consumer ignore stale estimates)
 
     # decoder.h:708-709 ------------------------------------------------------
     def set_sf(self, sf):
@@ -193,7 +219,8 @@ class lora_receiver(_MsgBlock):
     """python/lora_receiver.py:26-89: [conjugate] o (channelizer | resampler) -> decoder."""
 
     def __init__(self, samp_rate, center_freq, channel_list, bandwidth, sf, implicit, cr, crc, reduced_rate=False,
-                 conj=False, decimation=1, disable_channelization=False, disable_drift_correction=False, **decoder_kw):
+                 conj=False, decimation=1, disable_channelization=False, disable_drift_correction=False, cfo_correction=False,
+                 **decoder_kw):
         super().__init__()
         self.samp_rate = samp_rate
         self.center_freq = center_freq
@@ -209,7 +236,22 @@ class lora_receiver(_MsgBlock):
         self.disable_drift_correction = disable_drift_correction
         self.channelizer = None if disable_channelization else channelizer(samp_rate, center_freq, channel_list, bandwidth, decimation)
         self.decoder = decoder(samp_rate / decimation, bandwidth, sf, implicit, cr, crc, reduced_rate,
-                               disable_drift_correction, **decoder_kw)
+                               disable_drift_correction, cfo_estimates=bool(cfo_correction), **decoder_kw)
+        self.cfo_log = []                             # estimates in Hz, as applied
+        self._fed = 0                                 # items handed to the decoder so far
+        self._cfo_valid_from = 0
+        if cfo_correction and self.channelizer is not None:
+            # msg_connect((self.decoder, 'control'), (self.channelizer, 'control')) (python/lora_receiver.py:67) with the
+            # message upstream left commented out; conj flips the spectrum in front of the decoder, hence the sign
+            def on_control(msg):
+                if isinstance(msg, tuple) and msg[0] == "cfo":
+                    if msg[2] < self._cfo_valid_from:   # measured on samples filtered before the last correction: already accounted for
+                        return
+                    hz = -msg[1] if self.conj else msg[1]
+                    self.cfo_log.append(hz)
+                    self.channelizer.apply_cfo(hz)
+                    self._cfo_valid_from = self._fed    # decoder-input index from which the new tuning holds
+            self.decoder.subscribe("control", on_control)
         self.message_port_register_out("frames")     # message_port_register_hier_out('frames')
         self.decoder.subscribe("frames", lambda blob: self.message_port_pub("frames", blob))
 
@@ -221,6 +263,7 @@ class lora_receiver(_MsgBlock):
             y = self.channelizer.work(x)
         if self.conj:
             y = np.conj(y)
+        self._fed += int(np.asarray(y).size)
         self.decoder.work(y)
         return x.size
 

@@ -266,3 +266,44 @@ def awgn_sigma_for_snr(snr_db_inband: float, cfg: TxConfig, amplitude: float = 1
     p_sig = amplitude ** 2
     p_noise_inband = p_sig / (10.0 ** (snr_db_inband / 10.0))
     return float(np.sqrt(p_noise_inband * cfg.samp_rate / cfg.bw))
+
+# ---- header checksum / payload CRC as a LoRa transmitter computes them (the reference checks neither, README.md:12;
+# lora_hip_check_frame does).  In the decoder's byte domain: the CRC field is not whitened on air but de-whitened like data
+# by the reference (decoder_impl.cc:643), so the bytes that make a frame valid are the true CRC XOR the whitening bytes.
+def whitening_bytes(n: int) -> bytes:
+    r, out = 0xFF, bytearray()
+    for _ in range(n):
+        out.append(r)
+        r = ((r << 1) | (((r >> 7) ^ (r >> 5) ^ (r >> 4) ^ (r >> 3)) & 1)) & 0xFF
+    return bytes(out)
+
+
+def lora_crc16(payload: bytes) -> int:
+    crc = 0
+    for b in payload[:-2] if len(payload) >= 2 else b"":
+        crc ^= b << 8
+        for _ in range(8):
+            crc = ((crc << 1) ^ 0x1021) & 0xFFFF if crc & 0x8000 else (crc << 1) & 0xFFFF
+    if len(payload) >= 1:
+        crc ^= payload[-1]
+    if len(payload) >= 2:
+        crc ^= payload[-2] << 8
+    return crc
+
+
+def valid_crc_bytes(payload: bytes) -> bytes:
+    """The two bytes to pass as `crc_bytes` so that the decoded frame carries a valid payload CRC."""
+    c, w = lora_crc16(payload), whitening_bytes(len(payload) + 2)
+    return bytes([(c & 0xFF) ^ w[len(payload)], (c >> 8) ^ w[len(payload) + 1]])
+
+
+def valid_hdr_nibbles(length: int, cr: int, crc: bool) -> Tuple[int, int]:
+    """`hdr_nibbles` (low nibble of PHY byte 1, high nibble of PHY byte 2) holding the valid 5-bit header checksum."""
+    a = (length << 4) | (cr << 1) | (1 if crc else 0)
+    bit = lambda i: (a >> (11 - i)) & 1
+    c4 = bit(0) ^ bit(1) ^ bit(2) ^ bit(3)
+    c3 = bit(0) ^ bit(4) ^ bit(5) ^ bit(6) ^ bit(11)
+    c2 = bit(1) ^ bit(4) ^ bit(7) ^ bit(8) ^ bit(10)
+    c1 = bit(2) ^ bit(5) ^ bit(7) ^ bit(9) ^ bit(10) ^ bit(11)
+    c0 = bit(3) ^ bit(6) ^ bit(8) ^ bit(9) ^ bit(10) ^ bit(11)
+    return c4, (c3 << 3) | (c2 << 2) | (c1 << 1) | c0

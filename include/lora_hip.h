@@ -208,6 +208,44 @@ lora_hip_status lora_hip_last_plan(const lora_hip_decoder_t *h, uint32_t *burst_
 size_t          lora_hip_trace(const lora_hip_decoder_t *h, const lora_hip_step_t **steps);
 void            lora_hip_trace_clear(lora_hip_decoder_t *h);
 
+/* ---- explicit CFO estimate -----------------------------------------------------------------
+ * decoder_impl::experimental_determine_cfo (decoder_impl.cc:730-738) on caller-given windows of the device-resident
+ * IQ: each window (samples_per_symbol items from offsets[i], meant to be an aligned preamble upchirp such as
+ * detect_upchirp's result, :771-776) is multiplied by the ideal downchirp and the instantaneous frequency of the
+ * product is taken.  mode 0 = the reference's estimate, the single value at index 256 (bit-compatible with the
+ * compiled reference up to the float tolerance of two atan2f; useless under noise - which may be why its only call
+ * is commented out upstream); mode 1 = the mean over the window.  Hz, positive = the signal sits above the tuned
+ * frequency.  What upstream meant to do with it: publish ("cfo", value) on the block's "control" port for
+ * channelizer::apply_cfo (channelizer_impl.cc:68-71) - gr_lora_amd.lora.lora_receiver(cfo_correction=True) does.   */
+lora_hip_status lora_hip_estimate_cfo_device(lora_hip_decoder_t *h, const void *d_iq, size_t total_items,
+                                             const int64_t *offsets, size_t n, int mode, float *cfo_hz_out,
+                                             void *hip_stream);
+
+/* ---- frame validity (beyond the reference) -------------------------------------------------
+ * The reference publishes every frame it demodulates and checks nothing: "CRC checks of the payload and header"
+ * are the first item of its list of unsupported features (README.md:12), include/lora/utilities.h:396-404 is a
+ * header_checksum() stub that returns true (its comment holds the parity sets implemented here), and the PHY CRC
+ * is read out but unused (decoder_impl.cc:839).  lora_hip_check_frame evaluates both checks on a published blob
+ * (15 B loratap | 3 B PHY header | payload | 2 B CRC when the header says so), on the host, without a handle:
+ *   header: the 5 checksum bits (low nibble of PHY byte 1, high nibble of PHY byte 2) against the parity sets
+ *           over the 12 header bits length[7..0], cr[2..0], has_crc;
+ *   CRC:    CRC-16/CCITT (0x1021, init 0) over all payload bytes but the last two, XORed with those two
+ *           (low byte last); the transmitter does not whiten the CRC field, the reference de-whitens it like
+ *           data (decoder_impl.cc:643), so the received value is first XORed with the whitening bytes of its
+ *           two positions (x^8 + x^6 + x^5 + x^4 + 1, seed 0xff: the sequence lib/tables.h:30-44 decodes to).
+ * Known answer: the README frame 04 90 40 de ad be ef 70 0d passes both.  Implicit-header frames carry no
+ * header on air: has_header = 0 and only blobs whose length agrees with their PHY header are checked.        */
+typedef struct lora_hip_frame_check {
+    uint8_t  has_header;          /* blob length agrees with the PHY header's length / has_crc fields        */
+    uint8_t  header_checksum_ok;
+    uint8_t  has_crc;             /* PHY header bit 4 of byte 1                                              */
+    uint8_t  crc_ok;              /* 0 when has_crc is 0                                                     */
+    uint8_t  header_checksum_rx, header_checksum_calc; /* 5 bits each                                        */
+    uint16_t crc_rx, crc_calc;    /* as transmitted (whitening undone) / computed                            */
+    uint16_t reserved;
+} lora_hip_frame_check_t;
+lora_hip_status lora_hip_check_frame(const uint8_t *blob, size_t len, lora_hip_frame_check_t *out);
+
 #ifdef __cplusplus
 }
 #endif

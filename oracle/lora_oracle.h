@@ -97,7 +97,8 @@ uint32_t lora_oracle_bins(const lora_oracle_t *o);
 const float *lora_oracle_table(const lora_oracle_t *o, int which, size_t *n_floats);
 
 /* primitives exposed for unit / parity tests (all take >= the window they read) */
-uint32_t lora_oracle_get_shift_fft(lora_oracle_t *o, const float *iq);               /* :430-464 */
+uint32_t lora_oracle_get_shift_fft(lora_oracle_t *o, const float *iq);
+float lora_oracle_determine_cfo(lora_oracle_t *o, const float *iq, int mode); /* :730-738; mode 1 = mean over the window */               /* :430-464 */
 uint32_t lora_oracle_max_frequency_gradient_idx(lora_oracle_t *o, const float *iq); /* :466-491 */
 int32_t  lora_oracle_fine_sync(lora_oracle_t *o, const float *iq, int32_t bin_idx, int32_t search_space); /* :300-338, returns d_fine_sync */
 float    lora_oracle_detect_preamble_autocorr(lora_oracle_t *o, const float *iq);   /* :340-366 */

@@ -77,6 +77,8 @@ def _bind(L):
         L.lora_oracle_table.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
         L.lora_oracle_get_shift_fft.restype = C.c_uint32
         L.lora_oracle_get_shift_fft.argtypes = [C.c_void_p, C.c_void_p]
+        L.lora_oracle_determine_cfo.restype = C.c_float
+        L.lora_oracle_determine_cfo.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.lora_oracle_max_frequency_gradient_idx.restype = C.c_uint32
         L.lora_oracle_max_frequency_gradient_idx.argtypes = [C.c_void_p, C.c_void_p]
         L.lora_oracle_fine_sync.restype = C.c_int32
@@ -163,6 +165,10 @@ class Oracle:
     def get_shift_fft(self, iq) -> int:
         a = _iq(iq); assert a.size >= self.sps
         return self.L.lora_oracle_get_shift_fft(self.h, a.ctypes.data)
+
+    def determine_cfo(self, iq, mode: int = 0) -> float:
+        a = _iq(iq); assert a.size >= self.sps
+        return self.L.lora_oracle_determine_cfo(self.h, a.ctypes.data, mode)
 
     def max_frequency_gradient_idx(self, iq) -> int:
         a = _iq(iq); assert a.size >= self.sps

@@ -93,6 +93,8 @@ def _bind(L):
         L.ref_table.argtypes = [vp, C.c_int, C.POINTER(C.c_size_t)]
         L.ref_get_shift_fft.restype = C.c_uint32
         L.ref_get_shift_fft.argtypes = [vp, vp]
+        L.ref_experimental_determine_cfo.restype = C.c_float
+        L.ref_experimental_determine_cfo.argtypes = [vp, vp, C.c_uint32]
         L.ref_max_frequency_gradient_idx.restype = C.c_uint32
         L.ref_max_frequency_gradient_idx.argtypes = [vp, vp]
         L.ref_fine_sync.restype = C.c_int32
@@ -195,6 +197,10 @@ class Reference:
     def get_shift_fft(self, iq) -> int:
         a = _iq(iq); assert a.size >= self.sps
         return self.L.ref_get_shift_fft(self.h, a.ctypes.data)
+
+    def experimental_determine_cfo(self, iq) -> float:
+        a = _iq(iq); assert a.size >= self.sps
+        return self.L.ref_experimental_determine_cfo(self.h, a.ctypes.data, self.sps)
 
     def max_frequency_gradient_idx(self, iq) -> int:
         a = _iq(iq); assert a.size >= self.sps

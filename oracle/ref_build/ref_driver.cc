@@ -265,6 +265,10 @@ const float* ref_table(void* hv, int which, size_t* n_floats)
 
 /* ---- the block's own per-stage member functions, for primitive-level pinning ---- */
 uint32_t ref_get_shift_fft(void* hv, const float* iq) { return ((ref_handle*)hv)->d->get_shift_fft((const gr_complex*)iq); } /* :430-464 */
+float ref_experimental_determine_cfo(void* hv, const float* iq, uint32_t window)
+{
+    return ((ref_handle*)hv)->d->experimental_determine_cfo((const gr_complex*)iq, window); /* :730-738 */
+}
 uint32_t ref_max_frequency_gradient_idx(void* hv, const float* iq)
 {
     return ((ref_handle*)hv)->d->max_frequency_gradient_idx((const gr_complex*)iq); /* :466-491 */

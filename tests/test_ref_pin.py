@@ -280,3 +280,18 @@ def test_sync_shift_depends_on_volk_summation_order():
         moved[(sf, snr)] = (n_moved, n_sync)
     assert moved[(8, None)][0] == 0            # resolvable at SF8 without noise ...
     assert moved[(12, None)][0] >= 1           # ... rounding decides at SF12 even on a clean signal
+
+
+def test_cfo_estimate_vs_reference():
+    """experimental_determine_cfo (:730-738; unused upstream): the oracle's restatement, mode 0, against the compiled member function."""
+    rng = np.random.default_rng(77)
+    for sf in (7, 8, 10, 12):
+        from oracle import oracle
+        o, r = oracle.Oracle(sf=sf), R.Reference(sf=sf)
+        for k in range(6):
+            x = (rng.standard_normal(o.sps) + 1j * rng.standard_normal(o.sps)).astype(np.complex64)
+            if k % 2:
+                cfg = synth.TxConfig(sf=sf)
+                x = (synth.base_upchirp(cfg) * np.exp(2j * np.pi * (k * 700.0) * np.arange(o.sps) / 1e6) + 0.1 * x).astype(np.complex64)
+            a, b = o.determine_cfo(x, 0), r.experimental_determine_cfo(x)
+            assert a == b, (sf, k, a, b)
