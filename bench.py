@@ -106,6 +106,21 @@ def cpu_baseline(cfg, iq, offs, lens, budget_s=20.0):
             if time.perf_counter() - t_begin > budget_s / 3 and len(ts) >= 3:
                 break
         out[name] = (sample / float(np.median(ts)) / 1e6, sample, frames, len(ts))
+    # the reference's own lib/decoder_impl.cc (oracle/_ref, prebuilt where /root/reference exists: -O3 -march=x86-64-v3, VOLK
+    # and liquid-dsp replaced by stand-ins of plain loops) over the same sample, when the library travelled with the tree
+    out["reference_build"] = None
+    try:
+        from oracle import ref as R
+        if os.path.exists(R._LIB_FAST_PATH) or R.available():
+            ts = []
+            for _ in range(3):
+                dec = R.Reference(samp_rate=cfg.samp_rate, bandwidth=cfg.bw, sf=cfg.sf, cr=4, crc=True, reduced_rate=cfg.reduced_rate, fast=True)
+                t0 = time.perf_counter()
+                dec.run(seg)
+                ts.append(time.perf_counter() - t0)
+            out["reference_build"] = (sample / float(np.median(ts)) / 1e6, len(ts))
+    except Exception as e:   # the checker library is optional here
+        out["reference_build_error"] = repr(e)
     import concurrent.futures as cf
     ncores = os.cpu_count() or 1
     nthreads = max(1, min(ncores, len(offs)))
@@ -318,6 +333,11 @@ def main():
             res["cpu_baseline"] = {"value": round(cb["grad"][0], 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
                                    "sample": "oracle/lora_oracle.c (C restatement of lib/decoder_impl.cc) built -O3 -march=native on this host, reference-default gradient "
                                              "demodulator, median of %d runs over the first %d items of stream 0; fft demodulator: %.3f Msamples/s" % (cb["grad"][3], cb["grad"][1], cb["fft"][0]),
+                                   "reference_build": (None if not cb.get("reference_build") else
+                                                       {"value": round(cb["reference_build"][0], 3), "unit": "Msamples/s", "cores": 1,
+                                                        "sample": "the reference's lib/decoder_impl.cc itself (oracle/_ref/libref_decoder_fast.so: compiled unmodified, -O3 "
+                                                                  "-march=x86-64-v3, VOLK / liquid-dsp as stand-ins of plain loops, its default gradient demodulator), "
+                                                                  "same items, median of %d runs" % cb["reference_build"][1]}),
                                    "all_cores": {"value": round(cb["all_cores"][0], 3), "unit": "Msamples/s", "threads": cb["all_cores"][1],
                                                  "host_cores": cb["all_cores"][2], "sample": "one decoder per stream, gradient demod, up to 12e6 items each"}}
         print(json.dumps(res))

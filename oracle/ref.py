@@ -18,6 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _BUILD = os.path.join(_HERE, "ref_build")
 _LIB_PATH = os.path.join(_HERE, "_ref", "libref_decoder.so")
 _LIB_SIMD_PATH = os.path.join(_HERE, "_ref", "libref_decoder_simd.so")   # VOLK stand-in summing in 8 lanes
+_LIB_FAST_PATH = os.path.join(_HERE, "_ref", "libref_decoder_fast.so")   # -O3 -march=x86-64-v3 timing build (bench.py cpu_baseline)
 REFERENCE_ROOT = "/root/reference"
 
 
@@ -43,6 +44,16 @@ def available() -> bool:
 
 _lib = None
 _lib_simd = None
+_lib_fast = None
+
+
+def lib_fast():
+    """The timing build (never used for parity)."""
+    global _lib_fast
+    if _lib_fast is None:
+        build()
+        _lib_fast = _bind(C.CDLL(_LIB_FAST_PATH))
+    return _lib_fast
 
 
 def lib(simd: bool = False):
@@ -142,8 +153,8 @@ class Reference:
     driven by the scheduler loop of oracle/ref_build/ref_driver.cc."""
 
     def __init__(self, samp_rate=1e6, bandwidth=125000, sf=7, implicit=False, cr=4, crc=True,
-                 reduced_rate=False, disable_drift_correction=False, simd=False):
-        self.L = lib(simd)
+                 reduced_rate=False, disable_drift_correction=False, simd=False, fast=False):
+        self.L = lib_fast() if fast else lib(simd)
         self.h = self.L.ref_create(samp_rate, int(bandwidth), int(sf), int(implicit), int(cr), int(crc),
                                    int(reduced_rate), int(disable_drift_correction))
         if not self.h:
