@@ -32,7 +32,7 @@
 // state lives in LDS (W3Shared::st) and thread 0 replays the round's results over a register copy of it, in order,
 // stopping at the first window whose outcome invalidates the later ones (a state change, d_fine_sync != 0 :321,:856,
 // :883, the scan limit, the end of the data); every thread reads the next round's plan from LDS (double-buffered) into
-// scalar registers.  DETECT (NG groups x 4 windows), SYNC (closed form over block-wide prefix sums in double, all 1024
+// scalar registers.  DETECT (one window per group), SYNC (closed form over block-wide prefix sums in double, all 1024
 // threads), FIND_SFD (one-pass Pearson + closed-form 63-lag fine_sync per group) and the finalisation of a frame are
 // rounds of the same loop; a job that reaches its scan limit carries on as the next segment's tail probe (second phase,
 // as in walker2).
