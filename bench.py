@@ -40,10 +40,35 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 
 
 # ------------------------------------------------------------------------------------------------ workloads
+def _cached(key, build):
+    """LORA_BENCH_CACHE=<dir>: keep a synthesised workload (IQ + expected frames) between runs on one box - same-box A/B of
+    library variants (tools/ab.sh) then pays for the synthesis once"""
+    d = os.environ.get("LORA_BENCH_CACHE")
+    if not d:
+        return build()
+    import pickle
+    f_iq, f_meta = os.path.join(d, key + ".npy"), os.path.join(d, key + ".pkl")
+    if os.path.exists(f_iq) and os.path.exists(f_meta):
+        with open(f_meta, "rb") as f:
+            return (np.load(f_iq),) + pickle.load(f)
+    iq, offs, lens, expect = build()
+    os.makedirs(d, exist_ok=True)
+    np.save(f_iq, iq)
+    with open(f_meta, "wb") as f:
+        pickle.dump((offs, lens, expect), f)
+    return iq, offs, lens, expect
+
+
 def make_workload(sf, cr, n_packets, payload_len, n_streams, seed):
     """config 2 / 3: n_packets packets of payload_len bytes in n_streams streams, zero gaps of 2-6 symbols"""
     from gr_lora_amd import synth
     cfg = synth.TxConfig(sf=sf, cr=cr, crc=True, reduced_rate=(sf > 10))
+    key = "wl-sf%d-cr%d-%dx%dB-%dstreams-seed%d" % (sf, cr, n_packets, payload_len, n_streams, seed)
+    return (cfg,) + tuple(_cached(key, lambda: _make_workload(cfg, n_packets, payload_len, n_streams, seed)))
+
+
+def _make_workload(cfg, n_packets, payload_len, n_streams, seed):
+    from gr_lora_amd import synth
     rng = np.random.default_rng(seed)
     per = n_packets // n_streams
     pieces, offs, lens, expect = [], [], [], []
@@ -56,7 +81,7 @@ def make_workload(sf, cr, n_packets, payload_len, n_streams, seed):
         lens.append(st.iq.size)
         off += st.iq.size
         expect.append([synth.expected_frame_tail(p, cfg) for p in payloads])
-    return cfg, np.concatenate(pieces), offs, lens, expect
+    return np.concatenate(pieces), offs, lens, expect
 
 
 def make_gateway_workload(channels, seconds=2.0, sf=9):

@@ -16,8 +16,24 @@
 // being rewritten.
 
 constexpr int kW2DetectK = 4;   // DETECT windows per worker and round
-constexpr int kW2MaxWaves = 8; // wavefronts per workgroup the shared structures are sized for (16-wave workgroups, one
-                               // per CU, were measured slower: all 15 workers hit their load and VALU phases together)
+#ifndef LORA_W2_DOUBLE
+#define LORA_W2_DOUBLE 0 // 1-3: the worker beside the control wavefront takes two windows of a decode round (measured slower)
+#endif
+#ifndef LORA_W2_WAVES_SF7
+#define LORA_W2_WAVES_SF7 8
+#endif
+#ifndef LORA_W2_WAVES_SF8
+#define LORA_W2_WAVES_SF8 8
+#endif
+#ifndef LORA_W2_STAGGER
+#define LORA_W2_STAGGER 0
+#endif
+#ifndef LORA_W2_EU_SF8
+#define LORA_W2_EU_SF8 2 // wavefronts per SIMD the SF8 kernel's register budget is set for
+#endif
+// wavefronts per workgroup the shared structures are sized for (SF7: 16-wave workgroups, one per CU, were measured slower:
+// all 15 workers hit their load and VALU phases together)
+constexpr int kW2MaxWaves = LORA_W2_WAVES_SF7 > LORA_W2_WAVES_SF8 ? LORA_W2_WAVES_SF7 : LORA_W2_WAVES_SF8;
 
 enum W2Mode : int32_t { kPlanExit = 0, kPlanDetect, kPlanSync, kPlanSfd, kPlanPause, kPlanDecode, kPlanFinalize };
 
@@ -424,8 +440,11 @@ __device__ __attribute__((noinline)) void w2_sync_closed_form(const float *f2, d
                     pre[threadIdx.x] = oF; pre[NCH + threadIdx.x] = oG;
                 }
                 __syncthreads();
-                constexpr uint32_t R = sps / kW2; // consecutive shifts per thread
+                constexpr uint32_t R = (sps + kW2 - 1u) / kW2; // consecutive shifts per thread (the last threads may have none)
                 const uint32_t i0 = threadIdx.x * R;
+                bv = 0.0f; // max_correlation = 0 (:400)
+                bi = 0x7fffffff;
+                if (sps % kW2 != 0u && i0 >= sps) return;
                 auto prefix_at = [&](uint32_t j, double &F, double &G) { // sums over t < j
                     const uint32_t c = j / CH;
                     F = pre[c]; G = pre[NCH + c];
@@ -435,11 +454,10 @@ __device__ __attribute__((noinline)) void w2_sync_closed_form(const float *f2, d
                 prefix_at(i0, F0, G0);
                 prefix_at(i0 + n, F1, G1);
                 double s0 = F1 - F0, s1 = (G1 - G0) + (double)((int)sps - (int)i0) * s0;
-                bv = 0.0f; // max_correlation = 0 (:400)
-                bi = 0x7fffffff;
     #pragma unroll
                 for (uint32_t r = 0; r < R; r++) {
                     const uint32_t i = i0 + r;
+                    if (sps % kW2 != 0u && i >= sps) break;
                     const float c = (float)(sync_a * s0 + sync_b * s1);
                     if (c > bv) { bv = c; bi = (int)i; }
                     const double fin = (double)f2[i + n], fout = (double)f2[i];
@@ -454,6 +472,11 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
 {
     constexpr int N = 1 << SF, SPS = 8 * N;
     constexpr int kW2 = 64 * WAVES, kW2Workers = WAVES - 1; // the last wavefront is the control wavefront
+    // Decode rounds look at kW2Win windows: one per worker, plus one more taken by the worker that shares its SIMD with the
+    // control wavefront (LORA_W2_DOUBLE).  WAVES wavefronts land two per SIMD, so with every worker taking one window the SIMD
+    // of the (mostly waiting) control wavefront carries half the arithmetic of the others and the round lasts as long as theirs.
+    constexpr int kW2Win = kW2Workers + (LORA_W2_DOUBLE ? 1 : 0);
+    static_assert(kW2Win <= kW2MaxWaves, "speci is sized for kW2MaxWaves windows");
     static_assert(WAVES <= kW2MaxWaves, "W2Shared is sized for kW2MaxWaves wavefronts");
     constexpr uint32_t sps = SPS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -472,6 +495,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     const uint32_t jid = blockIdx.x;
     if (jid >= C.n_jobs) return;
     Job job = C.jobs[jid];           // (phase 1 rewrites start / limits: the job carries on as the next segment's probe)
+    if constexpr (SF == 7) job = uniform_job(job); // (scalar registers for the stream base and the limits: 54 -> 40 spilled VGPRs, +1.5 %; SF8 does not spill)
     uint32_t rec_cap = C.recs_per_job; // ... with what is left of the attempt-record capacity
     const float2 *__restrict__ X = C.iq + job.stream_off;
     const int64_t n_items = (int64_t)job.stream_len;
@@ -481,9 +505,24 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     const bool is_ctl = wave == kW2Workers;                 // control wavefront
     const bool t0 = threadIdx.x == kW2Workers * 64;         // the control thread: sole owner of the decoder state S
     if (is_ctl) __builtin_amdgcn_s_setprio(2);              // its serial bookkeeping is on every round's critical path
+    // the worker that takes two windows in a decode round: the lowest one on the control wavefront's SIMD
+    int dbl_wave = kW2Workers & 3;
+#if LORA_W2_DOUBLE == 2
+    {
+        const uint32_t simd = (__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3u;
+        if (lane == 0) ((volatile uint32_t *)W.red)[wave] = simd;
+        __syncthreads();
+        const uint32_t cs = ((volatile uint32_t *)W.red)[kW2Workers];
+        dbl_wave = -1;
+        for (int w = kW2Workers - 1; w >= 0; w--) if (((volatile uint32_t *)W.red)[w] == cs) dbl_wave = w;
+        dbl_wave = __builtin_amdgcn_readfirstlane(dbl_wave);
+        __syncthreads();
+    }
+#endif
 
     const uint32_t dbg_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime(), dbg_c0 = (uint32_t)(clock64() >> 6);
     const WaveTabs FT = wave_tabs_to_lds<SF>(P, tab4, vl, kW2);
+    walker_stagger(LORA_W2_STAGGER);
     for (uint32_t i = threadIdx.x; i < sps; i += kW2) ddl[i] = P.down_ifreq[i] - P.down_ifreq_avg;
 
     // plan for the next round from the TRUE state (control thread only)
@@ -503,10 +542,10 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         case kFindSfd: pl.mode = kPlanSfd; break;
         case kPause: pl.mode = kPlanPause; break;
         default:
-            pl.mode = kPlanDecode;
+            pl.mode = kPlanDecode; pl.n_win = kW2Win;
             if (S.state == kDecodePayload) { // symbols left in the packet (:866-870)
                 const int32_t rem = S.payload_symbols - (int32_t)S.n_words;
-                pl.n_win = rem < kW2Workers ? (rem > 0 ? rem : 1) : kW2Workers;
+                pl.n_win = rem < kW2Win ? (rem > 0 ? rem : 1) : kW2Win;
             }
             break;
         }
@@ -799,16 +838,25 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 const int wq = __builtin_ctzll(moved);
                 const int32_t redo = plan_prev_n - (wq + 1); // windows of the previous round to be demodulated again
                 dpos = pos - (int64_t)redo * sps + (int64_t)__builtin_amdgcn_readlane(f_l, wq);
-                dn = plan_n_win + redo < kW2Workers ? plan_n_win + redo : kW2Workers;
+                dn = plan_n_win + redo < kW2Win ? plan_n_win + redo : kW2Win;
             }
         }
         if (!is_ctl) {
-            const int64_t dwpos = dpos + (int64_t)wave * sps;
-            const bool dvalid = wave < dn && dwpos + 2 * (int64_t)sps <= n_items;
-            uint32_t ws = 0;
-            int32_t wfine = 0;
-            if (dvalid) wave_demod_symbol<SF, SF == 7>(P, FT, X + dwpos, ws, wfine);
-            if (lane == 0) { W.speci[plan_buf][wave][0] = dvalid ? (int32_t)ws : -1; W.speci[plan_buf][wave][1] = wfine; }
+            // window `wave`, and for the doubled worker window kW2Workers after it (one copy of the demodulator: no unrolling)
+            const int n_mine = (kW2Win > kW2Workers && wave == dbl_wave) ? 2 : 1;
+#if LORA_W2_DOUBLE == 3
+            if (n_mine == 2) __builtin_amdgcn_s_setprio(2); // two windows in the time the others take for one (reset at the top of the round)
+#endif
+#pragma nounroll
+            for (int rep = 0; rep < n_mine; rep++) {
+                const int widx = rep == 0 ? wave : kW2Workers;
+                const int64_t dwpos = dpos + (int64_t)widx * sps;
+                const bool dvalid = widx < dn && dwpos + 2 * (int64_t)sps <= n_items;
+                uint32_t ws = 0;
+                int32_t wfine = 0;
+                if (dvalid) wave_demod_symbol<SF, SF == 7>(P, FT, X + dwpos, ws, wfine);
+                if (lane == 0) { W.speci[plan_buf][widx][0] = dvalid ? (int32_t)ws : -1; W.speci[plan_buf][widx][1] = wfine; }
+            }
         } else { // the whole control wavefront, uniformly (identical values in every lane); t0 does the stores
             bool predicted = true;
             const long long tr0 = clock64();
@@ -819,8 +867,8 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             if (plan_resolve_prev) {
                 const int rb = plan_buf ^ 1;
                 // lane w fetches worker w's result: one LDS round trip for the round instead of two per symbol
-                const int32_t my_s = lane < kW2Workers ? W.speci[rb][lane][0] : -1, my_f = lane < kW2Workers ? W.speci[rb][lane][1] : 0;
-                for (int w = 0; w < kW2Workers; w++) {
+                const int32_t my_s = lane < kW2Win ? W.speci[rb][lane][0] : -1, my_f = lane < kW2Win ? W.speci[rb][lane][1] : 0;
+                for (int w = 0; w < kW2Win; w++) {
                     if (w > 0 && !w2_pre_step(L, job, rec_cap, sps)) break;
                     const int32_t sw = __builtin_amdgcn_readlane(my_s, w), fw = __builtin_amdgcn_readlane(my_f, w);
                     if (!(L.state == kDecodeHeader || L.state == kDecodePayload) || sw < 0) break;
@@ -843,10 +891,10 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             W2Plan np; // (built in registers, stored by t0)
             if (predicted) {
                 // the round in flight continues the packet; how much of the packet is left after it?
-                int32_t n_next = kW2Workers;
+                int32_t n_next = kW2Win;
                 if (L.state == kDecodePayload) {
                     const int32_t rem = L.payload_symbols - (int32_t)L.n_words - dn;
-                    n_next = rem < kW2Workers ? (rem > 0 ? rem : 0) : kW2Workers; // 0: nothing left to demodulate, only resolve
+                    n_next = rem < kW2Win ? (rem > 0 ? rem : 0) : kW2Win; // 0: nothing left to demodulate, only resolve
                 }
                 np.mode = kPlanDecode; np.pos = dpos + (int64_t)dn * sps; np.buf = plan_buf ^ 1; np.resolve_prev = 1; np.n_win = n_next;
                 np.prev_n = dn; np.pad = 0;
@@ -930,9 +978,9 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     if (t0 && bal_mine) __hip_atomic_store(bal_mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // nothing left: the neighbour keeps the CU
 }
 
-constexpr int kW2WavesSf7 = 8, kW2WavesSf8 = 8;
+constexpr int kW2WavesSf7 = LORA_W2_WAVES_SF7, kW2WavesSf8 = LORA_W2_WAVES_SF8;
 __global__ __launch_bounds__(64 * kW2WavesSf7, 4) void walker2_kernel_sf7(DevParams P, LaunchCfg C) { walker2_body<7, kW2WavesSf7>(P, C); }
-__global__ __launch_bounds__(64 * kW2WavesSf8, 2) void walker2_kernel_sf8(DevParams P, LaunchCfg C) { walker2_body<8, kW2WavesSf8>(P, C); }
+__global__ __launch_bounds__(64 * kW2WavesSf8, LORA_W2_EU_SF8) void walker2_kernel_sf8(DevParams P, LaunchCfg C) { walker2_body<8, kW2WavesSf8>(P, C); }
 
 static uint32_t walker2_threads(uint32_t sf) { return 64u * (uint32_t)(sf == 7u ? kW2WavesSf7 : kW2WavesSf8); }
 

@@ -37,6 +37,32 @@
 // rounds of the same loop; a job that reaches its scan limit carries on as the next segment's tail probe (second phase,
 // as in walker2).
 
+// build-time options (defaults = what ships; the others are kept for same-box A/B runs, tools/build_variant.sh + tools/ab.sh)
+#ifndef LORA_W3_PREFETCH
+#define LORA_W3_PREFETCH 0      // 1: decode rounds, 2: DETECT / FIND_SFD rounds touch the next round's lines in L2 (measured: no gain)
+#endif
+#ifndef LORA_W3_LATE_F_MASK
+#define LORA_W3_LATE_F_MASK 0   // bit (SF - 9): that SF's walker computes fine_sync's ifreq from a second read of the window
+#endif
+// The next two change nothing the kernels compute, only how much the register allocator has to juggle - and at 128 VGPRs with
+// ~60-200 of them spilled that decides where the spill reloads land.  A reload is a round trip to memory (the scratch lines do not
+// survive in L2 beside the IQ stream: ~1-2 us each), and one that lands in front of a round's first loads, or inside thread 0's
+// replay, is paid by the whole workgroup every round.  Chosen per SF from a same-box grid (tools/ab.sh): of HBM peak at
+// 256 packets, SF9 13.9 -> 14.8 %, SF10 15.5 -> 16.6 %, SF11 17.5 -> 18.2 %, SF12 14.0 -> 14.9 %; the same switches the other
+// way round cost SF11 19 %.
+#ifndef LORA_W3_UJ_MASK
+#define LORA_W3_UJ_MASK 15      // bit (SF - 9): the job record through readfirstlane (uniform_job): the stream base and the limits in scalar registers
+#endif
+#ifndef LORA_W3_MOD_MASK
+#define LORA_W3_MOD_MASK 11     // bit (SF - 9): the replay's power-of-two reductions as masks instead of 64-bit / runtime modulo (not SF11)
+#endif
+#ifndef LORA_W3_REPLAY_STATS
+#define LORA_W3_REPLAY_STATS 1  // LORA_HIP_DEBUG accounting of thread 0's replay inside the decode rounds
+#endif
+#ifndef LORA_W3_STAGGER
+#define LORA_W3_STAGGER 0       // start-up stagger between workgroups, shader clocks per step (measured: no gain)
+#endif
+
 template <int SF> struct W3Geom {
     static constexpr int N = 1 << SF, SPS = 8 * N;
     static constexpr int T = 1024;                      // threads per workgroup (16 wavefronts, one workgroup per CU)
@@ -52,7 +78,9 @@ template <int SF> struct W3Geom {
     static constexpr int CH = SPS / 16;                 // samples between a thread's consecutive loads
     static constexpr int NWL = TG / (8 * AR), NB = 16 / NWL; // pass 3: butterflies per thread
     static constexpr int LEN = SPS / T;                 // SYNC: shifts per thread (all groups together)
-    static constexpr bool LATE_F = PAIRS > 1;           // fine_sync's ifreq from a second read of the window (SF12)
+    static constexpr bool LATE_F = PAIRS > 1 || ((LORA_W3_LATE_F_MASK >> (SF - 9)) & 1); // fine_sync's ifreq from a second read of the window (SF12)
+    static constexpr bool UNIFORM_JOB = (LORA_W3_UJ_MASK >> (SF - 9)) & 1;  // the job record through readfirstlane (uniform_job)
+    static constexpr bool FAST_MOD = (LORA_W3_MOD_MASK >> (SF - 9)) & 1;    // power-of-two reductions of the replay as masks
     static constexpr uint32_t data_entries = (uint32_t)AR * SA; // per group
     static_assert(NB * M2 == 16, "pass 3 covers 16 values per thread");
     static_assert(AR * M2 * 8 == TG, "pass 2 uses every thread of the group once per round");
@@ -811,12 +839,16 @@ __device__ __attribute__((noinline)) W3SfdOut w3_sfd_round(W3SfdArgs P, const fl
 // ---- thread-0 bookkeeping ---------------------------------------------------------------------------------------
 // everything demodulate() / work() do once the bin is known (:506-529, :826-886), explicit or implicit header.
 // Returns true when the payload is complete: the caller requests the workgroup-wide finalisation round.
+template <bool FAST_MOD>
 __device__ __forceinline__ bool w3_post_symbol(const DevParams &P, W2State &S, Shared &sh, bool do_demod, uint32_t bin_idx, bool is_first)
 {
     bool block_done = false;
     if (do_demod) {
         const bool reduced = is_first || P.reduced_rate; // :495
-        if (reduced) bin_idx = (uint32_t)(lroundf((float)bin_idx / 4.0f) % (long)P.nbins_hdr); // :507-509
+        if (reduced) { // :507-509 (% N/4: a power of two, of a value >= 0)
+            if constexpr (FAST_MOD) bin_idx = (uint32_t)lroundf((float)bin_idx / 4.0f) & (P.nbins_hdr - 1u);
+            else bin_idx = (uint32_t)(lroundf((float)bin_idx / 4.0f) % (long)P.nbins_hdr);
+        }
         const uint32_t word = bin_idx ^ (bin_idx >> 1u); // :512
         const uint32_t need = 4u + (is_first ? 4u : S.cr); // :521
         if (S.n_words < 16u) sh.words[S.n_words] = word;
@@ -873,6 +905,23 @@ __device__ __forceinline__ bool w3_post_symbol(const DevParams &P, W2State &S, S
     return false;
 }
 
+// L2 touch of the symbol a group will most likely evaluate in the NEXT round (one dword per 128-byte line and thread; the value
+// is never used).  A round reads its NG windows in one burst at its very start - every CU at about the same time, so the burst
+// runs at the HBM limit (~11 B/clk/CU) while the rest of the round moves nothing; touched a round ahead, the lines come from L2 /
+// MALL instead.  The value must stay live until the data has landed (the caller consumes it at the top of the next round).
+template <int SF>
+__device__ __forceinline__ void w3_touch(const float2 *X, int64_t first_item, int64_t fallback_item, int64_t n_items, float (&v)[2])
+{
+    using G = W3Geom<SF>;
+    // (always a load - past the end of the stream it re-reads the current window - and nothing done to the value: any use,
+    // even a select against 0, makes the compiler wait for it right here)
+    const int64_t fi = first_item + (int64_t)G::SPS <= n_items ? first_item : fallback_item; // uniform per group
+    const w3_buf_t xb = w3_buf(w3_uniform_ptr(X + fi));
+    const uint32_t t = threadIdx.x % G::TG;
+#pragma unroll
+    for (int p = 0; p < G::PAIRS; p++) v[p] = w3_ld1(xb, 128u * ((uint32_t)(p * G::TG) + t), 0u);
+}
+
 // ---- the kernel -----------------------------------------------------------------------------------------------
 // ROUNDS.  The decoder state (W2State, as in walker2) lives in LDS and belongs to thread 0.  Every round starts from a
 // PLAN (position, what to evaluate, how many windows): in DETECT, FIND_SFD and DECODE_* the NG groups evaluate the NG
@@ -896,6 +945,7 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
     const uint32_t jid = blockIdx.x;
     if (jid >= C.n_jobs) return;
     Job job = C.jobs[jid];             // (phase 1 rewrites start / limits: the job carries on as the next segment's probe)
+    if constexpr (G::UNIFORM_JOB) job = uniform_job(job);
     uint32_t rec_cap = C.recs_per_job; // ... with what is left of the attempt-record capacity
     const float2 *__restrict__ X = C.iq + job.stream_off;
     const int64_t n_items = (int64_t)job.stream_len;
@@ -907,6 +957,7 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
     const W3DemodArgs DA{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode};
 
     w3_tables_to_lds<SF>(P, L);
+    walker_stagger(LORA_W3_STAGGER);
 
     // plan for the next round from the TRUE state (thread 0 only)
     auto plan_from = [&](W2State &St, W2Plan &pl) {
@@ -940,8 +991,12 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
         plan_from(S, ws.plan[0]);
     }
 
+    float touched[2] = {0.0f, 0.0f};
     for (uint32_t it = 0;; it++) {
         __syncthreads(); // plan[it & 1] and everything thread 0 wrote are visible; plan[(it + 1) & 1] is free
+#if LORA_W3_PREFETCH
+        asm volatile("" :: "v"(touched[0]), "v"(touched[1])); // the previous round's touch has landed by the time this round's loads are waited for
+#endif
         const W2Plan &pl_in = ws.plan[it & 1u];
         const uint64_t pl_pp = (uint64_t)pl_in.pos;
         const int64_t pos = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(pl_pp >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)pl_pp));
@@ -962,6 +1017,9 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
         if (plan_mode == kPlanDetect) { // :752-768, detect_preamble_autocorr :340-366
             float a[NG][4];
             w3_detect_round<SF>(xg, gvalid, ws, slot, a);
+#if LORA_W3_PREFETCH & 2
+            w3_touch<SF>(X, gpos + (int64_t)(NG + 1) * sps, gvalid ? gpos : pos, n_items, touched); // this round read symbols 0 .. NG of the scan
+#endif
             if (t0) {
                 W2State St = S;
                 for (int g = 0; g < NG; g++) {
@@ -1017,6 +1075,9 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
             const W3SfdOut fo = w3_sfd_round<SF>(W3SfdArgs{P.down_ifreq, P.up_ifreq_v, P.down_ifreq_avg, P.down_ifreq_sd, P.down_ifreq_dsum, P.sync_a, P.sync_b}, xg,
                                                  gvalid ? 1 : 0, &ws, slot);
             slot = __builtin_amdgcn_readfirstlane(fo.slot);
+#if LORA_W3_PREFETCH & 2
+            w3_touch<SF>(X, gpos + (int64_t)NG * sps, gvalid ? gpos : pos, n_items, touched);
+#endif
             if (t0) {
                 W2State St = S;
                 for (int g = 0; g < NG; g++) {
@@ -1086,7 +1147,14 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
             int32_t fq[NG];
             float eq[NG];
             w3_demod_round<SF>(DA, L, xg, dvalid, P.implicit != 0u, slot, sq, fq, eq);
+#if LORA_W3_PREFETCH & 1
+            w3_touch<SF>(X, gpos + (int64_t)NG * sps, gvalid ? gpos : pos, n_items, touched);
+#endif
             if (t0) {
+#if LORA_W3_REPLAY_STATS
+                const long long tr0 = clock64(); // (LORA_HIP_DEBUG accounting: ctl[0] = the demodulation, ctl[1] = thread 0's replay, of the decode rounds)
+                ws.stats.ctl[0] += (uint32_t)((tr0 - t_start) >> 6);
+#endif
                 W2State St = S;
                 for (int g = 0; g < NG; g++) {
                     if (g >= plan_n_win) break;
@@ -1103,11 +1171,12 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                     uint32_t bin_idx = 0;
                     int32_t fine = 0, step_bin = -1;
                     if (do_demod) { // :500, bin_idx = (s-1) mod N; compat keeps the s==0 -> 0 quirk of the gradient path
-                        bin_idx = (sg == 0u && P.demod_mode == 2u) ? 0u : (sg + P.nbins - 1u) % P.nbins;
+                        if constexpr (G::FAST_MOD) bin_idx = (sg == 0u && P.demod_mode == 2u) ? 0u : (sg + (uint32_t)G::N - 1u) % (uint32_t)G::N;
+                        else bin_idx = (sg == 0u && P.demod_mode == 2u) ? 0u : (sg + P.nbins - 1u) % P.nbins;
                         step_bin = (int32_t)bin_idx;
                         fine = fg; // :501-502
                     }
-                    if (w3_post_symbol(P, St, sh, do_demod, bin_idx, is_first)) { // payload complete: finalise with all threads
+                    if (w3_post_symbol<G::FAST_MOD>(P, St, sh, do_demod, bin_idx, is_first)) { // payload complete: finalise with all threads
                         St.fin_pending = 1; St.fin_st = st_w; St.fin_consumed = (int32_t)sps + fine; St.fin_bin = step_bin; St.fin_fine = fine;
                         break;
                     }
@@ -1117,6 +1186,10 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                 W2Plan np;
                 plan_from(St, np);
                 next = np; S = St;
+#if LORA_W3_REPLAY_STATS
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                ws.stats.ctl[1] += (uint32_t)((clock64() - tr0) >> 6);
+#endif
             }
         }
     }
@@ -1161,7 +1234,7 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
             W2Stats &Q = ws.stats;
             if (Q.prev_state >= 0) { Q.cyc[Q.prev_state] += (uint32_t)((clock64() - Q.prev_t) >> 6); Q.rounds[Q.prev_state]++; }
             for (int i = 0; i < 6; i++) { jr.cyc[i] = Q.cyc[i]; jr.rounds[i] = Q.rounds[i]; }
-            for (int i = 0; i < 4; i++) jr.ctl[i] = 0;
+            for (int i = 0; i < 4; i++) jr.ctl[i] = Q.ctl[i];
             for (int i = 0; i < 6; i++) jr.dbg[i] = 0;
         }
     }
