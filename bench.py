@@ -231,7 +231,7 @@ def main():
     ap.add_argument("--packets", type=int, default=None)
     ap.add_argument("--payload", type=int, default=32)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("LORA_BENCH_STREAMS", "8")))
-    ap.add_argument("--seconds", type=float, default=8.0, help="config 4: signal per channel (BASELINE: at least 2 s)")
+    ap.add_argument("--seconds", type=float, default=32.0, help="config 4: signal per channel per pass (BASELINE: continuous, at least 2 s; a pass of 8 s leaves the device half empty: 244 jobs of ~1 packet, DESIGN 5.2)")
     ap.add_argument("--demod", type=int, default=2, help="0 grad, 1 fft, 2 fft_compat")
     ap.add_argument("--depth", type=int, default=3, help="pipeline depth: 1 = strictly one pass after the other; 2 = while the device runs "
                     "step k+1 the host stitches step k (decoder handles alternating on one stream; walker kernels never overlap); "

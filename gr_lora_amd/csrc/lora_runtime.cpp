@@ -436,7 +436,7 @@ lora_hip_status run_jobs_end(lora_hip_decoder *h, RunOut &out)
         }
         double ctl[4] = {0};
         for (uint32_t j = 0; j < nj; j++) for (int i = 0; i < 4; i++) ctl[i] += 64.0 * out.res[j].ctl[i];
-        fprintf(stderr, "[lora_hip] control per job, kcycles: copy-in %.0f loop %.0f plan %.0f copy-out %.0f (walker3: demodulation %.0f, replay %.0f of the decode rounds)\n", ctl[0] / nj / 1e3, ctl[1] / nj / 1e3, ctl[2] / nj / 1e3, ctl[3] / nj / 1e3, ctl[0] / nj / 1e3, ctl[1] / nj / 1e3);
+        fprintf(stderr, "[lora_hip] control per job, kcycles: copy-in %.0f loop %.0f plan %.0f copy-out %.0f (walker3: demodulation %.0f, replay %.0f of the decode rounds; with LORA_W3_REPLAY_STATS=2 copy-in and symbol loop in the 3rd / 4th figure)\n", ctl[0] / nj / 1e3, ctl[1] / nj / 1e3, ctl[2] / nj / 1e3, ctl[3] / nj / 1e3, ctl[0] / nj / 1e3, ctl[1] / nj / 1e3);
         std::vector<double> tot(nj);
         for (uint32_t j = 0; j < nj; j++) { double t = 0; for (int i = 0; i < 6; i++) t += 64.0 * out.res[j].cyc[i]; tot[j] = t; }
         std::sort(tot.begin(), tot.end());

@@ -854,7 +854,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 const bool dvalid = widx < dn && dwpos + 2 * (int64_t)sps <= n_items;
                 uint32_t ws = 0;
                 int32_t wfine = 0;
-                if (dvalid) wave_demod_symbol<SF, SF == 7>(P, FT, X + dwpos, ws, wfine);
+                if (dvalid) wave_demod_symbol<SF, (SF == 7) || LORA_W2_EARLY_F_SF8>(P, FT, X + dwpos, ws, wfine);
                 if (lane == 0) { W.speci[plan_buf][widx][0] = dvalid ? (int32_t)ws : -1; W.speci[plan_buf][widx][1] = wfine; }
             }
         } else { // the whole control wavefront, uniformly (identical values in every lane); t0 does the stores

@@ -56,6 +56,9 @@
 #ifndef LORA_W3_MOD_MASK
 #define LORA_W3_MOD_MASK 11     // bit (SF - 9): the replay's power-of-two reductions as masks instead of 64-bit / runtime modulo (not SF11)
 #endif
+#ifndef LORA_W3_FAST_REPLAY
+#define LORA_W3_FAST_REPLAY 1   // the replay's short path for a full round of unmoved payload symbols
+#endif
 #ifndef LORA_W3_REPLAY_STATS
 #define LORA_W3_REPLAY_STATS 1  // LORA_HIP_DEBUG accounting of thread 0's replay inside the decode rounds
 #endif
@@ -1156,6 +1159,35 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                 ws.stats.ctl[0] += (uint32_t)((tr0 - t_start) >> 6);
 #endif
                 W2State St = S;
+#if LORA_W3_REPLAY_STATS > 1 // (finer: ctl[2] = the state copy-in, ctl[3] = the symbol loop)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const long long tr1 = clock64();
+                ws.stats.ctl[2] += (uint32_t)((tr1 - tr0) >> 6);
+#endif
+                // The common round - NG payload symbols inside the data, none of which moves the symbol clock - taken on its own:
+                // what the general loop below does with them is the symbol's word, the block's deinterleave when it is full and
+                // three counters, but as one loop over every case (header, implicit mode, traces, limits, a break per outcome) the
+                // compiler carries the whole state through ~300 instructions per symbol: 1.7 k clocks each on the one thread
+                // that runs them, with the workgroup waiting (LORA_W3_REPLAY_STATS: 6.7 k of a 50 k round at SF9).
+                bool fast = LORA_W3_FAST_REPLAY && !trace && P.implicit == 0u && St.state == kDecodePayload && plan_n_win == NG &&
+                            pos + (int64_t)(NG + 1) * (int64_t)sps <= n_items; // (every window passes the loop-top check, :91)
+#pragma unroll
+                for (int q = 0; q < NG; q++) fast = fast && fq[q] == 0;
+                if (fast) {
+#pragma unroll
+                    for (int g = 0; g < NG; g++) {
+                        const uint32_t sg = sq[g];
+                        uint32_t bin_idx;
+                        if constexpr (G::FAST_MOD) bin_idx = (sg == 0u && P.demod_mode == 2u) ? 0u : (sg + (uint32_t)G::N - 1u) % (uint32_t)G::N;
+                        else bin_idx = (sg == 0u && P.demod_mode == 2u) ? 0u : (sg + P.nbins - 1u) % P.nbins;
+                        if (w3_post_symbol<G::FAST_MOD>(P, St, sh, true, bin_idx, false)) { // payload complete
+                            St.fin_pending = 1; St.fin_st = kDecodePayload; St.fin_consumed = (int32_t)sps; St.fin_bin = (int32_t)bin_idx; St.fin_fine = 0;
+                            break;
+                        }
+                        St.n_steps++; // w2_end_step of a payload step without a trace
+                        St.pos += (int64_t)sps;
+                    }
+                } else
                 for (int g = 0; g < NG; g++) {
                     if (g >= plan_n_win) break;
                     if (g > 0 && (!(St.state == kDecodeHeader || St.state == kDecodePayload) || !w2_pre_step(St, job, rec_cap, sps))) break;
@@ -1183,6 +1215,9 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                     w2_end_step(St, job, C, recs, trace, st_w, (int32_t)sps + fine, step_bin, fine, 0.0f, t_start); // :856,:883
                     if (St.done || fine != 0) break; // (fine != 0: the later windows started at the wrong sample)
                 }
+#if LORA_W3_REPLAY_STATS > 1
+                ws.stats.ctl[3] += (uint32_t)((clock64() - tr1) >> 6);
+#endif
                 W2Plan np;
                 plan_from(St, np);
                 next = np; S = St;

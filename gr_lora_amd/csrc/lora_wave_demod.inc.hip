@@ -23,12 +23,17 @@
 //      part of the table) and a reduce-scatter over r = lane bits 2 (row_shl/shr:4 with bank masks), 1, 0
 //   4. |X|^2 arg-max, first maximum in bin order (:454-463)
 //   5. fine_sync over lags -1, 0, +1 against the ifreq template; the window's instantaneous frequency is
-//      computed from the registers that were loaded for the dechirp (EARLY_F) or from a second, cache-hot
-//      read after the FFT (SF8, where 32 more live registers would spill).
+//      computed from the registers that were loaded for the dechirp (EARLY_F: SF7, and SF8 at its 256-register budget) or
+//      from a second, cache-hot read after the FFT (an SF8 build held to 128 registers, where 32 more live ones would spill).
 //
 // Instruction costs this is written against (tools/ubench_valu.hip, cycles per wave64 instruction per SIMD):
 // v_fma/mul/add_f32 2.4-3.0, v_pk_{fma,mul,add}_f32 4.3, DPP moves and v_*_dpp 4.3, v_cndmask/v_cmp/v_max 4.3,
 // v_rcp_f32 and v_permlane*_swap 8.2.
+
+#ifndef LORA_W2_EARLY_F_SF8
+#define LORA_W2_EARLY_F_SF8 1 // SF8: fine_sync's ifreq from the registers loaded for the dechirp (as SF7) instead of a second, cache-hot read:
+                              // at the kernel's 256-register budget it fits without a spill (227 VGPRs) and measures +6.5 %
+#endif
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(256) void demod_symbols_wave_kernel(DevParams P, co
     for (uint32_t s = blockIdx.x * 4u + wave; s < n; s += gridDim.x * 4u) {
         uint32_t b;
         int32_t fs;
-        wave_demod_symbol<SF, SF == 7>(P, T, iq + offsets[s], b, fs);
+        wave_demod_symbol<SF, (SF == 7) || LORA_W2_EARLY_F_SF8>(P, T, iq + offsets[s], b, fs);
         if ((threadIdx.x & 63u) == 0u) { bins[s] = b; if (fine) fine[s] = fs; }
     }
 }
