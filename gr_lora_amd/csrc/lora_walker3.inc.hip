@@ -45,16 +45,16 @@
 #define LORA_W3_LATE_F_MASK 0   // bit (SF - 9): that SF's walker computes fine_sync's ifreq from a second read of the window
 #endif
 // The next two change nothing the kernels compute, only how much the register allocator has to juggle - and at 128 VGPRs with
-// ~60-200 of them spilled that decides where the spill reloads land.  A reload is a round trip to memory (the scratch lines do not
+// 40-190 of them spilled that decides where the spill reloads land.  A reload is a round trip to memory (the scratch lines do not
 // survive in L2 beside the IQ stream: ~1-2 us each), and one that lands in front of a round's first loads, or inside thread 0's
-// replay, is paid by the whole workgroup every round.  Chosen per SF from a same-box grid (tools/ab.sh): of HBM peak at
-// 256 packets, SF9 13.9 -> 14.8 %, SF10 15.5 -> 16.6 %, SF11 17.5 -> 18.2 %, SF12 14.0 -> 14.9 %; the same switches the other
-// way round cost SF11 19 %.
+// replay, is paid by the whole workgroup every round.  Same-box grids (tools/ab.sh), of HBM peak at 256 packets:
+// job record in scalar registers SF9 15.0 -> 15.4 %, SF10 15.8 -> 16.9 %, SF11 17.5 -> 18.4 %, SF12 14.1 -> 14.8 %.  (Before the
+// library was built with -greedy-reverse-local-assignment the same two switches moved SF11 between 14.1 % and 18.2 %.)
 #ifndef LORA_W3_UJ_MASK
 #define LORA_W3_UJ_MASK 15      // bit (SF - 9): the job record through readfirstlane (uniform_job): the stream base and the limits in scalar registers
 #endif
 #ifndef LORA_W3_MOD_MASK
-#define LORA_W3_MOD_MASK 11     // bit (SF - 9): the replay's power-of-two reductions as masks instead of 64-bit / runtime modulo (not SF11)
+#define LORA_W3_MOD_MASK 15     // bit (SF - 9): the replay's power-of-two reductions as masks instead of 64-bit / runtime modulo
 #endif
 #ifndef LORA_W3_FAST_REPLAY
 #define LORA_W3_FAST_REPLAY 1   // the replay's short path for a full round of unmoved payload symbols
