@@ -25,6 +25,12 @@ constexpr int kW2DetectK = 4;   // DETECT windows per worker and round
 #ifndef LORA_W2_WAVES_SF8
 #define LORA_W2_WAVES_SF8 8
 #endif
+#ifndef LORA_W2_SFD_K
+#define LORA_W2_SFD_K 2 // FIND_SFD windows per worker and round
+#endif
+#ifndef LORA_W2_SFD_UNROLL
+#define LORA_W2_SFD_UNROLL 1 // both evaluations inlined: the second window's loads are issued under the first one's arithmetic (+1 %)
+#endif
 #ifndef LORA_W2_STAGGER
 #define LORA_W2_STAGGER 0
 #endif
@@ -34,6 +40,8 @@ constexpr int kW2DetectK = 4;   // DETECT windows per worker and round
 // wavefronts per workgroup the shared structures are sized for (SF7: 16-wave workgroups, one per CU, were measured slower:
 // all 15 workers hit their load and VALU phases together)
 constexpr int kW2MaxWaves = LORA_W2_WAVES_SF7 > LORA_W2_WAVES_SF8 ? LORA_W2_WAVES_SF7 : LORA_W2_WAVES_SF8;
+
+constexpr int kW2SfdK = LORA_W2_SFD_K;
 
 enum W2Mode : int32_t { kPlanExit = 0, kPlanDetect, kPlanSync, kPlanSfd, kPlanPause, kPlanDecode, kPlanFinalize };
 
@@ -747,20 +755,36 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         }
 
         if (plan_mode == kPlanSfd) {
-            float c = 0.0f;
-            int32_t fine = 0;
-            if (wvalid) {
-                const W2SfdOut r = w2_sfd_window<SF>(X + wpos, T.v, T.dd, T.scratch + wave * 72, P.down_ifreq_sd, P.down_ifreq_dsum, P.sync_a, P.sync_b);
-                c = r.c; fine = r.fine;
+            // kW2SfdK windows per worker: worker w looks at the windows w, w + workers, ... of the round.  Behind SYNC lie ~6 upchirps,
+            // the two sync-word symbols and the first downchirp - nine steps: two rounds of one window per worker (17 k clocks each)
+            // or one round of two (30 k): FIND_SFD 104 k -> 89 k clocks per job, the SF7 walker +3 %, SF8 +1 %.  (A touch of the
+            // second window's lines behind the first one's loads: nothing.)
+            constexpr int kSfdWin = kW2SfdK * kW2Workers;
+            static_assert(kW2SfdK <= 2 && kSfdWin <= 64, "results go to specf[w][k] / speci[k][w]");
+#if LORA_W2_SFD_UNROLL
+#pragma unroll
+#else
+#pragma nounroll
+#endif
+            for (int k = 0; k < kW2SfdK; k++) {
+                const int64_t kpos = wpos + (int64_t)k * kW2Workers * sps;
+                const bool kvalid = !is_ctl && wave < plan_n_win && kpos + 2 * (int64_t)sps <= n_items;
+                float c = 0.0f;
+                int32_t fine = 0;
+                if (kvalid) {
+                    const W2SfdOut r = w2_sfd_window<SF>(X + kpos, T.v, T.dd, T.scratch + wave * 72, P.down_ifreq_sd, P.down_ifreq_dsum, P.sync_a, P.sync_b);
+                    c = r.c; fine = r.fine;
+                }
+                if (lane == 0 && !is_ctl) { W.specf[wave][k] = c; W.speci[k][wave][0] = kvalid ? 1 : 0; W.speci[k][wave][1] = fine; }
             }
-            if (lane == 0 && !is_ctl) { W.specf[wave][0] = c; W.speci[0][wave][0] = wvalid ? 1 : 0; W.speci[0][wave][1] = fine; }
             __syncthreads();
             if (is_ctl) { // the whole control wavefront, uniformly, on a register copy of the state (as the decode rounds do)
                 W2State L = S;
-                const float my_c = lane < kW2Workers ? W.specf[lane][0] : 0.0f;
-                const int32_t my_v = lane < kW2Workers ? W.speci[0][lane][0] : 0, my_f = lane < kW2Workers ? W.speci[0][lane][1] : 0;
+                const int qw = lane % kW2Workers, qk = lane / kW2Workers; // lane q fetches window q = qk * workers + qw
+                const float my_c = lane < kSfdWin ? W.specf[qw][qk] : 0.0f;
+                const int32_t my_v = lane < kSfdWin ? W.speci[qk][qw][0] : 0, my_f = lane < kSfdWin ? W.speci[qk][qw][1] : 0;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                for (int w = 0; w < kW2Workers; w++) {
+                for (int w = 0; w < kSfdWin; w++) {
                     if (w > 0 && !w2_pre_step(L, job, rec_cap, sps)) break;
                     if (!__builtin_amdgcn_readlane(my_v, w)) break;
                     const float cw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int32_t, my_c), w));
