@@ -9,7 +9,7 @@ set -u
 TAG=${1:-x}; shift || true
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
-rm -rf "$OUT"; mkdir -p "$OUT"
+rm -rf "$OUT"; mkdir -p "$OUT"   # (on a gpurun box this is a fresh directory; LOCALLY delete gpurun_out/prof_<tag> before merging a new run into it: tools/profile_summary.py takes every file it finds there)
 cd /tmp && export TMPDIR=/tmp
 STEPS=${PROFILE_STEPS:-10}
 CMD="python $REPO/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline $*"

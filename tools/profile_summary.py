@@ -11,13 +11,19 @@ import collections, csv, glob, json, os, shutil, sys
 tag = sys.argv[1]
 rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
 src = os.path.join("gpurun_out", "prof_" + tag)
-stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+# (gpurun MERGES a run's files into gpurun_out/: files of an earlier run of the same tag may still lie there under other names -
+# only the newest file of each kind counts)
+def newest(pattern):
+    found = glob.glob(pattern, recursive=True)
+    return [max(found, key=os.path.getmtime)] if found else []
+
+stats = newest(os.path.join(src, "stats", "**", "*kernel_stats.csv"))
 assert stats, "no kernel_stats.csv"
 shutil.copy(stats[0], os.path.join("profiles", "%s_%s_kernel_stats.csv" % (rnd, tag)))
 
 def per_dispatch(kind, counter):
     out = collections.defaultdict(list)  # (kernel, grid) -> values
-    for path in glob.glob(os.path.join(src, kind, "**", "*counter_collection.csv"), recursive=True):
+    for path in newest(os.path.join(src, kind, "**", "*counter_collection.csv")):
         acc, meta = collections.defaultdict(float), {}
         for row in csv.DictReader(open(path)):
             if row["Counter_Name"] != counter or not any(k in row["Kernel_Name"] for k in ("walker", "envelope_kernel", "edges_kernel")):
