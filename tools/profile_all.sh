@@ -1,0 +1,23 @@
+#!/bin/bash
+# tools/profile_all.sh - the round's evidence set on ONE GPU box (gpurun -- 'bash tools/profile_all.sh'; locally delete gpurun_out/prof_* first): per SF kernel stats + PMC traffic + bench line (tools/profile_round.sh), then the default
+# line, the reference-API path and config 4
+cd $GRAFT_REPO_ROOT
+export LORA_BENCH_CACHE=/dev/shm/lora_bench
+mkdir -p gpurun_out
+{
+tools/profile_round.sh sf7
+tools/profile_round.sh sf8 --config 3 --sf 8 --packets 1024
+PROFILE_STEPS=8 tools/profile_round.sh sf9 --config 3 --sf 9
+PROFILE_STEPS=8 tools/profile_round.sh sf10 --config 3 --sf 10
+PROFILE_STEPS=6 tools/profile_round.sh sf11 --config 3 --sf 11
+PROFILE_STEPS=4 tools/profile_round.sh sf12 --config 3 --sf 12
+python bench.py 2>/dev/null | tail -1 > gpurun_out/default_line.json
+python bench.py --path work 2>/dev/null | tail -1 > gpurun_out/work_line.json
+python bench.py --config 4 --steps 30 --warmup 5 2>/dev/null | tail -1 > gpurun_out/cfg4_line.json
+python bench.py --config 4 --seconds 8 --steps 30 --warmup 5 2>/dev/null | tail -1 > gpurun_out/cfg4_8s_line.json
+python bench.py --streams 1 --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/streams1_line.json
+} > gpurun_out/profile_all.log 2>&1
+# keep what travels back small: the per-dispatch traces are not needed once summarised... (kernel_stats + counter_collection csv only)
+find gpurun_out/prof_* -type f ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" ! -name "*.log" ! -name "line.json" -delete 2>/dev/null
+du -sh gpurun_out | tail -1
+tail -30 gpurun_out/profile_all.log
