@@ -3,10 +3,13 @@
 # as the pool requires), CSV output under gpurun_out/pmc/<group>/.  Summarise with tools/pmc_summary.py.
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$REPO/gpurun_out/pmc
-mkdir -p "$OUT"
+# usage: tools/pmc_walker.sh [tag [bench.py arguments]]   (default: tag "pmc", the default workload)
+TAG=${1:-pmc}; shift || true
+OUT=$REPO/gpurun_out/$TAG
+rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+export LORA_BENCH_CACHE=${LORA_BENCH_CACHE:-/dev/shm/lora_bench}
+CMD="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
 i=0
 for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" \
            "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
