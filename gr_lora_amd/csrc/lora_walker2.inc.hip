@@ -4,7 +4,8 @@
 // Same state machine as walker_body (decoder_impl::work, lib/decoder_impl.cc:740-903), organised in
 // ROUNDS: WAVES wavefronts = WAVES-1 workers + 1 control wavefront (512 threads: 7 workers; two workgroups per CU
 // at SF7.  A 16-wavefront workgroup with 15 workers was built and measured 30 % slower).  In DETECT, FIND_SFD and DECODE_*
-// every worker evaluates one upcoming symbol window at pos + w*sps (zero drift assumed); the control
+// every worker evaluates upcoming symbol windows at pos + w*sps (zero drift assumed: one per round in DECODE_*, two in FIND_SFD,
+// one or four in DETECT); the control
 // thread then replays the reference's per-call logic over the results in order and stops at the first
 // one whose outcome invalidates the later windows (a trigger, a state change, d_fine_sync != 0, end of
 // data).  The accepted sequence is therefore exactly the serial one.  DECODE rounds are PIPELINED: while
@@ -17,7 +18,7 @@
 
 constexpr int kW2DetectK = 4;   // DETECT windows per worker and round
 #ifndef LORA_W2_DOUBLE
-#define LORA_W2_DOUBLE 0 // 1-3: the worker beside the control wavefront takes two windows of a decode round (measured slower, DESIGN 4.1)
+#define LORA_W2_DOUBLE 0 // 1-3: the worker beside the control wavefront takes two windows of a decode round (measured slower, DESIGN 5.2)
 #endif
 #ifndef LORA_W2_WAVES_SF7
 #define LORA_W2_WAVES_SF7 8
@@ -32,7 +33,7 @@ constexpr int kW2DetectK = 4;   // DETECT windows per worker and round
 #define LORA_W2_SFD_UNROLL 1 // both evaluations inlined: the second window's loads are issued under the first one's arithmetic (+1 %)
 #endif
 #ifndef LORA_W2_STAGGER
-#define LORA_W2_STAGGER 0
+#define LORA_W2_STAGGER 0 // start-up stagger between workgroups, shader clocks per step (measured: no gain)
 #endif
 #ifndef LORA_W2_EU_SF8
 #define LORA_W2_EU_SF8 2 // wavefronts per SIMD the SF8 kernel's register budget is set for
