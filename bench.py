@@ -238,6 +238,9 @@ def main():
                     "3 = also the envelope pre-pass of step k+2 is issued ahead (it runs in the tail of step k's walker)")
     ap.add_argument("--chunk", type=int, default=1 << 22, help="--path work: items per lora_hip_work call")
     ap.add_argument("--batch", type=int, default=1 << 24, help="--path work: items per device pass (lora_hip_config_t.batch_items)")
+    ap.add_argument("--overlap", action="store_true", help="passes alternate between TWO HIP streams: the walker kernel of pass k+1 starts on the CUs that "
+                    "pass k's shorter jobs have left (a streaming receiver's mode; not the default: the per-kernel HIP-event durations then "
+                    "include the time a kernel shares the device with its neighbour, and roofline.frac is computed from them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -287,6 +290,9 @@ def main():
     depth = max(1, min(3, args.depth))
     hs = [capi.Handle(**kw) for _ in range(depth)]
     stream = torch.cuda.current_stream().cuda_stream
+    if args.overlap:
+        second = torch.cuda.Stream(device=dev)
+        stream = [stream, second.cuda_stream]
     gat = gather.AsyncSlotGather(dev, max(64, 2 * n_frames_expected))
 
     # One step = one full pass over the batch, software-pipelined the way a streaming receiver runs them
@@ -345,7 +351,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "workload_key": wkey, "items_per_gpu": n_items, "demod": ["grad", "fft", "fft_compat"][args.demod],
                        "bit_exact_vs_expected": verified, "parallelism": "streams sharded, dp%d; frame gather: 1 async all_gather per step" % world,
-                       "pipeline_depth": depth, "path": "device (IQ resident in HBM)", "source_hash": source_hash()},
+                       "pipeline_depth": depth, "path": "device (IQ resident in HBM)" + (", passes alternating between two HIP streams" if args.overlap else ""),
+                       "source_hash": source_hash()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": tq[0] if tq else None,
                          "traffic_unit": "HBM bytes per pass (rocprofv3 PMC, %s; null unless measured on these sources)" % (tq[1] if tq else "profiles/*pmc_traffic*.json"),

@@ -195,15 +195,18 @@ class PassPipeline:
     while step k+1 runs.  `handles` need decode_device_begin / _prepass / _end, drain_slots and timing (gr_lora_amd.capi.Handle;
     the CPU tests use a stub)."""
 
-    def __init__(self, handles, gatherer: AsyncSlotGather, dev_ptr: int, n_items: int, offs, lens, stream: int = 0):
+    def __init__(self, handles, gatherer: AsyncSlotGather, dev_ptr: int, n_items: int, offs, lens, stream=0):
+        """`stream`: one HIP stream handle, or a list of them - pass k then goes to stream k mod len(list): with two streams the
+        walker kernel of pass k+1 starts on the CUs pass k's shorter jobs have already left (bench.py --overlap)."""
         self.hs, self.gat, self.depth = list(handles), gatherer, len(handles)
-        self.args = (dev_ptr, n_items, offs, lens, stream)
+        self.streams = list(stream) if isinstance(stream, (list, tuple)) else [stream]
+        self.args = (dev_ptr, n_items, offs, lens)
 
     def _begin(self, k):   # the IQ is resident and unchanged: the envelope pre-pass need not wait for the stream (IQ_READY)
-        self.hs[k % self.depth].decode_device_begin(*self.args, iq_ready=True)
+        self.hs[k % self.depth].decode_device_begin(*self.args, self.streams[k % len(self.streams)], iq_ready=True)
 
     def _prepass(self, k):
-        self.hs[k % self.depth].decode_device_prepass(*self.args, iq_ready=True)
+        self.hs[k % self.depth].decode_device_prepass(*self.args, self.streams[k % len(self.streams)], iq_ready=True)
 
     def _finish(self, k):
         hk = self.hs[k % self.depth]
