@@ -201,7 +201,7 @@ def quoted_traffic(workload_key):
         except (OSError, ValueError):
             continue
         if pmc.get("workload_key") == workload_key and pmc.get("source_hash") == source_hash():
-            best = (int(pmc["hbm_bytes_per_pass_corrected"]), name)
+            best = (int(pmc["hbm_bytes_per_pass_corrected"]), name, pmc.get("rocprof_walker_avg_ms_per_pass"), pmc.get("rocprof_kernel_stats"))
     return best
 
 
@@ -254,7 +254,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # Under a launcher (WORLD_SIZE set) the process group is RCCL whatever the world size: `torchrun --nproc-per-node 1` drives
+    # the same collective code (AsyncSlotGather's all_gather_into_tensor on its side stream, the barrier, the MAX reduction)
+    # as an 8-GPU run - tests/test_gpu_rccl.py runs exactly that on the one GPU a gpurun box has.
+    use_dist = "WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
@@ -314,16 +318,16 @@ def main():
 
     run(40 if n_items < 4e8 else 4)   # pre-roll, untimed like the check above: brings the device to its sustained clocks
     run(args.warmup)                  # the W warm-up steps proper
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     walker_ms, launches = run(args.steps)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -351,10 +355,16 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "workload_key": wkey, "items_per_gpu": n_items, "demod": ["grad", "fft", "fft_compat"][args.demod],
                        "bit_exact_vs_expected": verified, "parallelism": "streams sharded, dp%d; frame gather: 1 async all_gather per step" % world,
+                       "process_group": ("nccl (RCCL), world %d" % world) if use_dist else "none (single process)",
                        "pipeline_depth": depth, "path": "device (IQ resident in HBM)" + (", passes alternating between two HIP streams" if args.overlap else ""),
                        "source_hash": source_hash()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": tq[0] if tq else None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         # the same fraction from the committed `rocprofv3 --kernel-trace --stats` summary of this workload on these
+                         # sources (average duration of the walker kernel there; null unless workload and source hash match)
+                         "frac_rocprof": (round(8.0 * n_items / (tq[2] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if tq and tq[2] else None),
+                         "rocprof_kernel_ms_per_pass": (tq[2] if tq else None), "rocprof_summary": (tq[3] if tq else None),
+                         "traffic": tq[0] if tq else None,
                          "traffic_unit": "HBM bytes per pass (rocprofv3 PMC, %s; null unless measured on these sources)" % (tq[1] if tq else "profiles/*pmc_traffic*.json"),
                          "kernel": kname, "kernel_ms_per_pass": round(kernel_ms, 4),
                          "launches_per_pass": launches / max(1, args.steps),
@@ -375,7 +385,7 @@ def main():
         print(json.dumps(res))
     for hk in hs:
         hk.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

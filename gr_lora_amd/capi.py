@@ -23,6 +23,7 @@ EXPORTS = [
     "lora_hip_get_geometry", "lora_hip_set_sf", "lora_hip_set_samp_rate", "lora_hip_work", "lora_hip_flush",
     "lora_hip_decode_device", "lora_hip_frames_available", "lora_hip_poll_frame", "lora_hip_drain_frames", "lora_hip_drain_slots", "lora_hip_demod_symbols_device", "lora_hip_demod_symbols_ex_device",
     "lora_hip_last_timing", "lora_hip_last_plan", "lora_hip_gap_starts_device", "lora_hip_decode_device_begin", "lora_hip_decode_device_end", "lora_hip_decode_device_prepass", "lora_hip_trace", "lora_hip_trace_clear", "lora_hip_check_frame", "lora_hip_estimate_cfo_device",
+    "lora_hip_set_stream_latency", "lora_hip_stream_info",
 ]
 
 
@@ -66,6 +67,11 @@ class FrameCheck(C.Structure):
     _fields_ = [("has_header", C.c_uint8), ("header_checksum_ok", C.c_uint8), ("has_crc", C.c_uint8), ("crc_ok", C.c_uint8),
                 ("header_checksum_rx", C.c_uint8), ("header_checksum_calc", C.c_uint8), ("crc_rx", C.c_uint16), ("crc_calc", C.c_uint16),
                 ("reserved", C.c_uint16)]
+
+
+class StreamInfo(C.Structure):
+    _fields_ = [("batch_items", C.c_uint64), ("buffered_items", C.c_uint64), ("passes", C.c_uint64), ("passes_by_latency", C.c_uint64),
+                ("consumed_base", C.c_int64), ("max_latency_ms", C.c_float), ("pass_in_flight", C.c_uint32)]
 
 
 class LoraHipError(RuntimeError):
@@ -128,6 +134,8 @@ def load():
     L.lora_hip_trace_clear.restype = None
     L.lora_hip_estimate_cfo_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_int64), C.c_size_t, C.c_int, C.POINTER(C.c_float), vp]
     L.lora_hip_estimate_cfo_device.restype = C.c_int
+    L.lora_hip_set_stream_latency.argtypes = [vp, C.c_float]
+    L.lora_hip_stream_info.argtypes = [vp, C.POINTER(StreamInfo)]
     L.lora_hip_check_frame.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(FrameCheck)]
     L.lora_hip_check_frame.restype = C.c_int
     L.lora_hip_channelizer_create.argtypes = [C.POINTER(ChannelizerConfig), C.POINTER(vp)]
@@ -197,6 +205,15 @@ class Handle:
 
     def flush(self):
         self._check(self.L.lora_hip_flush(self.h))
+
+    def set_stream_latency(self, max_latency_ms: float):
+        """lora_hip_set_stream_latency: wall-clock bound on how long a delivered sample waits for a device pass (0 = off)."""
+        self._check(self.L.lora_hip_set_stream_latency(self.h, float(max_latency_ms)))
+
+    def stream_info(self) -> StreamInfo:
+        out = StreamInfo()
+        self._check(self.L.lora_hip_stream_info(self.h, C.byref(out)))
+        return out
 
     # batched, device-resident
     def decode_device(self, dev_ptr: int, total_items: int, offs: Sequence[int], lens: Sequence[int], stream: int = 0):

@@ -172,6 +172,11 @@ struct lora_hip_decoder {
         std::vector<std::pair<uintptr_t, uintptr_t>> pinned; // caller ranges registered with hipHostRegister (DMA straight from them)
         std::vector<std::pair<uintptr_t, uintptr_t>> refused; // ranges the runtime would not register: do not ask again
         uint64_t bytes_direct = 0, bytes_staged = 0;
+        // latency bound (lora_hip_set_stream_latency): a pass is launched when the oldest unlaunched sample has waited this long
+        float max_latency_ms = 50.0f;
+        std::chrono::steady_clock::time_point t_first; // arrival of the first item of the chunk being filled
+        bool have_first = false;
+        uint64_t passes = 0, passes_by_latency = 0;
     } sp;
     int64_t host_base = 0;      // absolute item index of the first item of the stream region of the next pass
     uint32_t stream_cr = 0;
@@ -829,6 +834,9 @@ lora_hip_status lora_hip_decode_device_end(lora_hip_decoder_t *h)
 {
     if (!h) return LORA_HIP_ERR_ARG;
     if (!h->pass_open) return fail(h, LORA_HIP_ERR_ARG, "lora_hip_decode_device_end without a pass begun");
+    // (the streaming pipeline keeps its in-flight pass in the same PassCtx: collecting it here would leave lora_hip_work's tail,
+    // d_phdr.cr and power queue behind - that pass belongs to lora_hip_work / lora_hip_flush)
+    if (h->sp.inflight) return fail(h, LORA_HIP_ERR_ARG, "lora_hip_decode_device_end: the open pass is lora_hip_work's; call lora_hip_flush");
     h->pass_open = false;
     HIP_TRY(h, hipSetDevice(h->device));
     h->err.clear();
@@ -1003,6 +1011,8 @@ static lora_hip_status stream_rotate(lora_hip_decoder *h)
         h->pass_open = true;
         sp.inflight = true; sp.fl_off = sp.tailcap - sp.tail_len; sp.fl_len = len;
         sp.cur ^= 1; sp.fill = 0; sp.tail_len = 0;
+        sp.have_first = false;
+        sp.passes++;
     }
     // (shorter than one work() call of the reference, :91: keep filling the same chunk)
     return LORA_HIP_OK;
@@ -1019,6 +1029,12 @@ lora_hip_status lora_hip_work(lora_hip_decoder_t *h, const float *iq, size_t n_i
     const float2 *src = reinterpret_cast<const float2 *>(iq);
     size_t left = n_items;
     bool direct_pending = false;
+    // a pass whose kernel has finished is collected now - its frames are published by this call, not a chunk later
+    if (sp.inflight && h->pending.open && hipEventQuery(h->ev_done) == hipSuccess) {
+        s = stream_collect(h);
+        if (s != LORA_HIP_OK) return s;
+    }
+    (void)hipGetLastError(); // (hipErrorNotReady of the query)
     const bool direct = n_items != 0 && stream_host_pinned(h, iq, n_items * sizeof(float2)); // (the whole call's range, once)
     while (left) {
         if (sp.fill == h->batch_items) { // (a chunk that could not be launched yet because the stream was shorter than 2 sps)
@@ -1049,6 +1065,7 @@ lora_hip_status lora_hip_work(lora_hip_decoder_t *h, const float *iq, size_t n_i
             }
             sp.bytes_staged += m * sizeof(float2);
         }
+        if (!sp.have_first) { sp.have_first = true; sp.t_first = std::chrono::steady_clock::now(); }
         sp.fill += m; src += m; left -= m;
         if (sp.fill == h->batch_items) {
             s = stream_rotate(h);
@@ -1057,7 +1074,34 @@ lora_hip_status lora_hip_work(lora_hip_decoder_t *h, const float *iq, size_t n_i
     }
     // the caller may reuse its buffer as soon as we return (the scheduler's contract): the DMA out of it must be done
     if (direct_pending) HIP_TRY(h, hipStreamSynchronize(sp.copy_st));
+    // latency bound: the oldest sample not yet handed to a pass has waited long enough (and a pass could run at all, :91)
+    if (sp.max_latency_ms > 0.0f && sp.have_first && sp.fill != 0 && sp.tail_len + sp.fill >= 2u * (size_t)h->P.sps &&
+        std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - sp.t_first).count() >= sp.max_latency_ms) {
+        const uint64_t before = sp.passes;
+        s = stream_rotate(h);
+        if (s != LORA_HIP_OK) return s;
+        sp.passes_by_latency += sp.passes - before;
+    }
     if (consumed) *consumed = n_items;
+    return LORA_HIP_OK;
+}
+
+lora_hip_status lora_hip_set_stream_latency(lora_hip_decoder_t *h, float max_latency_ms)
+{
+    if (!h || !(max_latency_ms >= 0.0f)) return LORA_HIP_ERR_ARG;
+    h->sp.max_latency_ms = max_latency_ms;
+    return LORA_HIP_OK;
+}
+
+lora_hip_status lora_hip_stream_info(const lora_hip_decoder_t *h, lora_hip_stream_info_t *out)
+{
+    if (!h || !out) return LORA_HIP_ERR_ARG;
+    out->batch_items = h->batch_items;
+    out->buffered_items = h->sp.tail_len + h->sp.fill;
+    out->passes = h->sp.passes; out->passes_by_latency = h->sp.passes_by_latency;
+    out->consumed_base = h->host_base;
+    out->max_latency_ms = h->sp.max_latency_ms;
+    out->pass_in_flight = h->sp.inflight ? 1u : 0u;
     return LORA_HIP_OK;
 }
 

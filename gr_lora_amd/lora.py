@@ -81,8 +81,9 @@ class decoder(_MsgBlock):
                  batch_items=0, segment_symbols=0, cfo_estimates=False):
         super().__init__()
         self._cfo = bool(cfo_estimates)
-        self._hist = np.zeros(0, dtype=np.complex64)   # cfo_estimates: the most recent input, for the preamble windows
-        self._hist_base = 0                            # absolute item index of _hist[0]
+        self._hist = None                              # cfo_estimates: ring buffer of the most recent input, for the preamble windows
+        self._hist_end = 0                             # absolute item index one past the newest item in the ring
+        self.cfo_dropped = 0                           # estimates not published because their window had left the ring
         if sf < 6 or sf > 12:  # decoder_impl.cc:57-61 -- the reference prints this and exit(1)s
             sys.stderr.write("[LoRa Decoder] ERROR : Spreading factor should be between 6 and 12 (inclusive)!\n"
                              "                       Other values are currently not supported.\n")
@@ -105,6 +106,14 @@ class decoder(_MsgBlock):
             if implicit:
                 print("CR: \t\t%d" % cr)
                 print("CRC: \t\t%d" % int(bool(crc)))
+        if self._cfo:
+            # A frame surfaces at most two device passes after its last sample (one being filled, one in flight) and its
+            # preamble lies a whole packet further back: the ring holds 2 passes of the library's EFFECTIVE batch size
+            # (lora_hip_stream_info; 2M items at SF12, not the constructor argument) + the longest packet + a margin.
+            eff_batch = int(self._h.stream_info().batch_items)
+            ppm = int(sf) - 2 if reduced_rate else int(sf)          # bits per payload symbol (decoder_impl.cc:842-847)
+            longest = (14 + 8 + 8 * -(-(2 * 257 * 8) // (8 * ppm))) * self._h.sps   # preamble + header + ceil(257 B at CR 4/8 / block) blocks of 8
+            self._hist = np.zeros(2 * eff_batch + longest + 8 * self._h.sps, dtype=np.complex64)
         self.message_port_register_out("frames")    # decoder_impl.cc:120
         self.message_port_register_out("control")   # :121 (registered, never published upstream)
 
@@ -115,12 +124,17 @@ class decoder(_MsgBlock):
     def work(self, input_items) -> int:
         """Consumes every item handed in (buffers internally); publishes finished frames."""
         x = np.asarray(input_items)
-        if self._cfo:   # frames come out one chunk late (the passes are pipelined): keep three chunks of input
-            keep = 3 * max(int(self._h.batch_items), 1 << 20)
-            self._hist = np.concatenate([self._hist, x.astype(np.complex64, copy=False)])
-            if self._hist.size > keep:
-                self._hist_base += self._hist.size - keep
-                self._hist = self._hist[-keep:]
+        if self._cfo:   # preallocated ring: one copy of the new items, nothing re-copied
+            xc = x.astype(np.complex64, copy=False).ravel()
+            cap = self._hist.size
+            if xc.size >= cap:
+                xc = xc[-cap:]
+                self._hist_end += int(x.size) - cap
+            w = self._hist_end % cap
+            first = min(xc.size, cap - w)
+            self._hist[w:w + first] = xc[:first]
+            self._hist[:xc.size - first] = xc[first:]
+            self._hist_end += xc.size
         n = self._h.work(x)
         self._publish()
         return n
@@ -146,12 +160,15 @@ class decoder(_MsgBlock):
         settled; the estimate is the mean over the window (mode 1), not upstream's single sample."""
         import torch
         sps = self.samples_per_symbol
-        w0 = int(info.header_pos) - (25 * sps) // 4 - self._hist_base
-        if w0 < 0 or w0 + sps > self._hist.size:
+        cap = self._hist.size
+        a0 = int(info.header_pos) - (25 * sps) // 4           # absolute item index of the window
+        if a0 < max(self._hist_end - cap, 0) or a0 + sps > self._hist_end:
+            self.cfo_dropped += 1                                # (counted, not silent: the ring was sized too small for this traffic)
             return
-        d = torch.from_numpy(np.ascontiguousarray(self._hist[w0:w0 + sps]).view(np.float32)).to("cuda:%d" % self._h.device)
+        idx = (a0 + np.arange(sps)) % cap
+        d = torch.from_numpy(np.ascontiguousarray(self._hist[idx]).view(np.float32)).to("cuda:%d" % self._h.device)
         hz = float(self._h.estimate_cfo_device(d.data_ptr(), sps, [0], mode=1)[0])
-        self.message_port_pub("control", ("cfo", hz, w0 + self._hist_base))   # (the window's position lets a consumer ignore stale estimates)
+        self.message_port_pub("control", ("cfo", hz, a0))      # (the window's position lets a consumer ignore stale estimates)
 
     # decoder.h:708-709 ------------------------------------------------------
     def set_sf(self, sf):

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LORA_HIP_ABI_VERSION 1
+#define LORA_HIP_ABI_VERSION 2   /* 2: lora_hip_set_stream_latency, lora_hip_stream_info, lora_hip_detect_preambles_device */
 
 typedef enum lora_hip_status {
     LORA_HIP_OK = 0,
@@ -128,6 +128,27 @@ lora_hip_status lora_hip_work(lora_hip_decoder_t *h, const float *iq, size_t n_i
 /* Runs the device pass over everything buffered, honouring the scheduler rule that work() is only called
  * while 2*samples_per_symbol items remain (set_output_multiple, :91).                                      */
 lora_hip_status lora_hip_flush(lora_hip_decoder_t *h);
+
+/* Latency of the streaming path.  The reference publishes a frame inside the work() call that completes the packet
+ * (decoder_impl.cc:870-881).  Here samples are decoded in device passes: a pass is launched when batch_items have arrived
+ * OR when the oldest sample not yet handed to a pass has waited max_latency_ms of wall-clock time (and at least two symbols
+ * are buffered, :91), and a finished pass is collected - its frames published - by the next lora_hip_work call that finds its
+ * kernel done (hipEventQuery: no waiting).  A frame therefore surfaces within max_latency_ms + one device pass (< 1 ms for a
+ * latency-bounded pass) + the caller's own call period after its last sample arrived; a caller that delivers samples faster
+ * than batch_items per max_latency_ms never sees the bound (full chunks, full throughput).  Default 50 ms; 0 = off (passes
+ * only on full chunks and on lora_hip_flush).  What is decoded does not depend on where the passes fall.                   */
+lora_hip_status lora_hip_set_stream_latency(lora_hip_decoder_t *h, float max_latency_ms);
+
+typedef struct lora_hip_stream_info {
+    uint64_t batch_items;            /* effective chunk size (lora_hip_config_t.batch_items, or the automatic value)          */
+    uint64_t buffered_items;         /* delivered to lora_hip_work and not yet handed to a pass (tail + chunk being filled)     */
+    uint64_t passes;                 /* device passes launched so far                                                          */
+    uint64_t passes_by_latency;      /* ... of which because of the latency bound, not a full chunk or a flush                 */
+    int64_t  consumed_base;          /* absolute item index up to which the stream is decoded (frames before it are published) */
+    float    max_latency_ms;
+    uint32_t pass_in_flight;
+} lora_hip_stream_info_t;
+lora_hip_status lora_hip_stream_info(const lora_hip_decoder_t *h, lora_hip_stream_info_t *out);
 
 /* ---- batched, device-resident: many independent streams in one pass ------------------------------------- */
 /* d_iq: device pointer to cf32 items; stream i occupies items [stream_off[i], stream_off[i]+stream_len[i]).

@@ -1,0 +1,104 @@
+"""RCCL executed on the one GPU a test box has.
+
+The N > 1 path of bench.py - `dist.init_process_group("nccl")`, AsyncSlotGather's `all_gather_into_tensor` on its side stream
+with the pinned device-to-host copy ordered behind it, PassPipeline's begin(k+1) / end(k) loop over real decoder handles, the
+barrier + MAX reduction around the timed region - is world-size independent code; here it runs with world size 1 (one rank,
+backend nccl = RCCL) in a process of its own, against the oracle-free expectation `synth.expected_frame_tail`, and
+`torchrun --nproc-per-node 1 bench.py` is held against the plain single-process run.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["LORA_ROOT"])
+from gr_lora_amd import capi, gather, synth
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+dev = torch.device("cuda", 0)
+cfg = synth.TxConfig(sf=7, cr=4)
+rng = np.random.default_rng(11)
+streams, offs, lens, expect, off = [], [], [], [], 0
+for s in range(3):
+    payloads = [bytes(rng.integers(0, 256, 20 + 5 * s, dtype=np.uint8)) for _ in range(6)]
+    st = synth.build_stream(payloads, cfg, rng=rng, gap_symbols=(2.0, 6.0))
+    streams.append(st.iq); offs.append(off); lens.append(st.iq.size); off += st.iq.size
+    expect.append([synth.expected_frame_tail(p, cfg) for p in payloads])
+iq = np.concatenate(streams)
+d_iq = torch.from_numpy(iq.view(np.float32)).to(dev)
+hs = [capi.Handle(sf=7, cr=4, demod=capi.DEMOD_FFT_COMPAT) for _ in range(3)]
+gat = gather.AsyncSlotGather(dev, 64)
+assert gat.dist and gat.cuda and gat.stream is not None and gat.world == 1      # the CUDA + process-group branch, not the fallback
+pipe = gather.PassPipeline(hs, gat, d_iq.data_ptr(), int(iq.size), offs, lens, torch.cuda.current_stream().cuda_stream)
+kept = []
+steps = 7
+pipe.run(steps, kept)
+assert len(kept) == steps, len(kept)
+for slots, counts in kept:                                                     # every step's gather carries every frame of this rank
+    assert slots.shape[0] == 1 and counts == [18], (slots.shape, counts)
+    got = {}
+    for b, sid, _hp in gather.unpack_frames(slots[0], counts[0]):
+        got.setdefault(sid, []).append(b[15:])
+    assert all(got.get(s, []) == expect[s] for s in range(3)), "frames gathered over RCCL differ from the transmitted payloads"
+# the other collectives bench.py's timed region uses
+dist.barrier()
+t = torch.tensor([1.25], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); assert float(t.item()) == 1.25
+# gather_slots / gather_raw (the synchronous forms) over RCCL as well
+slots, counts = gather.gather_slots(gather.pack_frames([(b"\x01" * 40, 2, 77)], 1), dev)
+assert counts == [1] and gather.unpack_frames(slots[0], 1) == [(b"\x01" * 40, 2, 77)]
+for h in hs: h.close()
+dist.destroy_process_group()
+print("RCCL_WORLD1_OK")
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _env():
+    env = dict(os.environ)
+    env.update(LORA_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return env
+
+
+def test_pass_pipeline_and_async_gather_over_rccl_world1():
+    r = subprocess.run([sys.executable, "-c", _WORKER], env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def _bench(argv, env=None):
+    r = subprocess.run(argv, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert r.returncode == 0 and lines, (r.stdout[-2000:], r.stderr[-4000:])
+    return json.loads(lines[-1])
+
+
+def test_bench_under_torchrun_world1_matches_plain_run():
+    common = ["--gpus", "1", "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--packets", "1024"]
+    plain = _bench([sys.executable, "bench.py"] + common)
+    env = _env()
+    port = env.pop("MASTER_PORT")
+    launched = _bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", port,
+                       "bench.py"] + common, env=env)
+    assert plain["config"]["process_group"].startswith("none") and launched["config"]["process_group"] == "nccl (RCCL), world 1"
+    assert plain["config"]["bit_exact_vs_expected"] and launched["config"]["bit_exact_vs_expected"]
+    assert launched["n_gpus"] == 1 and launched["steps"] == 30
+    # the same work with the frame gather going through RCCL: within run-to-run noise of the plain run (two processes on a box
+    # that has just been leased: clocks differ by a few per cent between them)
+    ratio = launched["value"] / plain["value"]
+    assert 0.85 < ratio < 1.18, (plain["value"], launched["value"])

@@ -20,6 +20,8 @@ def newest(pattern):
 stats = newest(os.path.join(src, "stats", "**", "*kernel_stats.csv"))
 assert stats, "no kernel_stats.csv"
 shutil.copy(stats[0], os.path.join("profiles", "%s_%s_kernel_stats.csv" % (rnd, tag)))
+# average duration of the walker kernel in that summary, per pass (a pass may launch it more than once: launches_per_pass below)
+_walker_rows = [r for r in csv.DictReader(open(stats[0])) if "walker" in r["Name"]]
 
 def per_dispatch(kind, counter):
     out = collections.defaultdict(list)  # (kernel, grid) -> values
@@ -73,6 +75,10 @@ res = {
     "prepass_hbm_bytes_per_pass_corrected": 2.0 * pre_fetch + pre_write,
     "algorithmic_bytes_per_pass": 8 * line["config"]["items_per_gpu"],
     "traffic_over_algorithmic": (2.0 * fetch_raw + write_raw) / (8.0 * line["config"]["items_per_gpu"]),
+    # what bench.py prints as roofline.frac_rocprof / rocprof_kernel_ms_per_pass when workload and sources match
+    "rocprof_kernel_stats": "profiles/%s_%s_kernel_stats.csv" % (rnd, tag),
+    "rocprof_walker_calls": sum(int(r["Calls"]) for r in _walker_rows),
+    "rocprof_walker_avg_ms_per_pass": (sum(float(r["TotalDurationNs"]) for r in _walker_rows) / max(1, sum(int(r["Calls"]) for r in _walker_rows)) * launches / 1e6) if _walker_rows else None,
 }
 json.dump(res, open(os.path.join("profiles", "%s_%s_pmc_traffic.json" % (rnd, tag)), "w"), indent=1)
 lj = os.path.join(src, "line.json")
