@@ -281,7 +281,32 @@ def main():
     n_frames_expected = sum(len(e) for e in expect)
     kw = dict(samp_rate=cfg.samp_rate, bandwidth=cfg.bw, sf=cfg.sf, cr=4, crc=True, reduced_rate=cfg.reduced_rate, device=local_rank, demod=args.demod)
 
-    def check(frames_by_stream):
+    # What the decoder must publish.  FFT demodulators: the payloads as sent.  Gradient demodulator (--demod 0, the reference's
+    # shipped default): that estimator is not the transmitter's inverse on every symbol - the compiled reference itself loses a
+    # few payloads of this clean workload - so the yardstick is what THE REFERENCE published on the same IQ:
+    # tests/golden/fullsize_ref.json (made by oracle/_ref in the build container; frame count + sha256 per stream).
+    ref_fix = None
+    if args.demod == 0 and args.config in (2, 3) and rank == 0:
+        try:
+            fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_ref.json")))
+            want = dict(sf=sf, cr=args.cr, packets=packets, payload=args.payload, streams=min(args.streams, packets), seed=(2 if args.config == 2 else 100 * sf + 4))
+            ref_fix = next((e for e in fx.values() if all(e[k] == v for k, v in want.items())), None)
+        except (OSError, ValueError):
+            ref_fix = None
+
+    def _digest(frames):
+        h = hashlib.sha256()
+        for f in frames:
+            h.update(len(f).to_bytes(4, "little"))
+            h.update(f)
+        return h.hexdigest()
+
+    ref_checked = [False]
+
+    def check(frames_by_stream, full=None):
+        if ref_fix is not None and full is not None:
+            ref_checked[0] = True
+            return all(len(full.get(s, [])) == e["frames"] and _digest(full.get(s, [])) == e["sha256"] for s, e in enumerate(ref_fix["per_stream"]))
         return all(frames_by_stream.get(s, []) == expect[s] for s in range(len(offs)))
 
     if args.path == "work":
@@ -311,10 +336,11 @@ def main():
     verified = len(kept) == depth
     for slots, counts in kept:
         r = rank if len(counts) > 1 else 0
-        got = {}
+        got, full = {}, {}
         for b, sid, _hp in gather.unpack_frames(slots[r], counts[r]):
             got.setdefault(sid, []).append(b[15:])
-        verified = verified and check(got)
+            full.setdefault(sid, []).append(b)
+        verified = verified and check(got, full)
 
     run(40 if n_items < 4e8 else 4)   # pre-roll, untimed like the check above: brings the device to its sustained clocks
     run(args.warmup)                  # the W warm-up steps proper
@@ -345,8 +371,7 @@ def main():
         value = total_items * args.steps / elapsed / 1e6
         kernel_ms = walker_ms / max(1, args.steps)  # walker kernel time per pass (HIP events, launch stream)
         achieved = 8.0 * n_items / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        fast = args.demod != 0 and not os.environ.get("LORA_HIP_NO_FAST")
-        kname = ("walker2_kernel_sf%d" % sf) if (fast and sf in (7, 8)) else ("walker3_kernel_sf%d" % sf) if (fast and 9 <= sf <= 12) else "walker_kernel"
+        kname = hs[0].kernel_name()
         tq = quoted_traffic(wkey)
         res = {
             "metric": "IQ Msamples/s demodulated", "value": round(value, 3), "unit": "Msamples/s",
@@ -354,7 +379,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "workload_key": wkey, "items_per_gpu": n_items, "demod": ["grad", "fft", "fft_compat"][args.demod],
-                       "bit_exact_vs_expected": verified, "parallelism": "streams sharded, dp%d; frame gather: 1 async all_gather per step" % world,
+                       "bit_exact_vs_expected": verified,
+                       "expected": ("frames the compiled reference (oracle/_ref, gradient demodulator) published on this IQ: tests/golden/fullsize_ref.json"
+                                    if ref_checked[0] else "payloads as sent"),
+                       "parallelism": "streams sharded, dp%d; frame gather: 1 async all_gather per step" % world,
                        "process_group": ("nccl (RCCL), world %d" % world) if use_dist else "none (single process)",
                        "pipeline_depth": depth, "path": "device (IQ resident in HBM)" + (", passes alternating between two HIP streams" if args.overlap else ""),
                        "source_hash": source_hash()},

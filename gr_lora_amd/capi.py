@@ -23,7 +23,7 @@ EXPORTS = [
     "lora_hip_get_geometry", "lora_hip_set_sf", "lora_hip_set_samp_rate", "lora_hip_work", "lora_hip_flush",
     "lora_hip_decode_device", "lora_hip_frames_available", "lora_hip_poll_frame", "lora_hip_drain_frames", "lora_hip_drain_slots", "lora_hip_demod_symbols_device", "lora_hip_demod_symbols_ex_device",
     "lora_hip_last_timing", "lora_hip_last_plan", "lora_hip_gap_starts_device", "lora_hip_decode_device_begin", "lora_hip_decode_device_end", "lora_hip_decode_device_prepass", "lora_hip_trace", "lora_hip_trace_clear", "lora_hip_check_frame", "lora_hip_estimate_cfo_device",
-    "lora_hip_set_stream_latency", "lora_hip_stream_info",
+    "lora_hip_set_stream_latency", "lora_hip_stream_info", "lora_hip_walker_kernel_name",
 ]
 
 
@@ -134,6 +134,8 @@ def load():
     L.lora_hip_trace_clear.restype = None
     L.lora_hip_estimate_cfo_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_int64), C.c_size_t, C.c_int, C.POINTER(C.c_float), vp]
     L.lora_hip_estimate_cfo_device.restype = C.c_int
+    L.lora_hip_walker_kernel_name.argtypes = [vp]
+    L.lora_hip_walker_kernel_name.restype = C.c_char_p
     L.lora_hip_set_stream_latency.argtypes = [vp, C.c_float]
     L.lora_hip_stream_info.argtypes = [vp, C.POINTER(StreamInfo)]
     L.lora_hip_check_frame.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(FrameCheck)]
@@ -205,6 +207,10 @@ class Handle:
 
     def flush(self):
         self._check(self.L.lora_hip_flush(self.h))
+
+    def kernel_name(self) -> str:
+        """lora_hip_walker_kernel_name: the state-machine kernel this handle's passes launch."""
+        return self.L.lora_hip_walker_kernel_name(self.h).decode()
 
     def set_stream_latency(self, max_latency_ms: float):
         """lora_hip_set_stream_latency: wall-clock bound on how long a delivered sample waits for a device pass (0 = off)."""

@@ -142,6 +142,7 @@ int launch_envelope(const float2 *iq, const EnvStream *streams /* host table; fi
                     float *d_E, unsigned long long *d_bitmap /* one bit per block of E */, void *stream);
 
 int launch_walker(const DevParams &p, const LaunchCfg &c, void *stream);
+const char *walker_kernel_name(const DevParams &p);                        // the kernel launch_walker picks for this configuration
 int launch_demod_symbols(const DevParams &p, const float2 *iq, const int64_t *d_offsets, uint32_t n,
                          int demod, uint32_t *d_bins, int32_t *d_fine, float *scratch, void *stream);
 int launch_cfo(const DevParams &p, const float2 *iq, const int64_t *d_offsets, uint32_t n, int mode, float *d_out, void *stream); // N4: explicit CFO estimate

@@ -1234,6 +1234,8 @@ lora_hip_status lora_hip_last_plan(const lora_hip_decoder_t *h, uint32_t *burst_
     return LORA_HIP_OK;
 }
 
+const char *lora_hip_walker_kernel_name(const lora_hip_decoder_t *h) { return h ? walker_kernel_name(h->P) : ""; }
+
 lora_hip_status lora_hip_last_timing(const lora_hip_decoder_t *h, lora_hip_timing_t *t)
 {
     if (!h || !t) return LORA_HIP_ERR_ARG;

@@ -178,14 +178,16 @@ __device__ __forceinline__ void w2_end_step(W2State &S, const Job &job, const La
 // everything demodulate()/work() do once the bin is known (:506-529, :826-886); thread 0 only.
 // Returns true when the payload is complete: the caller must run the workgroup-wide finalisation.
 // WAVE: called by the whole (converged) control wavefront with identical arguments; the deinterleaver then uses the lanes.
+// do_demod = false: an implicit-header payload step whose energy fell under the threshold (:861-864) - no word, the packet ends.
 template <bool WAVE = false>
-__device__ __forceinline__ bool w2_post_symbol(const DevParams &P, W2State &S, Shared &sh, uint32_t bin_idx, bool is_first, uint32_t *wpk = nullptr)
+__device__ __forceinline__ bool w2_post_symbol(const DevParams &P, W2State &S, Shared &sh, uint32_t bin_idx, bool is_first, uint32_t *wpk = nullptr, bool do_demod = true)
 {
     const bool reduced = is_first || P.reduced_rate; // :495
+    bool block_done = false;
+    if (do_demod) {
     if (reduced) bin_idx = (uint32_t)lroundf((float)bin_idx / 4.0f) & (P.nbins_hdr - 1u); // :507-509 (% N/4, a power of two, of a value >= 0)
     const uint32_t word = bin_idx ^ (bin_idx >> 1u); // :512
     const uint32_t need = 4u + (is_first ? 4u : S.cr); // :521
-    bool block_done = false;
     if constexpr (WAVE) { // the block's words stay in a register: no LDS round trip per symbol
         const uint32_t sh8 = 8u * (S.n_words & 3u), ins = (word & 0xffu) << sh8, keep = ~(0xffu << sh8);
         if (S.n_words < 4u) wpk[0] = (wpk[0] & keep) | ins;
@@ -204,7 +206,12 @@ __device__ __forceinline__ bool w2_post_symbol(const DevParams &P, W2State &S, S
         S.n_words = 0;
         block_done = true;
     }
+    }
     if (is_first) {
+        if (block_done && P.implicit) { // :828-829: no header on air
+            S.payload_symbols = 1;
+            S.state = kDecodePayload;
+        } else
         if (block_done) { // decode(true) and header parse (:831-847)
             uint8_t hA[3], hB[3], h0[3] = {0, 0, 0};
             decode_header_bytes(sh, S.n_cw, 2, hA);
@@ -229,7 +236,7 @@ __device__ __forceinline__ bool w2_post_symbol(const DevParams &P, W2State &S, S
         }
         return false;
     }
-    if (block_done) S.payload_symbols -= (int32_t)(4u + S.cr); // :866-867
+    if (block_done && !P.implicit) S.payload_symbols -= (int32_t)(4u + S.cr); // :866-867
     if (S.payload_symbols <= 0) { // :870-881
         uint32_t n_bytes;
         if (S.cr >= 3u) n_bytes = (uint32_t)ceilf((float)S.n_cw * 4.0f / (4.0f + (float)S.cr)); // :658
@@ -476,7 +483,9 @@ __device__ __attribute__((noinline)) void w2_sync_closed_form(const float *f2, d
 }
 
 // ---- the kernel -----------------------------------------------------------------------------------------
-template <int SF, int WAVES>
+// GRAD: the reference's shipped demodulator (max_frequency_gradient_idx, :466-491, :499) in the decode rounds instead of the
+// dechirp + FFT: wave_demod_symbol_grad.  The FFT twiddle block is then not needed in LDS.
+template <int SF, int WAVES, bool GRAD>
 __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg &C)
 {
     constexpr int N = 1 << SF, SPS = 8 * N;
@@ -499,7 +508,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     constexpr uint32_t NV = (3u * SPS + 40u + 3u) & ~3u;
     float *ddl = vl + NV;
     v4f *tab4 = reinterpret_cast<v4f *>(ddl + SPS);
-    double *pre = reinterpret_cast<double *>(tab4 + WaveGeom<SF>::n_v4f); // SYNC: chunk prefix sums (2 x 256) + per-wavefront totals
+    double *pre = reinterpret_cast<double *>(tab4 + (GRAD ? 0u : WaveGeom<SF>::n_v4f)); // SYNC: chunk prefix sums (2 x 256) + per-wavefront totals
 
     const uint32_t jid = blockIdx.x;
     if (jid >= C.n_jobs) return;
@@ -530,7 +539,13 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
 #endif
 
     const uint32_t dbg_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime(), dbg_c0 = (uint32_t)(clock64() >> 6);
-    const WaveTabs FT = wave_tabs_to_lds<SF>(P, tab4, vl, kW2);
+    WaveTabs FT{};
+    if constexpr (GRAD) { // only the ifreq template
+        for (uint32_t i = threadIdx.x; i < 3u * sps + 40u; i += kW2) vl[i] = P.up_ifreq_v[i];
+        FT.v = vl;
+    } else {
+        FT = wave_tabs_to_lds<SF>(P, tab4, vl, kW2);
+    }
     walker_stagger(LORA_W2_STAGGER);
     for (uint32_t i = threadIdx.x; i < sps; i += kW2) ddl[i] = P.down_ifreq[i] - P.down_ifreq_avg;
 
@@ -552,7 +567,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         case kPause: pl.mode = kPlanPause; break;
         default:
             pl.mode = kPlanDecode; pl.n_win = kW2Win;
-            if (S.state == kDecodePayload) { // symbols left in the packet (:866-870)
+            if (S.state == kDecodePayload && !P.implicit) { // symbols left in the packet (:866-870); implicit: unknown until the energy drops
                 const int32_t rem = S.payload_symbols - (int32_t)S.n_words;
                 pl.n_win = rem < kW2Win ? (rem > 0 ? rem : 1) : kW2Win;
             }
@@ -879,8 +894,12 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 const bool dvalid = widx < dn && dwpos + 2 * (int64_t)sps <= n_items;
                 uint32_t ws = 0;
                 int32_t wfine = 0;
-                if (dvalid) wave_demod_symbol<SF, (SF == 7) || LORA_W2_EARLY_F_SF8>(P, FT, X + dwpos, ws, wfine);
-                if (lane == 0) { W.speci[plan_buf][widx][0] = dvalid ? (int32_t)ws : -1; W.speci[plan_buf][widx][1] = wfine; }
+                float wen = 0.0f;
+                if (dvalid) {
+                    if constexpr (GRAD) wave_demod_symbol_grad<SF>(P, FT.v, X + dwpos, P.implicit != 0u, ws, wfine, wen); // ws = bin_idx itself
+                    else wave_demod_symbol<SF, (SF == 7) || LORA_W2_EARLY_F_SF8>(P, FT, X + dwpos, ws, wfine, P.implicit != 0u ? &wen : nullptr);
+                }
+                if (lane == 0) { W.speci[plan_buf][widx][0] = dvalid ? (int32_t)ws : -1; W.speci[plan_buf][widx][1] = wfine; W.speci[plan_buf][widx][2] = __builtin_bit_cast(int32_t, wen); }
             }
         } else { // the whole control wavefront, uniformly (identical values in every lane); t0 does the stores
             bool predicted = true;
@@ -893,19 +912,27 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 const int rb = plan_buf ^ 1;
                 // lane w fetches worker w's result: one LDS round trip for the round instead of two per symbol
                 const int32_t my_s = lane < kW2Win ? W.speci[rb][lane][0] : -1, my_f = lane < kW2Win ? W.speci[rb][lane][1] : 0;
+                const int32_t my_e = (P.implicit != 0u && lane < kW2Win) ? W.speci[rb][lane][2] : 0;
                 for (int w = 0; w < kW2Win; w++) {
                     if (w > 0 && !w2_pre_step(L, job, rec_cap, sps)) break;
-                    const int32_t sw = __builtin_amdgcn_readlane(my_s, w), fw = __builtin_amdgcn_readlane(my_f, w);
+                    const int32_t sw = __builtin_amdgcn_readlane(my_s, w);
+                    int32_t fw = __builtin_amdgcn_readlane(my_f, w);
                     if (!(L.state == kDecodeHeader || L.state == kDecodePayload) || sw < 0) break;
                     const bool is_first = L.state == kDecodeHeader;
                     const int32_t st_w = L.state;
                     const uint32_t sres = (uint32_t)sw;
-                    const uint32_t bin_idx = (sres == 0u && P.demod_mode == 2u) ? 0u : (sres + (uint32_t)N - 1u) % (uint32_t)N;
-                    if (w2_post_symbol<true>(P, L, sh, bin_idx, is_first, wpk)) { // payload complete: finalise with all threads
-                        L.fin_pending = 1; L.fin_st = st_w; L.fin_consumed = (int32_t)sps + fw; L.fin_bin = (int32_t)bin_idx; L.fin_fine = fw;
+                    uint32_t bin_idx = GRAD ? sres : ((sres == 0u && P.demod_mode == 2u) ? 0u : (sres + (uint32_t)N - 1u) % (uint32_t)N);
+                    int32_t step_bin = (int32_t)bin_idx;
+                    bool do_demod = true;
+                    if (P.implicit != 0u && !is_first) { // determine_energy (:861-864, :368-375)
+                        const float ew = __builtin_bit_cast(float, __builtin_amdgcn_readlane(my_e, w));
+                        if (ew < L.energy_threshold) { L.payload_symbols = 0; L.payload_length = L.n_cw / 2u; do_demod = false; bin_idx = 0u; step_bin = -1; fw = 0; }
+                    }
+                    if (w2_post_symbol<true>(P, L, sh, bin_idx, is_first, wpk, do_demod)) { // payload complete: finalise with all threads
+                        L.fin_pending = 1; L.fin_st = st_w; L.fin_consumed = (int32_t)sps + fw; L.fin_bin = step_bin; L.fin_fine = fw;
                         break;
                     }
-                    w2_end_step(L, job, C, recs, trace, st_w, (int32_t)sps + fw, (int32_t)bin_idx, fw, 0.0f, t_start, t0);
+                    w2_end_step(L, job, C, recs, trace, st_w, (int32_t)sps + fw, step_bin, fw, 0.0f, t_start, t0);
                     if (L.done || fw != 0) break; // later windows started at the wrong sample
                 }
                 // is the round the workers are computing right now the true continuation?
@@ -917,7 +944,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             if (predicted) {
                 // the round in flight continues the packet; how much of the packet is left after it?
                 int32_t n_next = kW2Win;
-                if (L.state == kDecodePayload) {
+                if (L.state == kDecodePayload && !P.implicit) {
                     const int32_t rem = L.payload_symbols - (int32_t)L.n_words - dn;
                     n_next = rem < kW2Win ? (rem > 0 ? rem : 0) : kW2Win; // 0: nothing left to demodulate, only resolve
                 }
@@ -1004,15 +1031,24 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
 }
 
 constexpr int kW2WavesSf7 = LORA_W2_WAVES_SF7, kW2WavesSf8 = LORA_W2_WAVES_SF8;
-__global__ __launch_bounds__(64 * kW2WavesSf7, 4) void walker2_kernel_sf7(DevParams P, LaunchCfg C) { walker2_body<7, kW2WavesSf7>(P, C); }
-__global__ __launch_bounds__(64 * kW2WavesSf8, LORA_W2_EU_SF8) void walker2_kernel_sf8(DevParams P, LaunchCfg C) { walker2_body<8, kW2WavesSf8>(P, C); }
+__global__ __launch_bounds__(64 * kW2WavesSf7, 4) void walker2_kernel_sf7(DevParams P, LaunchCfg C) { walker2_body<7, kW2WavesSf7, false>(P, C); }
+__global__ __launch_bounds__(64 * kW2WavesSf8, LORA_W2_EU_SF8) void walker2_kernel_sf8(DevParams P, LaunchCfg C) { walker2_body<8, kW2WavesSf8, false>(P, C); }
+// the gradient demodulator (demod_mode 0, the reference's default): no FFT tables, fewer live registers
+#ifndef LORA_W2_EU_GRAD_SF7
+#define LORA_W2_EU_GRAD_SF7 4
+#endif
+#ifndef LORA_W2_EU_GRAD_SF8
+#define LORA_W2_EU_GRAD_SF8 4
+#endif
+__global__ __launch_bounds__(64 * kW2WavesSf7, LORA_W2_EU_GRAD_SF7) void walker2_kernel_sf7_grad(DevParams P, LaunchCfg C) { walker2_body<7, kW2WavesSf7, true>(P, C); }
+__global__ __launch_bounds__(64 * kW2WavesSf8, LORA_W2_EU_GRAD_SF8) void walker2_kernel_sf8_grad(DevParams P, LaunchCfg C) { walker2_body<8, kW2WavesSf8, true>(P, C); }
 
 static uint32_t walker2_threads(uint32_t sf) { return 64u * (uint32_t)(sf == 7u ? kW2WavesSf7 : kW2WavesSf8); }
 
-static uint32_t walker2_lds_bytes(uint32_t sf)
+static uint32_t walker2_lds_bytes(uint32_t sf, bool grad = false)
 {
     const uint32_t sps = 8u << sf;
     const uint32_t nv = (3u * sps + 40u + 3u) & ~3u;
     return (uint32_t)((sizeof(W2Shared) + 15) & ~(size_t)15) + (2u * sps + nv + sps) * (uint32_t)sizeof(float) +
-           wave_tables_floats(sf) * (uint32_t)sizeof(float) + (2u * 256u + 8u) * (uint32_t)sizeof(double);
+           (grad ? 0u : wave_tables_floats(sf) * (uint32_t)sizeof(float)) + (2u * 256u + 8u) * (uint32_t)sizeof(double);
 }

@@ -62,31 +62,42 @@
 #ifndef LORA_W3_REPLAY_STATS
 #define LORA_W3_REPLAY_STATS 1  // LORA_HIP_DEBUG accounting of thread 0's replay inside the decode rounds
 #endif
+#ifndef LORA_W3_T512_MASK
+#define LORA_W3_T512_MASK 0     // bit (SF - 9): that SF's kernels as 512-thread workgroups at a 256-register budget - every thread does the work of two
+                                // (2 / 2 / 2 / 4 sample chunks in pass 1, two units of passes 2 and 3): 8 wavefronts per CU instead of 16, no spills
+#endif
+#ifndef LORA_W3_EARLY_F_MASK
+#define LORA_W3_EARLY_F_MASK 0  // bit 3: SF12 keeps fine_sync's ifreq from pass 1 (needs the T512 register budget)
+#endif
 #ifndef LORA_W3_STAGGER
 #define LORA_W3_STAGGER 0       // start-up stagger between workgroups, shader clocks per step (measured: no gain)
 #endif
 
 template <int SF> struct W3Geom {
     static constexpr int N = 1 << SF, SPS = 8 * N;
-    static constexpr int T = 1024;                      // threads per workgroup (16 wavefronts, one workgroup per CU)
-    static constexpr int TG = SF >= 11 ? 1024 : N / 2;  // threads of one group = one symbol window
-    static constexpr int NG = T / TG;                   // groups: windows evaluated per round (SF9: 4, SF10: 2, SF11/12: 1)
+    static constexpr bool T512 = (LORA_W3_T512_MASK >> (SF - 9)) & 1;
+    static constexpr int T = T512 ? 512 : 1024;         // threads per workgroup (16 or 8 wavefronts, one workgroup per CU)
+    static constexpr int NG = SF == 9 ? 4 : SF == 10 ? 2 : 1; // groups: windows evaluated per round
+    static constexpr int TG = T / NG;                   // threads of one group = one symbol window
+    static constexpr int VT = SF >= 11 ? 1024 : N / 2;  // "virtual threads" of a group: the units of passes 2 and 3 (what TG is at T = 1024)
+    static constexpr int U = VT / TG;                   // units per thread in passes 2 and 3 (1; T512: 2)
     static constexpr int GW = TG / 64;                  // wavefronts per group
-    static constexpr int PAIRS = SPS / (16 * TG);       // (q0, r) pairs per thread: 1; SF12: 2
-    static constexpr int ROUNDS = PAIRS;                // passes over the rows of pass 1
+    static constexpr int PAIRS = SPS / (16 * TG);       // (q0, r) pairs per thread in pass 1: 1; SF12: 2; T512: 2 / 2 / 2 / 4
+    static constexpr int ROUNDS = SF == 12 ? 2 : 1;     // passes over the rows of pass 1 (SF12: a symbol is 256 KB against 160 KB of LDS)
     static constexpr int AR = 16 / ROUNDS;              // rows resident in LDS per round
     static constexpr int M = N / 16, M2 = M / 16, LOGM2 = ilog2(M2);
     static constexpr int SA = 8 * M + 8;                // entries per row
     static constexpr int NTW = N > 2048 ? N / 2 : N;    // W_N^t entries kept in LDS (SF12: half, the rest by sign)
     static constexpr int CH = SPS / 16;                 // samples between a thread's consecutive loads
-    static constexpr int NWL = TG / (8 * AR), NB = 16 / NWL; // pass 3: butterflies per thread
+    static constexpr int NWL = VT / (8 * AR), NB = 16 / NWL; // pass 3: butterflies per unit
     static constexpr int LEN = SPS / T;                 // SYNC: shifts per thread (all groups together)
-    static constexpr bool LATE_F = PAIRS > 1 || ((LORA_W3_LATE_F_MASK >> (SF - 9)) & 1); // fine_sync's ifreq from a second read of the window (SF12)
+    static constexpr bool LATE_F = (SF == 12 && !((LORA_W3_EARLY_F_MASK >> 3) & 1)) || ((LORA_W3_LATE_F_MASK >> (SF - 9)) & 1); // fine_sync's ifreq from a second read of the window (SF12: 64 more live registers otherwise)
     static constexpr bool UNIFORM_JOB = (LORA_W3_UJ_MASK >> (SF - 9)) & 1;  // the job record through readfirstlane (uniform_job)
     static constexpr bool FAST_MOD = (LORA_W3_MOD_MASK >> (SF - 9)) & 1;    // power-of-two reductions of the replay as masks
     static constexpr uint32_t data_entries = (uint32_t)AR * SA; // per group
-    static_assert(NB * M2 == 16, "pass 3 covers 16 values per thread");
-    static_assert(AR * M2 * 8 == TG, "pass 2 uses every thread of the group once per round");
+    static_assert(NB * M2 == 16, "pass 3 covers 16 values per unit");
+    static_assert(AR * M2 * 8 == VT, "pass 2 uses every unit of the group once per round");
+    static_assert(U * TG == VT && U == PAIRS / (SF == 12 ? 2 : 1) && TG % 64 == 0, "geometry");
 };
 
 struct alignas(16) W3Shared {
@@ -339,7 +350,7 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
 #define LORA_W3STAMP(i) do { if (stamps) stamps[i] = clock64(); } while (0)
     LORA_W3STAMP(0);
     using G = W3Geom<SF>;
-    constexpr int N = G::N, SPS = G::SPS, TG = G::TG, CH = G::CH, M2 = G::M2, AR = G::AR, SA = G::SA, PAIRS = G::PAIRS, ROUNDS = G::ROUNDS, NG = G::NG;
+    constexpr int N = G::N, SPS = G::SPS, TG = G::TG, CH = G::CH, M2 = G::M2, AR = G::AR, SA = G::SA, PAIRS = G::PAIRS, ROUNDS = G::ROUNDS, NG = G::NG, VT = G::VT, U = G::U;
     int tt = threadIdx.x;
     asm volatile("" : "+v"(tt)); // keeps per-thread table addresses out of the caller's loop-invariant set
     const int grp = __builtin_amdgcn_readfirstlane(tt / TG), t = tt % TG;
@@ -350,7 +361,7 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
     v2f *data = L.data + (size_t)grp * G::data_entries;
     const uint32_t tu = (uint32_t)t;
 
-    float f[G::LATE_F ? 1 : 16]; // ifreq[n - 1] of this thread's samples (kept from pass 1 unless LATE_F)
+    float f[G::LATE_F ? 1 : PAIRS][16]; // ifreq[n - 1] of this thread's samples (kept from pass 1 unless LATE_F)
     v2f hold[ROUNDS > 1 ? PAIRS : 1][8]; // SF12: rows 8..15 of pass 1 wait here for round 1
     float en = 0.0f;
 
@@ -380,7 +391,7 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
                         v2f ap[8];
 #pragma unroll
                         for (int c = 0; c < 8; c++)
-                            ap[c] = (h == 0 && c == 0) ? w3_ld2(xb, ob >= 8u ? ob - 8u : 0u, 0u) : w3_ld2(xb, ob, (uint32_t)((8 * h + c) * CH * 8 - 8));
+                            ap[c] = (h == 0 && c == 0) ? w3_ld2(xb, (p == 0) ? (ob >= 8u ? ob - 8u : 0u) : ob - 8u, 0u) : w3_ld2(xb, ob, (uint32_t)((8 * h + c) * CH * 8 - 8));
 #pragma unroll
                         for (int c = 0; c < 8; c += 4) {
                             const int q = 8 * h + c;
@@ -394,8 +405,8 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
 #else
                             w3_atan2_x4(im0, re0, im1, re1, o0, o1);
 #endif
-                            f[q] = (q == 0 && t == 0) ? 0.0f : o0.x; // n = 0 has no predecessor in the window
-                            f[q + 1] = o0.y; f[q + 2] = o1.x; f[q + 3] = o1.y;
+                            f[G::LATE_F ? 0 : p][q] = (p == 0 && q == 0 && t == 0) ? 0.0f : o0.x; // n = 0 has no predecessor in the window
+                            f[G::LATE_F ? 0 : p][q + 1] = o0.y; f[G::LATE_F ? 0 : p][q + 2] = o1.x; f[G::LATE_F ? 0 : p][q + 3] = o1.y;
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -450,7 +461,10 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
         if (g == 0) LORA_W3STAMP(2);
         // ---- pass 2 (in place) ----
         if (valid) {
-            const int row = (t >> 3) % AR, q1 = __builtin_amdgcn_readfirstlane(t / (8 * AR)); // (8 AR >= 64: the same in all lanes)
+#pragma unroll
+            for (int u = 0; u < U; u++) { // (unit vt of the group: what thread vt does at one unit per thread)
+            const int vt = t + u * TG;
+            const int row = (vt >> 3) % AR, q1 = __builtin_amdgcn_readfirstlane(vt / (8 * AR)); // (8 AR >= 64: the same in all lanes)
             v2f *pe = data + row * SA + q1 * 8 + r;
             v2f a[16];
 #pragma unroll
@@ -467,16 +481,20 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
             }
 #pragma unroll
             for (int m = 0; m < 16; m++) pe[M2 * 8 * m] = a[m];
+            }
         }
         if (g == 0) LORA_W3STAMP(3);
         __syncthreads();
         if (g == 0) LORA_W3STAMP(4);
         // ---- pass 3 + combine ----
         if (valid) {
-            const int w = t >> 3, row = w % AR, wl = w / AR;
-            v2f out[16]; // the combine coefficients first (pass-3 thread order; requesting them before pass 2 costs more in registers than the latency it hides)
 #pragma unroll
-            for (int i = 0; i < 16; i++) out[i] = w3_ld2(cb, 8u * tu, (uint32_t)((g * 16 + i) * TG * 8));
+            for (int u = 0; u < U; u++) {
+            const int vt = t + u * TG;
+            const int w = vt >> 3, row = w % AR, wl = w / AR;
+            v2f out[16]; // the combine coefficients first (pass-3 unit order; requesting them before pass 2 costs more in registers than the latency it hides)
+#pragma unroll
+            for (int i = 0; i < 16; i++) out[i] = w3_ld2(cb, 8u * (uint32_t)vt, (uint32_t)((g * 16 + i) * VT * 8));
 #pragma unroll
             for (int j = 0; j < G::NB; j++) {
                 const int m2 = wl * G::NB + j;
@@ -512,6 +530,7 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
             const bool better = mx > bv || (mx == bv && k1 < bi);
             bv = better ? mx : bv;
             bi = better ? k1 : bi;
+            }
         }
     }
     LORA_W3STAMP(5);
@@ -562,11 +581,11 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
             }
 #pragma unroll
             for (int c = 0; c < 16; c++) {
-                const float fk = G::LATE_F ? fl[c] : f[G::LATE_F ? 0 : c];
+                const float fk = G::LATE_F ? fl[c] : f[G::LATE_F ? 0 : p][c];
                 cs[0] += fk * v0[c]; cs[1] += fk * v1[c]; cs[2] += fk * v2[c];
             }
             if (p == PAIRS - 1 && t == TG - 1) { // ifreq[sps-1] = ifreq[sps-2] (:243): the duplicated tap at k = sps-1
-                const float flast = G::LATE_F ? fl[15] : f[G::LATE_F ? 0 : 15];
+                const float flast = G::LATE_F ? fl[15] : f[G::LATE_F ? 0 : p][15];
                 const uint32_t ko = 4u * (uint32_t)(SPS - 1);
                 cs[0] += flast * w3_ld1(vb, ko, 0u); cs[1] += flast * w3_ld1(vb, ko, 4u); cs[2] += flast * w3_ld1(vb, ko, 8u);
             }
@@ -577,6 +596,142 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
     w3_group_sums<SF, 3>(cs, ws, slot, grp, gwave, co, all);
     LORA_W3STAMP(8);
 #undef LORA_W3STAMP
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        float mx = 0.0f;
+        int32_t lag = 0;
+        if (co[g][0] > mx) { mx = co[g][0]; lag = -1; }
+        if (co[g][1] > mx) { mx = co[g][1]; lag = 0; }
+        if (co[g][2] > mx) { mx = co[g][2]; lag = 1; }
+        fine_out[g] = __builtin_amdgcn_readfirstlane(-lag);
+    }
+}
+
+// ---- the reference's SHIPPED demodulator, one window per group: max_frequency_gradient_idx (:466-491) + fine_sync -------
+// No FFT and no LDS array: thread t of the group owns the samples n = c CH + p TG + t as in pass 1 above and computes
+// f = ifreq[n] = arg(x[n+1] conj(x[n])) (successors by a second buffer load one item up: the same cache lines;
+// ifreq[sps-1] = ifreq[sps-2], :243).  The eight samples of bin i = n >> 3 sit in eight adjacent lanes: the bin average
+// (volk_32f_accumulator_s32f / D, :475-476) is three DPP adds, its left neighbour one lane permute - across wavefront and
+// chunk boundaries through a small LDS array (one value per wavefront, chunk and pair) - and the largest drop above 0.1
+// (:479-488) a first-maximum reduction over the group.  s_out[g] is demodulate()'s bin_idx itself.
+template <int SF>
+__device__ __forceinline__ void w3_demod_round_grad(const W3DemodArgs &P, const W3Lds<SF> &L, const float2 *__restrict__ x, bool valid, bool want_energy, int &slot,
+                                                    uint32_t (&s_out)[W3Geom<SF>::NG], int32_t (&fine_out)[W3Geom<SF>::NG], float (&en_out)[W3Geom<SF>::NG])
+{
+    using G = W3Geom<SF>;
+    constexpr int N = G::N, SPS = G::SPS, TG = G::TG, CH = G::CH, PAIRS = G::PAIRS, NG = G::NG, GW = G::GW;
+    int tt = threadIdx.x;
+    asm volatile("" : "+v"(tt));
+    const int grp = __builtin_amdgcn_readfirstlane(tt / TG), t = tt % TG;
+    const int lane = t & 63, gwave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const bool want_fine = P.enable_fine_sync != 0u;
+    const w3_buf_t xb = w3_buf(w3_uniform_ptr(x));
+    W3Shared &ws = *L.ws;
+    float *edge = reinterpret_cast<float *>(L.data + (size_t)grp * G::data_entries); // [(p 16 + c) GW + wave]: the last bin of every wavefront
+    const uint32_t tu = (uint32_t)t;
+
+    float f[PAIRS][16], A[PAIRS][16];
+    float en = 0.0f;
+    if (valid) {
+#pragma unroll
+        for (int p = 0; p < PAIRS; p++) {
+            const uint32_t ob = 8u * ((uint32_t)(p * TG) + tu);
+            v2f a[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) a[c] = w3_ld2(xb, ob, (uint32_t)(c * CH * 8));
+            if (want_energy) {
+#pragma unroll
+                for (int c = 0; c < 16; c++) en += a[c].x * a[c].x + a[c].y * a[c].y;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                v2f an[8]; // x[n + 1]
+#pragma unroll
+                for (int c = 0; c < 8; c++) an[c] = w3_ld2(xb, ob, (uint32_t)((8 * h + c) * CH * 8 + 8));
+#pragma unroll
+                for (int c = 0; c < 8; c += 4) {
+                    const int q = 8 * h + c;
+                    v2f im0, re0, im1, re1, o0, o1; // x[n+1] conj(x[n])
+                    im0 = (v2f){an[c].y * a[q].x - an[c].x * a[q].y, an[c + 1].y * a[q + 1].x - an[c + 1].x * a[q + 1].y};
+                    re0 = (v2f){an[c].x * a[q].x + an[c].y * a[q].y, an[c + 1].x * a[q + 1].x + an[c + 1].y * a[q + 1].y};
+                    im1 = (v2f){an[c + 2].y * a[q + 2].x - an[c + 2].x * a[q + 2].y, an[c + 3].y * a[q + 3].x - an[c + 3].x * a[q + 3].y};
+                    re1 = (v2f){an[c + 2].x * a[q + 2].x + an[c + 2].y * a[q + 2].y, an[c + 3].x * a[q + 3].x + an[c + 3].y * a[q + 3].y};
+                    w3_atan2_x4(im0, re0, im1, re1, o0, o1);
+                    f[p][q] = o0.x; f[p][q + 1] = o0.y; f[p][q + 2] = o1.x; f[p][q + 3] = o1.y;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        { // ifreq[sps-1] = ifreq[sps-2] (:243): the group's last thread takes its neighbour's value
+            const float dup = dpp_f<kDppWaveRor1>(f[PAIRS - 1][15]);
+            f[PAIRS - 1][15] = (t == TG - 1) ? dup : f[PAIRS - 1][15];
+        }
+#pragma unroll
+        for (int p = 0; p < PAIRS; p++)
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                float v = f[p][c];
+                v += dpp_f<kDppQuadXor1>(v); v += dpp_f<kDppQuadXor2>(v); v += dpp_f<kDppRowHalfMirror>(v); // the 8 samples of the bin (:475)
+                A[p][c] = v * 0.125f; // / d_decim_factor (:476)
+                if (lane == 63) edge[(p * 16 + c) * GW + gwave] = A[p][c];
+            }
+    }
+    __syncthreads();
+    float bv = 0.1f; // max_gradient = 0.1f (:479)
+    int bi = 0x7fffffff;
+    if (valid) {
+        const int perm_addr = ((lane - 8) & 63) << 2;
+#pragma unroll
+        for (int c = 0; c < 16; c++)
+#pragma unroll
+            for (int p = 0; p < PAIRS; p++) { // (c, p) ascending = bin index ascending
+                const float perm = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm_addr, __builtin_bit_cast(int, A[p][c])));
+                float left = perm;
+                if (lane < 8) { // the bin to the left lives in the previous wavefront / pair / chunk
+                    const int pp = (gwave > 0) ? p : (p > 0 ? p - 1 : PAIRS - 1), cc = (gwave > 0 || p > 0) ? c : c - 1;
+                    const int ww = (gwave > 0) ? gwave - 1 : GW - 1;
+                    left = (cc >= 0) ? edge[(pp * 16 + cc) * GW + ww] : 0.0f;
+                }
+                const float g = left - A[p][c]; // samples_ifreq_avg[i - 1] - samples_ifreq_avg[i] (:482)
+                const int i = (c * CH + p * TG + t) >> 3;
+                if (i >= 1 && g > bv) { bv = g; bi = i; } // strict '>' and ascending i: the first maximum
+            }
+    }
+    const bool all = grp == 0 && gwave == 0;
+    float bvs[NG];
+    int bis[NG];
+    w3_group_argmax_first<SF>(bv, bi, ws, slot, grp, gwave, bvs, bis, all);
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        const uint32_t max_index = (bis[g] == 0x7fffffff) ? 0u : (uint32_t)bis[g] + 1u; // :486
+        s_out[g] = ((uint32_t)N - max_index) % (uint32_t)N;                              // :490
+        fine_out[g] = 0; en_out[g] = 0.0f;
+    }
+    if (want_energy) {
+        float e1[1] = {en}, eo[NG][1];
+        w3_group_sums<SF, 1>(e1, ws, slot, grp, gwave, eo, all);
+#pragma unroll
+        for (int g = 0; g < NG; g++) en_out[g] = eo[g][0];
+    }
+    if (!want_fine) return;
+    float cs[3] = {0.f, 0.f, 0.f};
+    if (valid) { // fine_sync (:300-338), lags -1, 0, +1: c_lag = sum_k f[k] v[(bin_idx + 1) 8 + sps + lag + k]
+        uint32_t bin_idx = s_out[0];
+#pragma unroll
+        for (int g = 1; g < NG; g++) bin_idx = (grp == g) ? s_out[g] : bin_idx;
+        const w3_buf_t vb = w3_buf(w3_uniform_ptr(P.up_ifreq_v + ((int)(bin_idx + 1u) * 8 + SPS - 1))); // origin one element early: lag -1 at k = 0
+#pragma unroll
+        for (int p = 0; p < PAIRS; p++) {
+            const uint32_t nb = 4u * ((uint32_t)(p * TG) + tu);
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                const float v0 = w3_ld1(vb, nb, (uint32_t)(c * CH * 4)), v1 = w3_ld1(vb, nb, (uint32_t)(c * CH * 4 + 4)), v2 = w3_ld1(vb, nb, (uint32_t)(c * CH * 4 + 8));
+                cs[0] += f[p][c] * v0; cs[1] += f[p][c] * v1; cs[2] += f[p][c] * v2;
+            }
+        }
+    }
+    float co[NG][3];
+    w3_group_sums<SF, 3>(cs, ws, slot, grp, gwave, co, all);
 #pragma unroll
     for (int g = 0; g < NG; g++) {
         float mx = 0.0f;
@@ -913,7 +1068,7 @@ __device__ __forceinline__ bool w3_post_symbol(const DevParams &P, W2State &S, S
 // runs at the HBM limit (~11 B/clk/CU) while the rest of the round moves nothing; touched a round ahead, the lines come from L2 /
 // MALL instead.  The value must stay live until the data has landed (the caller consumes it at the top of the next round).
 template <int SF>
-__device__ __forceinline__ void w3_touch(const float2 *X, int64_t first_item, int64_t fallback_item, int64_t n_items, float (&v)[2])
+__device__ __forceinline__ void w3_touch(const float2 *X, int64_t first_item, int64_t fallback_item, int64_t n_items, float (&v)[4])
 {
     using G = W3Geom<SF>;
     // (always a load - past the end of the stream it re-reads the current window - and nothing done to the value: any use,
@@ -933,7 +1088,7 @@ __device__ __forceinline__ void w3_touch(const float2 *X, int64_t first_item, in
 // outcome that invalidates the later windows (a trigger, a state change, d_fine_sync != 0, a loop-top check, the end of
 // the data); it then writes the state back and the next plan.  The accepted sequence is exactly the serial one.  Keeping
 // the state out of the other wavefronts' registers is what lets the demodulator run without spills.
-template <int SF>
+template <int SF, bool GRAD>
 __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg &C)
 {
     using G = W3Geom<SF>;
@@ -994,11 +1149,11 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
         plan_from(S, ws.plan[0]);
     }
 
-    float touched[2] = {0.0f, 0.0f};
+    float touched[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     for (uint32_t it = 0;; it++) {
         __syncthreads(); // plan[it & 1] and everything thread 0 wrote are visible; plan[(it + 1) & 1] is free
 #if LORA_W3_PREFETCH
-        asm volatile("" :: "v"(touched[0]), "v"(touched[1])); // the previous round's touch has landed by the time this round's loads are waited for
+        asm volatile("" :: "v"(touched[0]), "v"(touched[1]), "v"(touched[2]), "v"(touched[3])); // the previous round's touch has landed by the time this round's loads are waited for
 #endif
         const W2Plan &pl_in = ws.plan[it & 1u];
         const uint64_t pl_pp = (uint64_t)pl_in.pos;
@@ -1149,7 +1304,8 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
             uint32_t sq[NG];
             int32_t fq[NG];
             float eq[NG];
-            w3_demod_round<SF>(DA, L, xg, dvalid, P.implicit != 0u, slot, sq, fq, eq);
+            if constexpr (GRAD) w3_demod_round_grad<SF>(DA, L, xg, dvalid, P.implicit != 0u, slot, sq, fq, eq); // sq = bin_idx itself
+            else w3_demod_round<SF>(DA, L, xg, dvalid, P.implicit != 0u, slot, sq, fq, eq);
 #if LORA_W3_PREFETCH & 1
             w3_touch<SF>(X, gpos + (int64_t)NG * sps, gvalid ? gpos : pos, n_items, touched);
 #endif
@@ -1178,7 +1334,8 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                     for (int g = 0; g < NG; g++) {
                         const uint32_t sg = sq[g];
                         uint32_t bin_idx;
-                        if constexpr (G::FAST_MOD) bin_idx = (sg == 0u && P.demod_mode == 2u) ? 0u : (sg + (uint32_t)G::N - 1u) % (uint32_t)G::N;
+                        if constexpr (GRAD) bin_idx = sg;
+                        else if constexpr (G::FAST_MOD) bin_idx = (sg == 0u && P.demod_mode == 2u) ? 0u : (sg + (uint32_t)G::N - 1u) % (uint32_t)G::N;
                         else bin_idx = (sg == 0u && P.demod_mode == 2u) ? 0u : (sg + P.nbins - 1u) % P.nbins;
                         if (w3_post_symbol<G::FAST_MOD>(P, St, sh, true, bin_idx, false)) { // payload complete
                             St.fin_pending = 1; St.fin_st = kDecodePayload; St.fin_consumed = (int32_t)sps; St.fin_bin = (int32_t)bin_idx; St.fin_fine = 0;
@@ -1203,7 +1360,8 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                     uint32_t bin_idx = 0;
                     int32_t fine = 0, step_bin = -1;
                     if (do_demod) { // :500, bin_idx = (s-1) mod N; compat keeps the s==0 -> 0 quirk of the gradient path
-                        if constexpr (G::FAST_MOD) bin_idx = (sg == 0u && P.demod_mode == 2u) ? 0u : (sg + (uint32_t)G::N - 1u) % (uint32_t)G::N;
+                        if constexpr (GRAD) bin_idx = sg;
+                        else if constexpr (G::FAST_MOD) bin_idx = (sg == 0u && P.demod_mode == 2u) ? 0u : (sg + (uint32_t)G::N - 1u) % (uint32_t)G::N;
                         else bin_idx = (sg == 0u && P.demod_mode == 2u) ? 0u : (sg + P.nbins - 1u) % P.nbins;
                         step_bin = (int32_t)bin_idx;
                         fine = fg; // :501-502
@@ -1290,14 +1448,19 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
     } // phase
 }
 
-__global__ __launch_bounds__(1024, 4) void walker3_kernel_sf9(DevParams P, LaunchCfg C) { walker3_body<9>(P, C); }
-__global__ __launch_bounds__(1024, 4) void walker3_kernel_sf10(DevParams P, LaunchCfg C) { walker3_body<10>(P, C); }
-__global__ __launch_bounds__(1024, 4) void walker3_kernel_sf11(DevParams P, LaunchCfg C) { walker3_body<11>(P, C); }
-__global__ __launch_bounds__(1024, 4) void walker3_kernel_sf12(DevParams P, LaunchCfg C) { walker3_body<12>(P, C); }
+__global__ __launch_bounds__(W3Geom<9>::T, W3Geom<9>::T512 ? 2 : 4) void walker3_kernel_sf9(DevParams P, LaunchCfg C) { walker3_body<9, false>(P, C); }
+__global__ __launch_bounds__(W3Geom<10>::T, W3Geom<10>::T512 ? 2 : 4) void walker3_kernel_sf10(DevParams P, LaunchCfg C) { walker3_body<10, false>(P, C); }
+__global__ __launch_bounds__(W3Geom<11>::T, W3Geom<11>::T512 ? 2 : 4) void walker3_kernel_sf11(DevParams P, LaunchCfg C) { walker3_body<11, false>(P, C); }
+__global__ __launch_bounds__(W3Geom<12>::T, W3Geom<12>::T512 ? 2 : 4) void walker3_kernel_sf12(DevParams P, LaunchCfg C) { walker3_body<12, false>(P, C); }
+// demod_mode 0: the gradient demodulator (the reference's shipped default, :499) in the decode rounds
+__global__ __launch_bounds__(W3Geom<9>::T, W3Geom<9>::T512 ? 2 : 4) void walker3_kernel_sf9_grad(DevParams P, LaunchCfg C) { walker3_body<9, true>(P, C); }
+__global__ __launch_bounds__(W3Geom<10>::T, W3Geom<10>::T512 ? 2 : 4) void walker3_kernel_sf10_grad(DevParams P, LaunchCfg C) { walker3_body<10, true>(P, C); }
+__global__ __launch_bounds__(W3Geom<11>::T, W3Geom<11>::T512 ? 2 : 4) void walker3_kernel_sf11_grad(DevParams P, LaunchCfg C) { walker3_body<11, true>(P, C); }
+__global__ __launch_bounds__(W3Geom<12>::T, W3Geom<12>::T512 ? 2 : 4) void walker3_kernel_sf12_grad(DevParams P, LaunchCfg C) { walker3_body<12, true>(P, C); }
 
 // ---- symbol-level kernel: one group per symbol, for lora_hip_demod_symbols_device ------------------------------
-template <int SF>
-__global__ __launch_bounds__(1024, 4) void demod_symbols_w3_kernel(DevParams P, const float2 *iq, const int64_t *offsets, uint32_t n,
+template <int SF, bool GRAD>
+__global__ __launch_bounds__(W3Geom<SF>::T, W3Geom<SF>::T512 ? 2 : 4) void demod_symbols_w3_kernel(DevParams P, const float2 *iq, const int64_t *offsets, uint32_t n,
                                                                     uint32_t *bins, int32_t *fine, long long *stamps_out)
 {
     using G = W3Geom<SF>;
@@ -1313,7 +1476,8 @@ __global__ __launch_bounds__(1024, 4) void demod_symbols_w3_kernel(DevParams P, 
         int32_t fs[G::NG];
         float en[G::NG];
         long long stamps[9];
-        w3_demod_round<SF>(W3DemodArgs{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode}, L, iq + offsets[valid ? s0 + grp : s0], valid, false, slot, b, fs, en,
+        if constexpr (GRAD) w3_demod_round_grad<SF>(W3DemodArgs{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode}, L, iq + offsets[valid ? s0 + grp : s0], valid, false, slot, b, fs, en);
+        else w3_demod_round<SF>(W3DemodArgs{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode}, L, iq + offsets[valid ? s0 + grp : s0], valid, false, slot, b, fs, en,
                            stamps_out ? stamps : nullptr);
         if (stamps_out && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && s0 == blockIdx.x * G::NG + gridDim.x * G::NG) // (second round of block 0: every wavefront's stamps)
             for (int i = 0; i < 9; i++) stamps_out[(threadIdx.x >> 6) * 9 + i] = stamps[i];
@@ -1332,7 +1496,7 @@ template <int SF>
 static void build_w3_tables_sf(float2 *tw, float2 *ctab)
 {
     using G = W3Geom<SF>;
-    constexpr int N = G::N, SPS = G::SPS, T = G::TG;
+    constexpr int N = G::N, SPS = G::SPS, T = G::VT;
     for (int t = 0; t < G::NTW; t++) {
         const double a = -2.0 * M_PI * (double)t / (double)N;
         tw[t] = make_float2((float)std::cos(a), (float)std::sin(a));
@@ -1370,6 +1534,6 @@ void build_w3_tables(uint32_t sf, float2 *tw, float2 *ctab /* sps entries */)
     else if (sf == 12u) build_w3_tables_sf<12>(tw, ctab);
 }
 
-static uint32_t walker3_threads(uint32_t) { return 1024u; }
+static uint32_t walker3_threads(uint32_t sf) { return (uint32_t)(sf == 9u ? W3Geom<9>::T : sf == 10u ? W3Geom<10>::T : sf == 11u ? W3Geom<11>::T : W3Geom<12>::T); }
 static uint32_t walker3_groups(uint32_t sf) { return sf == 9u ? W3Geom<9>::NG : sf == 10u ? W3Geom<10>::NG : 1u; }
 static uint32_t walker3_lds(uint32_t sf) { return sf == 9u ? w3_lds_bytes<9>() : sf == 10u ? w3_lds_bytes<10>() : sf == 11u ? w3_lds_bytes<11>() : w3_lds_bytes<12>(); }

@@ -40,7 +40,9 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int kDppQuadXor1 = 0xB1, kDppQuadXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140, kDppRor8 = 0x128,
               kDppBcast15 = 0x142, kDppBcast31 = 0x143,
-              kDppWaveRor1 = 0x13C; // lane i reads lane i - 1, lane 0 reads lane 63 (GFX9 wavefront rotate)
+              kDppWaveRor1 = 0x13C, // lane i reads lane i - 1, lane 0 reads lane 63 (GFX9 wavefront rotate)
+              kDppWaveRol1 = 0x134, // lane i reads lane i + 1, lane 63 reads lane 0
+              kDppRowHalfMirror = 0x141;
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v)
@@ -222,6 +224,7 @@ __device__ __forceinline__ v2f ifreq_prod_pk(v2f p0, v2f c0, v2f p1, v2f c1)
 // fine_sync(bin_idx, 2) (0 when drift correction is disabled).  Must be called by a whole wavefront.
 template <int SF, bool EARLY_F>
 __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const WaveTabs &T, const float2 *__restrict__ x, uint32_t &s_out, int32_t &fine_out,
+                                                  float *en_out = nullptr /* implicit header: the window's energy (determine_energy, :368-375) */,
                                                   long long *stamps = nullptr /* tools/probe_phases.hip */)
 {
 #define LORA_WSTAMP(i) do { if (stamps) stamps[i] = clock64(); } while (0)
@@ -246,6 +249,12 @@ __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const Wave
 #pragma unroll
     for (int j = 0; j < J; j++) a[j] = xv[j * 64 + nl];
 #endif
+    if (en_out) { // (a uniform branch: only implicit-header decoders ask)
+        v2f e2 = (v2f){0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < J; j++) e2 = __builtin_elementwise_fma(a[j], a[j], e2);
+        *en_out = wave_sum_u(e2.x + e2.y);
+    }
     if (EARLY_F && want_fine) {
         // sample n - 1 of this lane's n = 64 j + lane sits in the neighbouring lane (lane 0: lane 63 of the previous
         // register): one wave rotate per register instead of a second, dependent round of loads.  (A second batch of
@@ -391,6 +400,94 @@ __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const Wave
 #undef LORA_WSTAMP
 }
 
+// ---- the reference's SHIPPED demodulator on one wavefront: max_frequency_gradient_idx (:466-491) + fine_sync (:300-338) ----
+// No FFT at all: the window's instantaneous frequency (which fine_sync needs anyway) is averaged over the D = 8 samples of
+// every bin (volk_32f_accumulator_s32f, :475-476) and the largest drop between neighbouring averages above 0.1 marks the
+// symbol boundary (:479-488).  Lane l owns n = 64 j + l as above; here f[j] = ifreq[n] = arg(x[n+1] conj(x[n])) - the successor
+// by a wave rotate, lane 63 from the next register - so that the eight samples of bin i = 8 j + (l >> 3) sit in one aligned
+// group of eight lanes of register j: the bin average is three v_add with a DPP operand, its left neighbour one lane permute.
+// ifreq[sps-1] = ifreq[sps-2] (:243).  bin_out is demodulate()'s bin_idx itself (the FFT path's (s - 1) mod N); en_out the
+// window's energy (determine_energy, :368-375) when want_energy.
+template <int SF>
+__device__ __forceinline__ void wave_demod_symbol_grad(const DevParams &P, const float *__restrict__ Tv, const float2 *__restrict__ x, bool want_energy,
+                                                       uint32_t &bin_out, int32_t &fine_out, float &en_out)
+{
+    using G = WaveGeom<SF>;
+    constexpr int N = G::N, J = G::J, SPS = G::SPS;
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane)); // (as in wave_demod_symbol: keeps per-lane addresses out of the caller's loop-invariant set)
+    const auto xv = (const __attribute__((address_space(1))) v2f *)x;
+    v2f a[J];
+#pragma unroll
+    for (int j = 0; j < J; j++) a[j] = xv[j * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0); // all loads issued before the first use
+    en_out = 0.0f;
+    if (want_energy) {
+        v2f e2 = (v2f){0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < J; j++) e2 = __builtin_elementwise_fma(a[j], a[j], e2);
+        en_out = wave_sum_u(e2.x + e2.y);
+    }
+    float f[J];
+    {
+        v2f cn = dpp2<kDppWaveRol1>(a[0]); // a[j] of lane + 1 (lane 63: of lane 0)
+#pragma unroll
+        for (int j = 0; j < J; j += 2) {
+            const v2f c0 = cn, c1 = dpp2<kDppWaveRol1>(a[j + 1]);
+            const v2f c2 = (j + 2 < J) ? dpp2<kDppWaveRol1>(a[j + 2]) : c1;
+            cn = c2;
+            // x[n + 1]: the neighbouring lane's sample of the same register; for lane 63 lane 0's sample of the NEXT register
+            const v2f s0 = (lane == 63) ? c1 : c0, s1 = (lane == 63) ? c2 : c1;
+            const v2f fp = ifreq_prod_pk(a[j], s0, a[j + 1], s1);
+            f[j] = fp.x; f[j + 1] = fp.y;
+        }
+        const float dup = dpp_f<kDppWaveRor1>(f[J - 1]); // ifreq[sps-1] = ifreq[sps-2] (:243)
+        f[J - 1] = (lane == 63) ? dup : f[J - 1];
+    }
+    // bin averages (:474-477) and the largest drop (:479-488)
+    float bv = 0.1f; // max_gradient = 0.1f
+    int bi = 0x7fffffff;
+    {
+        const int m = lane >> 3;
+        const int perm_addr = ((lane - 8) & 63) << 2;
+        float prev_perm = 0.0f;
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            float A = f[j];
+            A += dpp_f<kDppQuadXor1>(A); A += dpp_f<kDppQuadXor2>(A); A += dpp_f<kDppRowHalfMirror>(A); // sum over the 8 lanes of the bin
+            A *= 0.125f; // / d_decim_factor
+            const float perm = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm_addr, __builtin_bit_cast(int, A))); // bin (m - 1) mod 8 of this register
+            const float left = (m == 0) ? prev_perm : perm; // bin i - 1: for m = 0 bin 7 of the previous register
+            prev_perm = perm;
+            const float g = left - A; // samples_ifreq_avg[i - 1] - samples_ifreq_avg[i]
+            const int i = 8 * j + m;
+            if ((j > 0 || m > 0) && g > bv) { bv = g; bi = i; } // i runs from 1; strict '>' keeps the first maximum
+        }
+    }
+    const float best = wave_max_nonneg_u(bv);
+    const int first = wave_min_u((bv == best) ? bi : 0x7fffffff);
+    const uint32_t max_index = (first == 0x7fffffff) ? 0u : (uint32_t)first + 1u; // :486
+    const uint32_t bin_idx = ((uint32_t)N - max_index) % (uint32_t)N;              // :490
+    bin_out = bin_idx;
+    fine_out = 0;
+    if (P.enable_fine_sync == 0u) return;
+    // fine_sync (:300-338), lags -1, 0, +1: c_lag = sum_k f[k] v[(bin_idx + 1) 8 + sps + lag + k], k = 64 j + lane
+    const float *__restrict__ vp = Tv + ((int)(bin_idx + 1u) * 8 + SPS) + (lane - 1);
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const float fj = f[j];
+        c0 += fj * vp[64 * j]; c1 += fj * vp[64 * j + 1]; c2 += fj * vp[64 * j + 2];
+    }
+    c0 = wave_sum_u(c0); c1 = wave_sum_u(c1); c2 = wave_sum_u(c2);
+    float mx = 0.0f;
+    int32_t lag = 0;
+    if (c0 > mx) { mx = c0; lag = -1; }
+    if (c1 > mx) { mx = c1; lag = 0; }
+    if (c2 > mx) { mx = c2; lag = 1; }
+    fine_out = -lag;
+}
+
 // copies the packed table block (down4 | twn4 | tws4 | xst4) and the ifreq template into LDS; all threads of the block
 template <int SF>
 __device__ __forceinline__ WaveTabs wave_tabs_to_lds(const DevParams &P, v4f *lds4, float *lds_v, uint32_t nthreads)
@@ -471,6 +568,24 @@ __global__ __launch_bounds__(256) void demod_symbols_wave_kernel(DevParams P, co
         uint32_t b;
         int32_t fs;
         wave_demod_symbol<SF, (SF == 7) || LORA_W2_EARLY_F_SF8>(P, T, iq + offsets[s], b, fs);
+        if ((threadIdx.x & 63u) == 0u) { bins[s] = b; if (fine) fine[s] = fs; }
+    }
+}
+
+template <int SF>
+__global__ __launch_bounds__(256) void demod_symbols_wave_grad_kernel(DevParams P, const float2 *iq, const int64_t *offsets, uint32_t n, uint32_t *bins, int32_t *fine)
+{
+    using G = WaveGeom<SF>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *lds_v = reinterpret_cast<float *>(smem);
+    for (uint32_t i = threadIdx.x; i < 3u * G::SPS + 40u; i += 256u) lds_v[i] = P.up_ifreq_v[i];
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6;
+    for (uint32_t s = blockIdx.x * 4u + wave; s < n; s += gridDim.x * 4u) {
+        uint32_t b;
+        int32_t fs;
+        float en;
+        wave_demod_symbol_grad<SF>(P, lds_v, iq + offsets[s], false, b, fs, en);
         if ((threadIdx.x & 63u) == 0u) { bins[s] = b; if (fine) fine[s] = fs; }
     }
 }

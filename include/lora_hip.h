@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LORA_HIP_ABI_VERSION 2   /* 2: lora_hip_set_stream_latency, lora_hip_stream_info, lora_hip_detect_preambles_device */
+#define LORA_HIP_ABI_VERSION 2   /* 2: lora_hip_set_stream_latency, lora_hip_stream_info, lora_hip_walker_kernel_name */
 
 typedef enum lora_hip_status {
     LORA_HIP_OK = 0,
@@ -221,6 +221,10 @@ lora_hip_status lora_hip_demod_symbols_ex_device(lora_hip_decoder_t *h, const vo
 
 /* ---- introspection --------------------------------------------------------------------------------------- */
 lora_hip_status lora_hip_last_timing(const lora_hip_decoder_t *h, lora_hip_timing_t *t);
+/* Name of the state-machine kernel this handle's passes launch (diagnostics; what a rocprofv3 kernel trace will show):
+ * walker2_kernel_sf7/8[_grad] (wave per symbol), walker3_kernel_sf9..12[_grad] (workgroup per symbol), walker_kernel* (generic:
+ * other decimations, LORA_HIP_NO_FAST).                                                                                        */
+const char     *lora_hip_walker_kernel_name(const lora_hip_decoder_t *h);
 
 /* How the last pass cut its streams into speculation segments (diagnostics): *burst_aware = 1 when the cuts were placed
  * in the gaps between bursts found by the energy-envelope pre-pass, 0 for the fixed grid (configured segment length,

@@ -1,8 +1,15 @@
 """BASELINE.json's configurations at their FULL sizes against the CPU oracle (same demodulator): every frame, every header
-position.  config 2: 1024 packets x 32 B at SF7 as one stream and as 8 streams; config 3: 256 packets per SF for SF7-9,
-32 for SF10-12, CR4/5 and CR4/8; config 4: 64 continuous SF9 channels.  The oracle runs one decoder per stream on a
-thread pool (the ctypes calls release the GIL)."""
+position.  config 2: 1024 packets x 32 B at SF7 as one stream and as 8 streams; config 3: 256 packets per SF, SF7-12,
+CR4/5 and CR4/8; config 4: 64 continuous SF9 channels.  The oracle runs one decoder per stream on a thread pool (the
+ctypes calls release the GIL).
+
+In the reference's shipped configuration (gradient demodulator, decoder_impl.cc:499) configs 2 and 3 are ALSO held to
+fixtures made by the compiled reference itself (tests/golden/fullsize_ref.json, tests/golden/make_fullsize_golden.py):
+frame count, sha256 over the published frames and every header position, per stream."""
 import concurrent.futures as cf
+import hashlib
+import json
+import os
 
 import numpy as np
 import pytest
@@ -58,9 +65,46 @@ def test_config2_full_size(oracle_mod, streams):
     assert [[f[15:] for f in g[0]] for g in got] == expect
 
 
+def _digest(frames):
+    h = hashlib.sha256()
+    for f in frames:
+        h.update(len(f).to_bytes(4, "little"))
+        h.update(f)
+    return h.hexdigest()
+
+
+_FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_ref.json")
+
+
+def _against_reference_fixture(tag):
+    """GPU DEMOD_GRAD (walker2 / walker3 gradient kernels) == what the compiled reference published on the same IQ"""
+    fx = json.load(open(_FIX))[tag]
+    cfg, iq, offs, lens, expect = bench.make_workload(fx["sf"], fx["cr"], fx["packets"], fx["payload"], fx["streams"], seed=fx["seed"])
+    assert int(iq.size) == fx["n_items"]
+    got = _gpu_streams(iq, offs, lens, 0, **fx["decoder_kw"])
+    for s, ((gf, gp), want) in enumerate(zip(got, fx["per_stream"])):
+        assert len(gf) == want["frames"], (tag, s, len(gf), want["frames"])
+        assert _digest(gf) == want["sha256"], (tag, s)
+        if fx["sf"] <= 10:
+            assert gp == want["header_pos"], (tag, s)
+        else:  # SF11 / SF12: the reference's own SYNC shift ties below its float resolution (tests/parity_util.py)
+            assert all(abs(a - b) <= 1 for a, b in zip(gp, want["header_pos"])), (tag, s)
+
+
+@pytest.mark.parametrize("streams", [1, 8])
+def test_config2_full_size_grad_vs_reference_fixture(streams):
+    _against_reference_fixture("config2-%dstream%s" % (streams, "s" if streams > 1 else ""))
+
+
+@pytest.mark.parametrize("sf", [7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("cr", [1, 4])
+def test_config3_full_size_grad_vs_reference_fixture(sf, cr):
+    _against_reference_fixture("config3-sf%d-cr%d" % (sf, cr))
+
+
 @pytest.mark.parametrize("sf", [7, 8, 9, 10, 11, 12])
 def test_config3_full_size(oracle_mod, sf):
-    n = 256 if sf <= 9 else 32
+    n = 256
     for cr in (1, 4):
         cfg, iq, offs, lens, expect = bench.make_workload(sf, cr, n, 32, 8, seed=100 * sf + cr)
         kw = dict(sf=sf, cr=4, reduced_rate=(sf > 10))

@@ -97,7 +97,7 @@ def test_frequency_offset_identical(oracle_mod, sf, cr, cfo):
     _assert_identical(oracle_mod, st.iq, sf=sf, cr=cr)
 
 
-@pytest.mark.parametrize("sf", [7, 8, 9, 10])
+@pytest.mark.parametrize("sf", [7, 8, 9, 10, pytest.param(11, marks=pytest.mark.slow), pytest.param(12, marks=pytest.mark.slow)])
 def test_decode_long_identical(oracle_mod, sf):
     """suite `decode_long`: 255-byte payload 00..fe, CR4/8 (apps/generate_test_suites.py:157-170)."""
     cfg, st = _stream(sf, 4, 1, seed=sf, payloads=[bytes(range(255))])
