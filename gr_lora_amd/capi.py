@@ -23,7 +23,7 @@ EXPORTS = [
     "lora_hip_get_geometry", "lora_hip_set_sf", "lora_hip_set_samp_rate", "lora_hip_work", "lora_hip_flush",
     "lora_hip_decode_device", "lora_hip_frames_available", "lora_hip_poll_frame", "lora_hip_drain_frames", "lora_hip_drain_slots", "lora_hip_demod_symbols_device", "lora_hip_demod_symbols_ex_device",
     "lora_hip_last_timing", "lora_hip_last_plan", "lora_hip_gap_starts_device", "lora_hip_decode_device_begin", "lora_hip_decode_device_end", "lora_hip_decode_device_prepass", "lora_hip_trace", "lora_hip_trace_clear", "lora_hip_check_frame", "lora_hip_estimate_cfo_device",
-    "lora_hip_set_stream_latency", "lora_hip_stream_info", "lora_hip_walker_kernel_name",
+    "lora_hip_set_stream_latency", "lora_hip_stream_info", "lora_hip_walker_kernel_name", "lora_hip_window_stats_device", "lora_hip_detect_preambles_device",
 ]
 
 
@@ -72,6 +72,15 @@ class FrameCheck(C.Structure):
 class StreamInfo(C.Structure):
     _fields_ = [("batch_items", C.c_uint64), ("buffered_items", C.c_uint64), ("passes", C.c_uint64), ("passes_by_latency", C.c_uint64),
                 ("consumed_base", C.c_int64), ("max_latency_ms", C.c_float), ("pass_in_flight", C.c_uint32)]
+
+
+class WindowStats(C.Structure):
+    _fields_ = [("bin_down", C.c_int32), ("peak_down", C.c_float), ("total_down", C.c_float), ("bin_up", C.c_int32), ("peak_up", C.c_float), ("total_up", C.c_float)]
+
+
+class Preamble(C.Structure):
+    _fields_ = [("header_pos", C.c_int64), ("run_pos", C.c_int64), ("stream", C.c_uint32), ("run_len", C.c_uint32), ("bin", C.c_int32), ("sfd_index", C.c_int32),
+                ("pmr", C.c_float), ("cfo_bins", C.c_float), ("cfo_hz", C.c_float), ("reserved", C.c_uint32)]
 
 
 class LoraHipError(RuntimeError):
@@ -134,6 +143,8 @@ def load():
     L.lora_hip_trace_clear.restype = None
     L.lora_hip_estimate_cfo_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_int64), C.c_size_t, C.c_int, C.POINTER(C.c_float), vp]
     L.lora_hip_estimate_cfo_device.restype = C.c_int
+    L.lora_hip_window_stats_device.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(WindowStats), vp]
+    L.lora_hip_detect_preambles_device.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_uint32, C.c_float, C.POINTER(Preamble), C.c_size_t, C.POINTER(C.c_size_t), vp]
     L.lora_hip_walker_kernel_name.argtypes = [vp]
     L.lora_hip_walker_kernel_name.restype = C.c_char_p
     L.lora_hip_set_stream_latency.argtypes = [vp, C.c_float]
@@ -278,6 +289,23 @@ class Handle:
         self._check(self.L.lora_hip_estimate_cfo_device(self.h, C.c_void_p(dev_ptr), total_items, off.ctypes.data_as(C.POINTER(C.c_int64)), off.size, mode,
                                                         out.ctypes.data_as(C.POINTER(C.c_float)), C.c_void_p(stream)))
         return out
+
+    def window_stats_device(self, dev_ptr: int, total_items: int, offsets: Sequence[int], stream: int = 0):
+        """lora_hip_window_stats_device: per window (bin_down, peak_down, total_down, bin_up, peak_up, total_up)."""
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        out = (WindowStats * max(off.size, 1))()
+        self._check(self.L.lora_hip_window_stats_device(self.h, dev_ptr, total_items, off.ctypes.data, off.size, out, stream))
+        return [(o.bin_down, o.peak_down, o.total_down, o.bin_up, o.peak_up, o.total_up) for o in out[: off.size]]
+
+    def detect_preambles_device(self, dev_ptr: int, total_items: int, offs: Sequence[int], lens: Sequence[int], threshold: float = 0.0, stream: int = 0, cap: int = 4096):
+        """lora_hip_detect_preambles_device: FFT-domain preamble detection (acquires below 0 dB); list of dicts."""
+        o = np.ascontiguousarray(offs, dtype=np.uint64)
+        l = np.ascontiguousarray(lens, dtype=np.uint64)
+        out = (Preamble * cap)()
+        n = C.c_size_t(0)
+        self._check(self.L.lora_hip_detect_preambles_device(self.h, dev_ptr, total_items, o.ctypes.data, l.ctypes.data, o.size, float(threshold), out, cap, C.byref(n), stream))
+        return [dict(header_pos=p.header_pos, run_pos=p.run_pos, stream=p.stream, run_len=p.run_len, bin=p.bin, sfd_index=p.sfd_index, pmr=p.pmr,
+                     cfo_bins=p.cfo_bins, cfo_hz=p.cfo_hz) for p in out[: n.value]]
 
     def frames_available(self) -> int:
         return self.L.lora_hip_frames_available(self.h)

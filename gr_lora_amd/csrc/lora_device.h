@@ -145,6 +145,7 @@ int launch_walker(const DevParams &p, const LaunchCfg &c, void *stream);
 const char *walker_kernel_name(const DevParams &p);                        // the kernel launch_walker picks for this configuration
 int launch_demod_symbols(const DevParams &p, const float2 *iq, const int64_t *d_offsets, uint32_t n,
                          int demod, uint32_t *d_bins, int32_t *d_fine, float *scratch, void *stream);
+int launch_detect_windows(const DevParams &p, const float2 *iq, const int64_t *d_offsets, uint32_t n, void *d_out /* 24 B per window */, void *stream); // N4: lora_detect.inc.hip
 int launch_cfo(const DevParams &p, const float2 *iq, const int64_t *d_offsets, uint32_t n, int mode, float *d_out, void *stream); // N4: explicit CFO estimate
 bool walker3_covers(uint32_t sf);                                          // SF9-12: lora_walker3.inc.hip
 uint32_t w3_tw_entries(uint32_t sf);

@@ -1226,6 +1226,129 @@ lora_hip_status lora_hip_estimate_cfo_device(lora_hip_decoder_t *h, const void *
     return LORA_HIP_OK;
 }
 
+// ---- FFT-domain preamble detection (definition: oracle/preamble_oracle.py) ----------------------------
+static lora_hip_status window_stats_abs(lora_hip_decoder_t *h, const float2 *d_iq, const std::vector<int64_t> &offsets, std::vector<lora_hip_window_stats_t> &out, hipStream_t st)
+{
+    static_assert(sizeof(lora_hip_window_stats_t) == 24, "kernel record layout");
+    const size_t n = offsets.size();
+    out.resize(n);
+    if (n == 0) return LORA_HIP_OK;
+    HIP_TRY(h, h->d_offsets.reserve(n));
+    HIP_TRY(h, h->d_bins.reserve(6u * n));
+    HIP_TRY(h, hipMemcpyAsync(h->d_offsets.p, offsets.data(), n * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    if (launch_detect_windows(h->P, d_iq, h->d_offsets.p, (uint32_t)n, h->d_bins.p, st) != 0)
+        return fail(h, LORA_HIP_ERR_HIP, "detect launch failed: %s", hipGetErrorString(hipGetLastError()));
+    HIP_TRY(h, hipMemcpyAsync(out.data(), h->d_bins.p, n * sizeof(lora_hip_window_stats_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    return LORA_HIP_OK;
+}
+
+lora_hip_status lora_hip_window_stats_device(lora_hip_decoder_t *h, const void *d_iq, size_t total_items, const int64_t *offsets, size_t n,
+                                             lora_hip_window_stats_t *out, void *hip_stream)
+{
+    if (!h || !d_iq || (n && (!offsets || !out))) return LORA_HIP_ERR_ARG;
+    for (size_t i = 0; i < n; i++)
+        if (offsets[i] < 0 || (uint64_t)offsets[i] + h->P.sps > total_items) return fail(h, LORA_HIP_ERR_ARG, "window %zu out of range", i);
+    HIP_TRY(h, hipSetDevice(h->device));
+    std::vector<int64_t> offs(offsets, offsets + n);
+    std::vector<lora_hip_window_stats_t> res;
+    const lora_hip_status s = window_stats_abs(h, (const float2 *)d_iq, offs, res, (hipStream_t)hip_stream);
+    if (s != LORA_HIP_OK) return s;
+    std::copy(res.begin(), res.end(), out);
+    return LORA_HIP_OK;
+}
+
+lora_hip_status lora_hip_detect_preambles_device(lora_hip_decoder_t *h, const void *d_iq, size_t total_items, const uint64_t *stream_off,
+                                                 const uint64_t *stream_len, uint32_t n_streams, float threshold, lora_hip_preamble_t *out, size_t cap,
+                                                 size_t *n_found, void *hip_stream)
+{
+    if (!h || !d_iq || !n_found || (n_streams && (!stream_off || !stream_len)) || (cap && !out) || !(threshold >= 0.0f)) return LORA_HIP_ERR_ARG;
+    *n_found = 0;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int64_t sps = h->P.sps, N = h->P.nbins, D = h->P.decim;
+    const float thr = threshold > 0.0f ? threshold : (float)(std::log((double)N) + 4.6);
+    constexpr int64_t kMinRun = 4, kSfdReach = 6;
+    hipStream_t st = (hipStream_t)hip_stream;
+    auto pmr = [&](float peak, float total) { const float rest = total - peak; return rest > 0.0f ? peak * (float)(N - 1) / rest : INFINITY; };
+    auto circ = [&](int32_t a, int32_t b) { int64_t d = std::llabs((int64_t)a - b) % N; return std::min(d, N - d); };
+    // stage A: one window per symbol of every stream, one launch
+    std::vector<int64_t> offs;
+    std::vector<size_t> first(n_streams + 1u, 0);
+    for (uint32_t s = 0; s < n_streams; s++) {
+        if (stream_off[s] > total_items || stream_len[s] > total_items - stream_off[s]) return fail(h, LORA_HIP_ERR_ARG, "stream %u exceeds the buffer", s);
+        const int64_t K = (int64_t)(stream_len[s] / (uint64_t)sps) - 1;
+        first[s] = offs.size();
+        for (int64_t k = 0; k < K; k++) offs.push_back((int64_t)stream_off[s] + k * sps);
+    }
+    first[n_streams] = offs.size();
+    std::vector<lora_hip_window_stats_t> A;
+    lora_hip_status rc = window_stats_abs(h, (const float2 *)d_iq, offs, A, st);
+    if (rc != LORA_HIP_OK) return rc;
+    // runs, per stream
+    struct Cand { uint32_t stream; int64_t k, e, a0; int32_t bin; float pmr; size_t b_first, b_n; };
+    std::vector<Cand> cands;
+    std::vector<int64_t> boffs;
+    for (uint32_t s = 0; s < n_streams; s++) {
+        const lora_hip_window_stats_t *W = A.data() + first[s];
+        const int64_t K = (int64_t)(first[s + 1] - first[s]), len = (int64_t)stream_len[s];
+        int64_t k = 0;
+        while (k < K) {
+            if (!(pmr(W[k].peak_down, W[k].total_down) >= thr)) { k++; continue; }
+            int64_t e = k + 1;
+            while (e < K && pmr(W[e].peak_down, W[e].total_down) >= thr && circ(W[e].bin_down, W[e - 1].bin_down) <= 1) e++;
+            if (e - k >= kMinRun) {
+                int32_t best = W[k].bin_down; int64_t best_n = 0; // most frequent bin; ties: the smallest
+                for (int64_t i = k; i < e; i++) {
+                    int64_t c = 0;
+                    for (int64_t j = k; j < e; j++) c += W[j].bin_down == W[i].bin_down;
+                    if (c > best_n || (c == best_n && W[i].bin_down < best)) { best_n = c; best = W[i].bin_down; }
+                }
+                float pm = 0.0f;
+                for (int64_t i = k; i < e; i++) pm += pmr(W[i].peak_down, W[i].total_down);
+                int64_t a0 = k * sps - (int64_t)best * D;
+                if (a0 < 0) a0 += sps;
+                Cand c{s, k, e, a0, best, pm / (float)(e - k), boffs.size(), 0};
+                for (int64_t j = 0; j <= (e - k) + kSfdReach; j++) {
+                    const int64_t p = a0 + j * sps;
+                    if (p + sps > len) break;
+                    boffs.push_back((int64_t)stream_off[s] + p);
+                    c.b_n++;
+                }
+                cands.push_back(c);
+            }
+            k = e;
+        }
+    }
+    // stage B: the aligned windows of every candidate, one launch
+    std::vector<lora_hip_window_stats_t> B;
+    rc = window_stats_abs(h, (const float2 *)d_iq, boffs, B, st);
+    if (rc != LORA_HIP_OK) return rc;
+    size_t n_out = 0;
+    bool overflow = false;
+    int64_t skip_until = -1; uint32_t skip_stream = 0xffffffffu;
+    for (const Cand &c : cands) {
+        if (c.stream == skip_stream && c.k < skip_until) continue; // (a run that begins inside the packet just reported)
+        const lora_hip_window_stats_t *W = B.data() + c.b_first;
+        int64_t found = -1;
+        for (size_t j = 0; j + 1 < c.b_n; j++) {
+            if (pmr(W[j].peak_up, W[j].total_up) >= thr && W[j].peak_up > W[j].peak_down && pmr(W[j + 1].peak_up, W[j + 1].total_up) >= thr &&
+                W[j + 1].peak_up > W[j + 1].peak_down) { found = (int64_t)j; break; }
+        }
+        if (found < 0) continue;
+        const int32_t bu = W[found].bin_up, sb = bu < N / 2 ? bu : bu - (int32_t)N;
+        if (n_out < cap) {
+            lora_hip_preamble_t &o = out[n_out];
+            o.header_pos = c.a0 + found * sps + 2 * sps + sps / 4; o.run_pos = c.k * sps; o.stream = c.stream; o.run_len = (uint32_t)(c.e - c.k);
+            o.bin = c.bin; o.sfd_index = (int32_t)found; o.pmr = c.pmr; o.cfo_bins = -0.5f * (float)sb;
+            o.cfo_hz = o.cfo_bins * (float)h->cfg.bandwidth / (float)N; o.reserved = 0;
+        } else overflow = true;
+        n_out++;
+        skip_stream = c.stream; skip_until = (c.a0 + (found + 2) * sps) / sps;
+    }
+    *n_found = n_out;
+    return overflow ? LORA_HIP_ERR_OVERFLOW : LORA_HIP_OK;
+}
+
 lora_hip_status lora_hip_last_plan(const lora_hip_decoder_t *h, uint32_t *burst_aware, uint32_t *segments)
 {
     if (!h) return LORA_HIP_ERR_ARG;

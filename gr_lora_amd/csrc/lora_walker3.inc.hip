@@ -63,8 +63,10 @@
 #define LORA_W3_REPLAY_STATS 1  // LORA_HIP_DEBUG accounting of thread 0's replay inside the decode rounds
 #endif
 #ifndef LORA_W3_T512_MASK
-#define LORA_W3_T512_MASK 0     // bit (SF - 9): that SF's kernels as 512-thread workgroups at a 256-register budget - every thread does the work of two
-                                // (2 / 2 / 2 / 4 sample chunks in pass 1, two units of passes 2 and 3): 8 wavefronts per CU instead of 16, no spills
+#define LORA_W3_T512_MASK 11    // bit (SF - 9): that SF's kernels as 512-thread workgroups at a 256-register budget - every thread does the work of two
+                                // (2 / 2 / 2 / 4 sample chunks in pass 1, two units of passes 2 and 3): 8 wavefronts per CU instead of 16 and no spill
+                                // left in the demodulator (tools/scratch_where.py).  Same-box A/B against 1024 x 128 (256 packets, round 3):
+                                // SF9 +8 %, SF10 +9 %, SF12 +22 % (its eight held rows now ARE registers), SF11 -1 %: on for SF9, SF10, SF12
 #endif
 #ifndef LORA_W3_EARLY_F_MASK
 #define LORA_W3_EARLY_F_MASK 0  // bit 3: SF12 keeps fine_sync's ifreq from pass 1 (needs the T512 register budget)
@@ -752,33 +754,95 @@ __device__ __forceinline__ void w3_tables_to_lds(const DevParams &P, const W3Lds
     for (int i = threadIdx.x; i < G::NTW; i += G::T) L.tw[i] = src[i];
 }
 
-// ---- DETECT (:340-366): sums of c1 conj(c2), |c1|^2, |c2|^2 over the symbol pair at x, one window per group ----
+// ---- acquisition rounds look at several windows per group (round 3).  At one window per group and round an acquisition was a
+// chain of 5 DETECT + 1 SYNC + 10 FIND_SFD + 1 PAUSE rounds at SF11 (LORA_HIP_DEBUG), each a first-touch HBM round trip, a
+// workgroup-wide reduction and thread 0's replay: a quarter of a job.  Now every group evaluates KD (DETECT) / KS (FIND_SFD)
+// windows behind ONE barrier sequence, as walker2's workers do; the partial sums of all windows meet in an LDS scratch area that
+// aliases the demodulator's data array (idle in these rounds), and thread 0 replays the NQ = NG K results in order.
+#ifndef LORA_W3_SFD_INLINE
+#define LORA_W3_SFD_INLINE __attribute__((noinline))
+#endif
+#ifndef LORA_W3_DET_K
+#define LORA_W3_DET_K 0x4421   // DETECT windows per group and round, one hex digit per SF (SF9 lowest): 1, 2, 4, 4
+#endif
+#ifndef LORA_W3_SFD_K
+#define LORA_W3_SFD_K 0x4442   // FIND_SFD windows per group and round: 2, 4, 4, 4
+#endif
+template <int SF> struct W3Acq {
+    static constexpr int KD = (LORA_W3_DET_K >> (4 * (SF - 9))) & 15, KS = (LORA_W3_SFD_K >> (4 * (SF - 9))) & 15;
+    static constexpr int NQD = KD * W3Geom<SF>::NG, NQS = KS * W3Geom<SF>::NG; // windows per round
+    static_assert(KD >= 1 && KS >= 1 && NQD <= 8 && NQS <= 8, "results are kept for at most 8 windows per round");
+};
+struct alignas(16) W3AcqScratch { // in the demodulator's LDS data array
+    float   part[8][16][4];    // [window][wavefront of its group][sum]
+    double  dpart[8][16][2];   // FIND_SFD: G0, G1 of fine_sync's closed form
+    float   edge[8][72];       // FIND_SFD: head / tail samples of the window's ifreq
+    int32_t lag[8];
+};
+
+// ---- DETECT (:340-366): sums of c1 conj(c2), |c1|^2, |c2|^2 over the symbol pairs of the windows q = grp KD + k at x0 + q sps.
+// A group's KD windows are consecutive: its KD + 1 symbols are read once, the energy of a symbol serves the two windows it
+// belongs to (summed in the same order either way).  out[q] = {re, im, e1, e2}, uniform.
 template <int SF>
-__device__ __forceinline__ void w3_detect_round(const float2 *__restrict__ x, bool valid, W3Shared &ws, int &slot, float (&out)[W3Geom<SF>::NG][4])
+__device__ __forceinline__ void w3_detect_round(const float2 *__restrict__ x0, int n_valid, W3AcqScratch *sc, float (&out)[W3Acq<SF>::NQD][4])
 {
     using G = W3Geom<SF>;
-    const auto xv = (const __attribute__((address_space(1))) v2f *)x;
-    const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x / G::TG), t = (int)threadIdx.x % G::TG, gwave = __builtin_amdgcn_readfirstlane(t >> 6);
-    float a[4] = {0.f, 0.f, 0.f, 0.f};
-    if (valid) {
+    constexpr int KD = W3Acq<SF>::KD, NQ = W3Acq<SF>::NQD, GW = G::GW;
+    int tt = threadIdx.x;
+    asm volatile("" : "+v"(tt)); // keeps per-thread offsets out of the caller's loop-invariant set (they would be parked in scratch)
+    const int grp = __builtin_amdgcn_readfirstlane(tt / G::TG), t = tt % G::TG, gwave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    const int q0 = grp * KD;
+    float d0[KD], d1[KD], e[KD + 1];
 #pragma unroll
+    for (int k = 0; k < KD; k++) { d0[k] = 0.f; d1[k] = 0.f; }
+#pragma unroll
+    for (int k = 0; k <= KD; k++) e[k] = 0.f;
+    if (q0 < n_valid) {
+        const w3_buf_t xb = w3_buf(w3_uniform_ptr(x0 + (int64_t)q0 * G::SPS));
+#pragma unroll 1
         for (int p = 0; p < G::PAIRS; p++) {
+            const uint32_t ob = 8u * (uint32_t)(p * G::TG + t);
             v2f u[16], w[16];
 #pragma unroll
-            for (int c = 0; c < 16; c++) u[c] = xv[c * G::CH + p * G::TG + t];
+            for (int c = 0; c < 16; c++) u[c] = w3_ld2(xb, ob, (uint32_t)(c * G::CH * 8));
 #pragma unroll
-            for (int c = 0; c < 16; c++) w[c] = xv[G::SPS + c * G::CH + p * G::TG + t];
+            for (int c = 0; c < 16; c++) e[0] += u[c].x * u[c].x + u[c].y * u[c].y;
 #pragma unroll
-            for (int c = 0; c < 16; c++) {
-                const v2f c1 = u[c], c2 = w[c];
-                a[0] += c1.x * c2.x + c1.y * c2.y;
-                a[1] += c1.y * c2.x - c1.x * c2.y;
-                a[2] += c1.x * c1.x + c1.y * c1.y;
-                a[3] += c2.x * c2.x + c2.y * c2.y;
+            for (int k = 0; k < KD; k++) {
+                if (q0 + k < n_valid) { // (uniform per group)
+                    const w3_buf_t wb = w3_buf(w3_uniform_ptr(x0 + (int64_t)(q0 + k + 1) * G::SPS));
+#pragma unroll
+                    for (int c = 0; c < 16; c++) w[c] = w3_ld2(wb, ob, (uint32_t)(c * G::CH * 8));
+#pragma unroll
+                    for (int c = 0; c < 16; c++) {
+                        const v2f c1 = u[c], c2 = w[c];
+                        d0[k] += c1.x * c2.x + c1.y * c2.y;
+                        d1[k] += c1.y * c2.x - c1.x * c2.y;
+                        e[k + 1] += c2.x * c2.x + c2.y * c2.y;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 16; c++) u[c] = w[c];
+                }
             }
         }
     }
-    w3_group_sums<SF, 4>(a, ws, slot, grp, gwave, out, grp == 0 && gwave == 0);
+#pragma unroll
+    for (int k = 0; k <= KD; k++) e[k] = wave_sum_rows(e[k]);
+#pragma unroll
+    for (int k = 0; k < KD; k++) {
+        const float s0 = wave_sum_rows(d0[k]), s1 = wave_sum_rows(d1[k]);
+        if (lane == 0) { float *o = sc->part[q0 + k][gwave]; o[0] = s0; o[1] = s1; o[2] = e[k]; o[3] = e[k + 1]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < GW; w++) v += sc->part[q][w][j];
+            out[q][j] = w3_uni(v);
+        }
 }
 
 // ---- SYNC (:770-783, detect_upchirp :392-413), all threads of the workgroup together --------------------------
@@ -882,115 +946,131 @@ __device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double syn
     return W3SyncOut{bv, bi, slot};
 }
 
-// ---- FIND_SFD (:385-390, :283-298, :801-803), one window per group --------------------------------------------
-// Pearson correlation of the window's ifreq with the ideal downchirp ifreq (one pass); for an upchirp (c < -0.97)
-// fine_sync(-1, 4 D) over the 63 lags in closed form (see w2_sfd_window for the derivation).  Results of all groups
-// come back packed: c[g] and fine[g].
-struct W3SfdOut { float c[4]; int32_t fine[4]; int slot; };
+// ---- FIND_SFD (:385-390, :283-298, :801-803): the windows q = k NG + grp, k < KS, at x0 + q sps ---------------------------
+// Pearson correlation of each window's ifreq with the ideal downchirp ifreq (one pass); for an upchirp (c < -0.97)
+// fine_sync(-1, 4 D) over the 63 lags in closed form (see w2_sfd_window for the derivation).  c[q] and fine[q] come back uniform.
+struct W3SfdOut { float c[8]; int32_t fine[8]; };
 struct W3SfdArgs { const float *down_ifreq, *up_ifreq_v; float down_ifreq_avg, down_ifreq_sd, down_ifreq_dsum; double sync_a, sync_b; };
 template <int SF>
-__device__ __attribute__((noinline)) W3SfdOut w3_sfd_round(W3SfdArgs P, const float2 *__restrict__ x, int valid_i, W3Shared *wsp, int slot)
+__device__ LORA_W3_SFD_INLINE W3SfdOut w3_sfd_round(W3SfdArgs P, const float2 *__restrict__ x0, int n_valid, W3AcqScratch *sc)
 {
     using G = W3Geom<SF>;
-    constexpr int SPS = G::SPS, TG = G::TG, CH = G::CH, PAIRS = G::PAIRS, GW = G::GW, NG = G::NG;
-    W3Shared &ws = *wsp;
-    const bool valid = valid_i != 0;
-    const w3_buf_t xb = w3_buf(w3_uniform_ptr(x)), ddb = w3_buf(P.down_ifreq);
-    const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x / TG), t = (int)threadIdx.x % TG, lane = t & 63, gwave = __builtin_amdgcn_readfirstlane(t >> 6);
-    float a3[3] = {0.f, 0.f, 0.f};
-    double g0 = 0.0, g1 = 0.0;
-    float f_first = 0.0f, f_last = 0.0f; // chunk 0 of pair 0, chunk 15 of the last pair
-    if (valid) {
+    constexpr int SPS = G::SPS, TG = G::TG, CH = G::CH, PAIRS = G::PAIRS, GW = G::GW, NG = G::NG, KS = W3Acq<SF>::KS, NQ = W3Acq<SF>::NQS;
+    const w3_buf_t ddb = w3_buf(P.down_ifreq);
+    int tt = threadIdx.x;
+    asm volatile("" : "+v"(tt));
+    const int grp = __builtin_amdgcn_readfirstlane(tt / TG), t = tt % TG, lane = t & 63, gwave = __builtin_amdgcn_readfirstlane(t >> 6);
+#pragma unroll 1
+    for (int k = 0; k < KS; k++) {
+        const int q = k * NG + grp;
+        float a3[3] = {0.f, 0.f, 0.f};
+        double g0 = 0.0, g1 = 0.0;
+        float f_first = 0.0f, f_last = 0.0f; // chunk 0 of pair 0, chunk 15 of the last pair
+        if (q < n_valid) { // (uniform per group)
+            const w3_buf_t xb = w3_buf(w3_uniform_ptr(x0 + (int64_t)q * SPS));
+#pragma unroll 1
+            for (int p = 0; p < PAIRS; p++) {
+                const int base = p * TG + t;
+                const uint32_t ob = 8u * (uint32_t)base;
+                v2f a[16], ap[16];
+                float dd[16], f[16];
 #pragma unroll
-        for (int p = 0; p < PAIRS; p++) {
-            const int base = p * TG + t;
-            const uint32_t ob = 8u * (uint32_t)base;
-            v2f a[16], ap[16];
-            float dd[16], f[16];
+                for (int c = 0; c < 16; c++) a[c] = w3_ld2(xb, ob, (uint32_t)(c * CH * 8));
+                ap[0] = w3_ld2(xb, (p == 0) ? (ob >= 8u ? ob - 8u : 0u) : ob - 8u, 0u);
 #pragma unroll
-            for (int c = 0; c < 16; c++) a[c] = w3_ld2(xb, ob, (uint32_t)(c * CH * 8));
-            ap[0] = w3_ld2(xb, (p == 0) ? (ob >= 8u ? ob - 8u : 0u) : ob - 8u, 0u);
+                for (int c = 1; c < 16; c++) ap[c] = w3_ld2(xb, ob, (uint32_t)(c * CH * 8 - 8));
+                dd[0] = w3_ld1(ddb, base >= 1 ? 4u * (uint32_t)(base - 1) : 0u, 0u);
 #pragma unroll
-            for (int c = 1; c < 16; c++) ap[c] = w3_ld2(xb, ob, (uint32_t)(c * CH * 8 - 8));
-            dd[0] = w3_ld1(ddb, base >= 1 ? 4u * (uint32_t)(base - 1) : 0u, 0u);
+                for (int c = 1; c < 16; c++) dd[c] = w3_ld1(ddb, 4u * (uint32_t)base, (uint32_t)(c * CH * 4 - 4));
+                if (p == 0) w3_ifreq16<true>(a, ap, t == 0, f);
+                else w3_ifreq16<false>(a, ap, false, f);
 #pragma unroll
-            for (int c = 1; c < 16; c++) dd[c] = w3_ld1(ddb, 4u * (uint32_t)base, (uint32_t)(c * CH * 4 - 4));
-            if (p == 0) w3_ifreq16<true>(a, ap, t == 0, f);
-            else w3_ifreq16<false>(a, ap, false, f);
-#pragma unroll
-            for (int c = 0; c < 16; c++) {
-                const float fk = f[c];
-                const float d = dd[c] - P.down_ifreq_avg;
-                a3[0] += fk; a3[1] += fk * fk; a3[2] += fk * d; // f is 0 for the non-existent k = -1
-                const int k = c * CH + base - 1;
-                g0 += (double)fk; g1 += (double)k * (double)fk;
+                for (int c = 0; c < 16; c++) {
+                    const float fk = f[c];
+                    const float d = dd[c] - P.down_ifreq_avg;
+                    a3[0] += fk; a3[1] += fk * fk; a3[2] += fk * d; // f is 0 for the non-existent k = -1
+                    const int kk = c * CH + base - 1;
+                    g0 += (double)fk; g1 += (double)kk * (double)fk;
+                }
+                if (p == 0) f_first = f[0];
+                if (p == PAIRS - 1) f_last = f[15];
             }
-            if (p == 0) f_first = f[0];
-            if (p == PAIRS - 1) f_last = f[15];
+            if (t == TG - 1) { g0 += (double)f_last; g1 += (double)(SPS - 1) * (double)f_last; } // duplicated last tap (:243); only the lags use g0, g1
         }
+#pragma unroll
+        for (int j = 0; j < 3; j++) a3[j] = wave_sum_rows(a3[j]);
+        g0 = w3_wave_sum_d(g0); g1 = w3_wave_sum_d(g1);
+        if (lane == 0) {
+            float *o = sc->part[q][gwave];
+            o[0] = a3[0]; o[1] = a3[1]; o[2] = a3[2];
+            sc->dpart[q][gwave][0] = g0; sc->dpart[q][gwave][1] = g1;
+        }
+        // head[k] = fe[k], k < 32 (threads 1 .. 32 of chunk 0); tail[j] = fe[sps-1-j], j <= 32 (the last threads of chunk 15)
+        float *scr = sc->edge[q];
+        if (t >= 1 && t <= 32) scr[t - 1] = f_first;
+        if (t >= TG - 32) scr[32 + 1 + (TG - 1 - t)] = f_last;
+        if (t == TG - 1) scr[32] = f_last;
     }
-    float a3o[NG][3];
-    w3_group_sums<SF, 3>(a3, ws, slot, grp, gwave, a3o);
+    __syncthreads();
     W3SfdOut R;
     bool any_up = false;
 #pragma unroll
-    for (int g = 0; g < 4; g++) { R.c[g] = 0.0f; R.fine[g] = 0; }
+    for (int q = 0; q < 8; q++) { R.c[q] = 0.0f; R.fine[q] = 0; }
 #pragma unroll
-    for (int g = 0; g < NG; g++) {
+    for (int q = 0; q < NQ; q++) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < GW; w++) { s0 += sc->part[q][w][0]; s1 += sc->part[q][w][1]; s2 += sc->part[q][w][2]; }
+        s0 = w3_uni(s0); s1 = w3_uni(s1); s2 = w3_uni(s2);
         const float nf = (float)(SPS - 1);
-        const float average = a3o[g][0] / nf;
-        const float var = fmaxf(a3o[g][1] / nf - average * average, 0.0f);
+        const float average = s0 / nf;
+        const float var = fmaxf(s1 / nf - average * average, 0.0f);
         const float sd = sqrtf(var) * P.down_ifreq_sd;
-        R.c[g] = (a3o[g][2] - average * P.down_ifreq_dsum) / sd / nf;
-        any_up = any_up || (R.c[g] < -0.97f);
+        R.c[q] = (s2 - average * P.down_ifreq_dsum) / sd / nf;
+        any_up = any_up || (R.c[q] < -0.97f);
     }
-    R.slot = slot;
     if (!any_up) return R; // (uniform)
-    // fine_sync(-1, 32): c_i = sum_{k<sps} fe[k] v[sps + i + k], i = -31 .. 31, fe[sps-1] = fe[sps-2]
-    if (valid && t == TG - 1) { g0 += (double)f_last; g1 += (double)(SPS - 1) * (double)f_last; } // duplicated last tap (:243)
-    g0 = w3_wave_sum_d(g0); g1 = w3_wave_sum_d(g1);
-    double *dr = ws.dred[slot & 1] + grp * 18;
-    if (lane == 0) { dr[gwave] = g0; dr[GW + gwave] = g1; }
-    // head[k] = fe[k], k < 32 (threads 1 .. 32 of chunk 0); tail[q] = fe[sps-1-q], q <= 32 (the last threads of chunk 15)
-    float *scr = ws.sfd[grp];
-    if (t >= 1 && t <= 32) scr[t - 1] = f_first;
-    if (t >= TG - 32) scr[32 + 1 + (TG - 1 - t)] = f_last;
-    if (t == TG - 1) scr[32] = f_last;
-    __syncthreads();
+    // fine_sync(-1, 32): c_i = sum_{k<sps} fe[k] v[sps + i + k], i = -31 .. 31, fe[sps-1] = fe[sps-2]; one wavefront per group
     if (gwave == 0) {
-        double G0 = 0.0, G1 = 0.0;
-        for (int w = 0; w < GW; w++) { G0 += dr[w]; G1 += dr[GW + w]; }
-        const int i = lane - 31; // this lane's lag
-        float ps = scr[lane];
+#pragma unroll 1
+        for (int k = 0; k < KS; k++) {
+            const int q = k * NG + grp;
+            if (!(R.c[q] < -0.97f)) continue; // (uniform)
+            double G0 = 0.0, G1 = 0.0;
+            for (int w = 0; w < GW; w++) { G0 += sc->dpart[q][w][0]; G1 += sc->dpart[q][w][1]; }
+            const float *scr = sc->edge[q];
+            const int i = lane - 31; // this lane's lag
+            float ps = scr[lane];
 #pragma unroll
-        for (int o = 1; o < 32; o <<= 1) {
-            const float up = __shfl_up(ps, o, 32);
-            if ((lane & 31) >= o) ps += up;
-        }
-        const float hsum = __shfl(ps, lane < 31 ? 30 - lane : 0, 64); // H_{-i} for the negative lags
-        float c_i = -3.0e38f;
-        if (lane <= 62) {
-            const double a = P.sync_a, b = P.sync_b;
-            const double wd = (double)P.up_ifreq_v[2 * SPS - 1] - (a + b * (double)(SPS - 1));
-            double edge;
-            float wrap_f;
-            if (i >= 0) { edge = i > 0 ? -(double)ps : 0.0; wrap_f = scr[32 + i]; }
-            else { edge = (double)hsum; wrap_f = scr[-i - 1]; }
-            c_i = (float)(a * G0 + b * ((double)i * G0 + G1) + b * (double)SPS * edge + wd * (double)wrap_f);
-        }
-        int li = lane;
+            for (int o = 1; o < 32; o <<= 1) {
+                const float up = __shfl_up(ps, o, 32);
+                if ((lane & 31) >= o) ps += up;
+            }
+            const float hsum = __shfl(ps, lane < 31 ? 30 - lane : 0, 64); // H_{-i} for the negative lags
+            float c_i = -3.0e38f;
+            if (lane <= 62) {
+                const double a = P.sync_a, b = P.sync_b;
+                const double wd = (double)P.up_ifreq_v[2 * SPS - 1] - (a + b * (double)(SPS - 1));
+                double edge;
+                float wrap_f;
+                if (i >= 0) { edge = i > 0 ? -(double)ps : 0.0; wrap_f = scr[32 + i]; }
+                else { edge = (double)hsum; wrap_f = scr[-i - 1]; }
+                c_i = (float)(a * G0 + b * ((double)i * G0 + G1) + b * (double)SPS * edge + wd * (double)wrap_f);
+            }
+            int li = lane;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { // first maximum in lag order (strict '>' scan from 0, :311)
-            const float ov = __shfl_xor(c_i, o, 64);
-            const int oi = __shfl_xor(li, o, 64);
-            if (ov > c_i || (ov == c_i && oi < li)) { c_i = ov; li = oi; }
+            for (int o = 32; o > 0; o >>= 1) { // first maximum in lag order (strict '>' scan from 0, :311)
+                const float ov = __shfl_xor(c_i, o, 64);
+                const int oi = __shfl_xor(li, o, 64);
+                if (ov > c_i || (ov == c_i && oi < li)) { c_i = ov; li = oi; }
+            }
+            const int32_t lag = (c_i > 0.0f) ? li - 31 : 0;
+            if (lane == 0) sc->lag[q] = lag;
         }
-        const int32_t lag = (c_i > 0.0f) ? li - 31 : 0;
-        if (lane == 0) ws.ibc[grp] = lag;
     }
     __syncthreads();
 #pragma unroll
-    for (int g = 0; g < NG; g++) R.fine[g] = (R.c[g] < -0.97f) ? -ws.ibc[g] : 0;
+    for (int q = 0; q < NQ; q++) R.fine[q] = (R.c[q] < -0.97f) ? -sc->lag[q] : 0;
     return R;
 }
 
@@ -1172,19 +1252,22 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
         const bool gvalid = gpos + 2 * (int64_t)sps <= n_items; // this group's window lies inside the data (:91)
         const float2 *__restrict__ xg = X + (gvalid ? gpos : pos);
 
+        // windows of this round that lie inside the data (:91): the first n_in_data of pos, pos + sps, ...
+        const int64_t fit64 = (n_items - pos) / (int64_t)sps - 1;
+        const int n_in_data = fit64 < 0 ? 0 : (fit64 > 64 ? 64 : (int)fit64);
+        W3AcqScratch *acq = reinterpret_cast<W3AcqScratch *>(L.data);
+
         if (plan_mode == kPlanDetect) { // :752-768, detect_preamble_autocorr :340-366
-            float a[NG][4];
-            w3_detect_round<SF>(xg, gvalid, ws, slot, a);
-#if LORA_W3_PREFETCH & 2
-            w3_touch<SF>(X, gpos + (int64_t)(NG + 1) * sps, gvalid ? gpos : pos, n_items, touched); // this round read symbols 0 .. NG of the scan
-#endif
+            constexpr int NQ = W3Acq<SF>::NQD;
+            float a[NQ][4];
+            w3_detect_round<SF>(X + pos, n_in_data < NQ ? n_in_data : NQ, acq, a);
             if (t0) {
                 W2State St = S;
-                for (int g = 0; g < NG; g++) {
+                for (int g = 0; g < NQ; g++) {
                     if (g > 0 && (St.state != kDetect || !w2_pre_step(St, job, rec_cap, sps))) break;
                     float a0 = a[0][0], a1 = a[0][1], a2 = a[0][2], a3 = a[0][3];
 #pragma unroll
-                    for (int q = 1; q < NG; q++) if (g == q) { a0 = a[q][0]; a1 = a[q][1]; a2 = a[q][2]; a3 = a[q][3]; }
+                    for (int q = 1; q < NQ; q++) if (g == q) { a0 = a[q][0]; a1 = a[q][1]; a2 = a[q][2]; a3 = a[q][3]; }
                     St.energy_threshold = a3 / 2.0f; // :357
                     const float pushed = a2 / (float)sps; // d_pwr_queue.push_back (:360)
                     if (St.npush >= 4u) { St.push_tail[0] = St.push_tail[1]; St.push_tail[1] = St.push_tail[2]; St.push_tail[2] = St.push_tail[3]; St.push_tail[3] = pushed; }
@@ -1230,20 +1313,17 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
         }
 
         if (plan_mode == kPlanSfd) { // :785-818
-            const W3SfdOut fo = w3_sfd_round<SF>(W3SfdArgs{P.down_ifreq, P.up_ifreq_v, P.down_ifreq_avg, P.down_ifreq_sd, P.down_ifreq_dsum, P.sync_a, P.sync_b}, xg,
-                                                 gvalid ? 1 : 0, &ws, slot);
-            slot = __builtin_amdgcn_readfirstlane(fo.slot);
-#if LORA_W3_PREFETCH & 2
-            w3_touch<SF>(X, gpos + (int64_t)NG * sps, gvalid ? gpos : pos, n_items, touched);
-#endif
+            constexpr int NQ = W3Acq<SF>::NQS;
+            const W3SfdOut fo = w3_sfd_round<SF>(W3SfdArgs{P.down_ifreq, P.up_ifreq_v, P.down_ifreq_avg, P.down_ifreq_sd, P.down_ifreq_dsum, P.sync_a, P.sync_b}, X + pos,
+                                                 n_in_data < NQ ? n_in_data : NQ, acq);
             if (t0) {
                 W2State St = S;
-                for (int g = 0; g < NG; g++) {
+                for (int g = 0; g < NQ; g++) {
                     if (g > 0 && (St.state != kFindSfd || !w2_pre_step(St, job, rec_cap, sps))) break;
                     float c = fo.c[0];
                     int32_t fs = fo.fine[0];
 #pragma unroll
-                    for (int q = 1; q < NG; q++) if (g == q) { c = fo.c[q]; fs = fo.fine[q]; }
+                    for (int q = 1; q < NQ; q++) if (g == q) { c = fo.c[q]; fs = fo.fine[q]; }
                     int32_t fine = 0;
                     if (c > 0.96f) { // :792
                         St.state = kPause;
@@ -1254,6 +1334,14 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                     }
                     w2_end_step(St, job, C, recs, trace, kFindSfd, (int32_t)sps + fine, -1, fine, c, t_start); // :816
                     if (St.done || fine != 0) break; // (fine != 0: the later windows started at the wrong sample)
+                }
+                // PAUSE (:820-824) looks at no sample: the step is taken here, behind its own loop-top checks, instead of in a
+                // round of its own (as walker2 does)
+                if (St.state == kPause && !St.done && w2_pre_step(St, job, rec_cap, sps)) {
+                    St.state = kDecodeHeader;
+                    const int32_t consumed = (int32_t)(sps + P.delay_after_sync);
+                    St.att_hdr = St.pos + consumed;
+                    w2_end_step(St, job, C, recs, trace, kPause, consumed, -1, 0, 0.0f, t_start);
                 }
                 W2Plan np;
                 plan_from(St, np);

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LORA_HIP_ABI_VERSION 2   /* 2: lora_hip_set_stream_latency, lora_hip_stream_info, lora_hip_walker_kernel_name */
+#define LORA_HIP_ABI_VERSION 2   /* 2: lora_hip_set_stream_latency, lora_hip_stream_info, lora_hip_walker_kernel_name, lora_hip_window_stats_device, lora_hip_detect_preambles_device */
 
 typedef enum lora_hip_status {
     LORA_HIP_OK = 0,
@@ -245,6 +245,47 @@ void            lora_hip_trace_clear(lora_hip_decoder_t *h);
 lora_hip_status lora_hip_estimate_cfo_device(lora_hip_decoder_t *h, const void *d_iq, size_t total_items,
                                              const int64_t *offsets, size_t n, int mode, float *cfo_hz_out,
                                              void *hip_stream);
+
+/* ---- FFT-domain preamble detection (beyond the reference) --------------------------------------
+ * The reference acquires a packet with a time-domain autocorrelation of adjacent symbols (detect_preamble_autocorr,
+ * decoder_impl.cc:340-366, gate 0.90 at :755) and an instantaneous-frequency correlation against the ideal downchirp (gate
+ * 0.96 at :792); both need the signal above the noise of the whole sample-rate band (nothing acquired at <= 20 dB).
+ * These two calls look where LoRa's processing gain is - the dechirped spectrum of get_shift_fft (:430-464) - and acquire
+ * down to the sensitivity of the spreading factor (SF12: about -20 dB in-band).  No reference behaviour exists to be
+ * identical to: the definition is oracle/preamble_oracle.py (float64), to which the device results are held.
+ *
+ * lora_hip_window_stats_device: for n windows of samples_per_symbol items at offsets[i] (host array, item indices into
+ * d_iq) the peak bin, peak power and total power over the N bins k in [-N/2, N/2) (index k mod N) of the sps-point DFT of
+ * x * d_downchirp ("down": sees upchirps) and of conj(x) * d_downchirp ("up": sees downchirps, bins mirrored).
+ *
+ * lora_hip_detect_preambles_device: scans every stream at one window per symbol; a preamble is a run of >= 4 consecutive
+ * windows whose peak-to-mean ratio peak (N-1) / (total - peak) reaches `threshold` (0: ln N + 4.6) with peak bins agreeing
+ * within +-1; the symbol clock is aligned to the run (a carrier offset is absorbed into the alignment exactly as the
+ * reference's SYNC step absorbs it, :392-413), the SFD is the first pair of aligned windows dominated by downchirps, and
+ * header_pos = SFD + 2.25 symbols (:820-824): feed it to lora_hip_demod_symbols_device at header_pos + k * sps.
+ * cfo_hz: from the opposite displacement of up- and downchirps (resolution bw / 2N).  LORA_HIP_ERR_OVERFLOW when cap is
+ * too small (*n_found = what was found).                                                                            */
+typedef struct lora_hip_window_stats {
+    int32_t bin_down; float peak_down, total_down;
+    int32_t bin_up;   float peak_up, total_up;
+} lora_hip_window_stats_t;
+lora_hip_status lora_hip_window_stats_device(lora_hip_decoder_t *h, const void *d_iq, size_t total_items, const int64_t *offsets,
+                                             size_t n, lora_hip_window_stats_t *out, void *hip_stream);
+typedef struct lora_hip_preamble {
+    int64_t  header_pos;          /* item index within the stream of the first header symbol, on the aligned symbol clock */
+    int64_t  run_pos;             /* item index of the first window of the run                                            */
+    uint32_t stream;
+    uint32_t run_len;             /* windows of the run                                                                   */
+    int32_t  bin;                 /* the run's peak bin before alignment (timing + carrier offset, in bins)               */
+    int32_t  sfd_index;           /* aligned window, counted from the run's first, where the SFD begins                   */
+    float    pmr;                 /* mean peak-to-mean ratio over the run                                                  */
+    float    cfo_bins, cfo_hz;    /* carrier offset estimate                                                               */
+    uint32_t reserved;
+} lora_hip_preamble_t;
+lora_hip_status lora_hip_detect_preambles_device(lora_hip_decoder_t *h, const void *d_iq, size_t total_items,
+                                                 const uint64_t *stream_off, const uint64_t *stream_len, uint32_t n_streams,
+                                                 float threshold, lora_hip_preamble_t *out, size_t cap, size_t *n_found,
+                                                 void *hip_stream);
 
 /* ---- frame validity (beyond the reference) -------------------------------------------------
  * The reference publishes every frame it demodulates and checks nothing: "CRC checks of the payload and header"

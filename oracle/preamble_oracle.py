@@ -1,0 +1,115 @@
+"""TEST INFRASTRUCTURE ONLY -- numpy (float64) restatement of the FFT-domain preamble detector, the part of SURVEY 8(f) N4
+that goes beyond the reference (gr_lora_amd/csrc/lora_detect.hip + lora_hip_detect_preambles_device).
+
+What it replaces: the reference acquires a packet with a time-domain autocorrelation of two adjacent symbols
+(detect_preamble_autocorr, lib/decoder_impl.cc:340-366, gate >= 0.90 at :755) followed by an instantaneous-frequency correlation
+(gate > 0.96 at :792).  Both need the signal well above the noise of the full sample-rate band: SURVEY M7 measures 0 of 6 packets
+acquired at <= 20 dB.  LoRa's processing gain lives in the dechirped spectrum; this detector looks there.  There is no reference
+behaviour to be bit-identical to ("parity unpinned" by construction): the device implementation is held to THIS definition.
+
+Definition (sps samples per symbol, N = 2^SF bins, D = sps / N; |X|^2 is the pruned dechirp spectrum of get_shift_fft,
+:430-464, without its N/2 fold - the N bins k in [-N/2, N/2) of the sps-point DFT of x * d_downchirp):
+  stage A  windows at k * sps, k < len // sps - 1: for the window itself ("down" reference: sees UPCHIRPS) and for its complex
+           conjugate ("up" reference: sees DOWNCHIRPS, bins mirrored) the peak bin, the peak power and the total power;
+           pmr = peak * (N - 1) / (total - peak).
+  runs     maximal runs of >= MIN_RUN consecutive windows with pmr_down >= thr whose peak bins agree within +-1 (circular).
+           A window cut anywhere out of a train of identical upchirps holds one full cyclically shifted chirp: the preamble
+           gives (preamble_len - 1) such windows whatever the cut.
+  align    tau = bin * D samples (bin = the run's most frequent peak bin): windows moved EARLIER by tau see the upchirps
+           at bin 0.  (A carrier offset moves the peak like a timing offset does; the alignment absorbs it, as the reference's
+           SYNC step does, :392-413.)
+  stage B  aligned windows a0 + j * sps over the run and SFD_REACH symbols past it, both references.  The SFD is the first j
+           with pmr_up >= thr, peak_up > peak_down, and the same for j + 1 (two whole downchirps).
+  result   header_pos = a_j + 2 sps + sps / 4 (the 2.25 downchirps, :820-824), peak-to-mean ratio of the run, cfo_bins =
+           signed(bin_up at the SFD) / 2 (up- and downchirps move in opposite directions under a carrier offset).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+MIN_RUN = 4
+SFD_REACH = 6
+
+
+def default_threshold(nbins: int) -> float:
+    """peak-to-mean ratio a window must reach: the largest of N exponential noise bins averages ln N + 0.58; 4 above that"""
+    return float(np.log(nbins) + 4.6)
+
+
+def _spectrum(win: np.ndarray, down: np.ndarray, nbins: int) -> np.ndarray:
+    sps = win.size
+    F = np.fft.fft(win.astype(np.complex128) * down.astype(np.complex128))
+    X = np.concatenate([F[: nbins // 2], F[sps - nbins // 2:]])   # bins 0 .. N/2-1, -N/2 .. -1 (the reference's d_tmp layout, :447-449)
+    return (X.real ** 2 + X.imag ** 2)
+
+
+def window_stats(iq: np.ndarray, pos: int, down: np.ndarray, nbins: int):
+    """(bin_down, peak_down, total_down, bin_up, peak_up, total_up) of the window at pos"""
+    sps = down.size
+    w = iq[pos:pos + sps]
+    pd = _spectrum(w, down, nbins)
+    pu = _spectrum(np.conj(w), down, nbins)
+    bd, bu = int(np.argmax(pd)), int(np.argmax(pu))
+    return bd, float(pd[bd]), float(pd.sum()), bu, float(pu[bu]), float(pu.sum())
+
+
+def _pmr(peak, total, nbins):
+    rest = total - peak
+    return peak * (nbins - 1) / rest if rest > 0 else np.inf
+
+
+def _circ(a, b, n):
+    d = abs(a - b) % n
+    return min(d, n - d)
+
+
+def detect(iq: np.ndarray, down: np.ndarray, nbins: int, threshold: float | None = None):
+    """-> list of dicts: header_pos, run_start (window index), run_len, bin, pmr, sfd_index, cfo_bins"""
+    iq = np.asarray(iq)
+    sps = down.size
+    D = sps // nbins
+    thr = default_threshold(nbins) if threshold is None else float(threshold)
+    K = iq.size // sps - 1
+    if K < MIN_RUN:
+        return []
+    A = [window_stats(iq, k * sps, down, nbins) for k in range(K)]
+    good = [_pmr(a[1], a[2], nbins) >= thr for a in A]
+    out = []
+    k = 0
+    while k < K:
+        if not good[k]:
+            k += 1
+            continue
+        e = k + 1
+        while e < K and good[e] and _circ(A[e][0], A[e - 1][0], nbins) <= 1:
+            e += 1
+        if e - k >= MIN_RUN:
+            bins = [A[i][0] for i in range(k, e)]
+            b = max(set(bins), key=lambda v: (bins.count(v), -v))           # most frequent; ties: the smallest bin
+            tau = b * D                                                       # bins 0 .. N-1: the window starts tau samples into a chirp
+            a0 = k * sps - tau
+            if a0 < 0:
+                a0 += sps
+            pmr_run = float(np.mean([_pmr(A[i][1], A[i][2], nbins) for i in range(k, e)]))
+            found = None
+            n_al = (e - k) + SFD_REACH
+            B = []
+            for j in range(n_al + 1):
+                p = a0 + j * sps
+                if p + sps > iq.size:
+                    break
+                B.append(window_stats(iq, p, down, nbins))
+            for j in range(len(B) - 1):
+                s0, s1 = B[j], B[j + 1]
+                if (_pmr(s0[4], s0[5], nbins) >= thr and s0[4] > s0[1] and _pmr(s1[4], s1[5], nbins) >= thr and s1[4] > s1[1]):
+                    found = j
+                    break
+            if found is not None:
+                bu = B[found][3]
+                sb = bu if bu < nbins // 2 else bu - nbins
+                out.append(dict(header_pos=int(a0 + found * sps + 2 * sps + sps // 4), run_start=k, run_len=e - k, bin=int(b), pmr=pmr_run,
+                                sfd_index=int(found), cfo_bins=-0.5 * sb))
+                k = max(e, (a0 + (found + 2) * sps) // sps)                  # go on behind the SFD
+                continue
+        k = e
+    return out

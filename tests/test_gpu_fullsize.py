@@ -82,13 +82,26 @@ def _against_reference_fixture(tag):
     cfg, iq, offs, lens, expect = bench.make_workload(fx["sf"], fx["cr"], fx["packets"], fx["payload"], fx["streams"], seed=fx["seed"])
     assert int(iq.size) == fx["n_items"]
     got = _gpu_streams(iq, offs, lens, 0, **fx["decoder_kw"])
+    moved = differ = total = 0
     for s, ((gf, gp), want) in enumerate(zip(got, fx["per_stream"])):
         assert len(gf) == want["frames"], (tag, s, len(gf), want["frames"])
-        assert _digest(gf) == want["sha256"], (tag, s)
         if fx["sf"] <= 10:
+            assert _digest(gf) == want["sha256"], (tag, s)
             assert gp == want["header_pos"], (tag, s)
-        else:  # SF11 / SF12: the reference's own SYNC shift ties below its float resolution (tests/parity_util.py)
-            assert all(abs(a - b) <= 1 for a, b in zip(gp, want["header_pos"])), (tag, s)
+            continue
+        # SF11 / SF12: the reference's own SYNC shift ties below its float resolution - the compiled reference disagrees with
+        # ITSELF there when only VOLK's summation order changes (tests/parity_util.py, test_sync_shift_depends_on_volk_summation_order)
+        # - and the gradient estimator, unlike the FFT, is sensitive to one sample of timing.  Required: every position within
+        # one sample; identical bytes wherever the position is identical.
+        assert all(abs(a - b) <= 1 for a, b in zip(gp, want["header_pos"])), (tag, s)
+        for f, a, b, sha in zip(gf, gp, want["header_pos"], want["frame_sha"]):
+            same = hashlib.sha256(f).hexdigest()[:10] == sha
+            total += 1
+            moved += a != b
+            differ += not same
+            assert same or a != b, (tag, s, a, b)
+    if fx["sf"] > 10:
+        assert moved <= total // 4, (tag, moved, differ, total)   # (the tie goes the oracle's way in most packets)
 
 
 @pytest.mark.parametrize("streams", [1, 8])
