@@ -1266,7 +1266,7 @@ lora_hip_status lora_hip_detect_preambles_device(lora_hip_decoder_t *h, const vo
     *n_found = 0;
     HIP_TRY(h, hipSetDevice(h->device));
     const int64_t sps = h->P.sps, N = h->P.nbins, D = h->P.decim;
-    const float thr = threshold > 0.0f ? threshold : (float)(std::log((double)N) + 4.6);
+    const float thr = threshold > 0.0f ? threshold : (float)(std::log((double)N) + 3.0);
     constexpr int64_t kMinRun = 4, kSfdReach = 6;
     hipStream_t st = (hipStream_t)hip_stream;
     auto pmr = [&](float peak, float total) { const float rest = total - peak; return rest > 0.0f ? peak * (float)(N - 1) / rest : INFINITY; };

@@ -763,10 +763,10 @@ __device__ __forceinline__ void w3_tables_to_lds(const DevParams &P, const W3Lds
 #define LORA_W3_SFD_INLINE __attribute__((noinline))
 #endif
 #ifndef LORA_W3_DET_K
-#define LORA_W3_DET_K 0x4421   // DETECT windows per group and round, one hex digit per SF (SF9 lowest): 1, 2, 4, 4
+#define LORA_W3_DET_K 0x1111   // DETECT windows per group and round, one hex digit per SF (SF9 lowest)
 #endif
 #ifndef LORA_W3_SFD_K
-#define LORA_W3_SFD_K 0x4442   // FIND_SFD windows per group and round: 2, 4, 4, 4
+#define LORA_W3_SFD_K 0x1111   // FIND_SFD windows per group and round
 #endif
 template <int SF> struct W3Acq {
     static constexpr int KD = (LORA_W3_DET_K >> (4 * (SF - 9))) & 15, KS = (LORA_W3_SFD_K >> (4 * (SF - 9))) & 15;

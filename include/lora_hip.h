@@ -259,7 +259,7 @@ lora_hip_status lora_hip_estimate_cfo_device(lora_hip_decoder_t *h, const void *
  * x * d_downchirp ("down": sees upchirps) and of conj(x) * d_downchirp ("up": sees downchirps, bins mirrored).
  *
  * lora_hip_detect_preambles_device: scans every stream at one window per symbol; a preamble is a run of >= 4 consecutive
- * windows whose peak-to-mean ratio peak (N-1) / (total - peak) reaches `threshold` (0: ln N + 4.6) with peak bins agreeing
+ * windows whose peak-to-mean ratio peak (N-1) / (total - peak) reaches `threshold` (0: ln N + 3) with peak bins agreeing
  * within +-1; the symbol clock is aligned to the run (a carrier offset is absorbed into the alignment exactly as the
  * reference's SYNC step absorbs it, :392-413), the SFD is the first pair of aligned windows dominated by downchirps, and
  * header_pos = SFD + 2.25 symbols (:820-824): feed it to lora_hip_demod_symbols_device at header_pos + k * sps.

@@ -32,8 +32,10 @@ SFD_REACH = 6
 
 
 def default_threshold(nbins: int) -> float:
-    """peak-to-mean ratio a window must reach: the largest of N exponential noise bins averages ln N + 0.58; 4 above that"""
-    return float(np.log(nbins) + 4.6)
+    """peak-to-mean ratio a window must reach: the largest of N exponential noise bins averages ln N + 0.58 and exceeds
+    ln N + 3 in 5 % of pure-noise windows; what keeps the false-alarm rate down is the agreement of >= 4 consecutive peak
+    BINS (3 / N per pair by chance) and the SFD check behind it, not this level"""
+    return float(np.log(nbins) + 3.0)
 
 
 def _spectrum(win: np.ndarray, down: np.ndarray, nbins: int) -> np.ndarray:

@@ -89,19 +89,22 @@ def _against_reference_fixture(tag):
             assert _digest(gf) == want["sha256"], (tag, s)
             assert gp == want["header_pos"], (tag, s)
             continue
-        # SF11 / SF12: the reference's own SYNC shift ties below its float resolution - the compiled reference disagrees with
-        # ITSELF there when only VOLK's summation order changes (tests/parity_util.py, test_sync_shift_depends_on_volk_summation_order)
-        # - and the gradient estimator, unlike the FFT, is sensitive to one sample of timing.  Required: every position within
-        # one sample; identical bytes wherever the position is identical.
+        # SF11 / SF12: the reference's own SYNC shift (detect_upchirp, :392-413) ties between adjacent samples below the resolution
+        # of its float sum - the compiled reference disagrees with ITSELF in every SF12 packet when only VOLK's summation order
+        # changes (tests/test_ref_pin.py::test_sync_shift_depends_on_volk_summation_order) - and the device's closed form
+        # (double precision) lands on the other side of that tie from the sequential-sum build the fixture was made with: every
+        # header one sample beside it (tools/r03_diag_sf11.py).  The FFT demodulators do not care; the gradient estimator does at
+        # CR 4/5, where no FEC absorbs a flipped bin: 4-7 % of those frames differ, none at CR 4/8.  Required here: every position
+        # within one sample, and no more differing frames than that.
         assert all(abs(a - b) <= 1 for a, b in zip(gp, want["header_pos"])), (tag, s)
         for f, a, b, sha in zip(gf, gp, want["header_pos"], want["frame_sha"]):
             same = hashlib.sha256(f).hexdigest()[:10] == sha
             total += 1
             moved += a != b
             differ += not same
-            assert same or a != b, (tag, s, a, b)
+            assert same or a != b, (tag, s, a, b)        # identical timing => identical bytes
     if fx["sf"] > 10:
-        assert moved <= total // 4, (tag, moved, differ, total)   # (the tie goes the oracle's way in most packets)
+        assert differ <= (total // 10 if fx["cr"] < 3 else 0), (tag, moved, differ, total)
 
 
 @pytest.mark.parametrize("streams", [1, 8])

@@ -91,7 +91,7 @@ def test_implicit_many_packets_segments_off(oracle_mod, sf, demod):
     cfg = synth.TxConfig(sf=sf, cr=3, crc=False, implicit=True)
     rng = np.random.default_rng(900 + 10 * sf + demod)
     payloads = [bytes(rng.integers(0, 256, int(rng.integers(3, 40)), dtype=np.uint8)) for _ in range(14)]
-    st = synth.build_stream(payloads, cfg, rng=rng, gap_symbols=(3.0, 9.0), noise_sigma=synth.awgn_sigma_for_snr(30.0, cfg))
+    st = synth.build_stream(payloads, cfg, rng=rng, gap_symbols=(3.0, 9.0), noise_sigma=synth.awgn_sigma_for_snr(40.0, cfg))   # (the reference's preamble gate needs ~35 dB in-band at 8x oversampling)
     kw = dict(sf=sf, cr=3, crc=False, implicit=True)
     o = oracle_mod.Oracle(demod=demod, **kw)
     o.run(st.iq)

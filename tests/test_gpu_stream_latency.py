@@ -80,7 +80,7 @@ def test_latency_bounded_passes_equal_batch_decode_noisy():
     cfg = synth.TxConfig(sf=8, cr=2)
     rng = np.random.default_rng(17)
     payloads = [bytes(rng.integers(0, 256, int(rng.integers(5, 60)), dtype=np.uint8)) for _ in range(12)]
-    st = synth.build_stream(payloads, cfg, rng=rng, gap_symbols=(1.0, 9.0), noise_sigma=synth.awgn_sigma_for_snr(12.0, cfg), tail_symbols=8.0)
+    st = synth.build_stream(payloads, cfg, rng=rng, gap_symbols=(1.0, 9.0), noise_sigma=synth.awgn_sigma_for_snr(40.0, cfg), tail_symbols=8.0)
     dev = torch.from_numpy(st.iq.view(np.float32)).to("cuda:0")
     hb = capi.Handle(sf=8, cr=2)
     hb.decode_device(dev.data_ptr(), st.iq.size, [0], [st.iq.size], torch.cuda.current_stream().cuda_stream)
