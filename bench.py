@@ -109,6 +109,11 @@ def make_gateway_workload(channels, seconds=2.0, sf=9):
 
 
 # --------------------------------------------------------------------------------------------- CPU baseline
+def synth_payload_symbols(n_bytes, cfg):
+    from gr_lora_amd import synth
+    return synth.payload_symbol_count(n_bytes, cfg.sf, cfg.cr, cfg.reduced_rate)
+
+
 def cpu_baseline(cfg, iq, offs, lens, budget_s=20.0):
     """The reference decoder's CPU path timed beside the GPU: the C restatement of lib/decoder_impl.cc (oracle/), built
     -O3 -march=native on THIS host, same input already in RAM, steady clock around the stream -> frames
@@ -241,6 +246,8 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="passes alternate between TWO HIP streams: the walker kernel of pass k+1 starts on the CUs that "
                     "pass k's shorter jobs have left (a streaming receiver's mode; not the default: the per-kernel HIP-event durations then "
                     "include the time a kernel shares the device with its neighbour, and roofline.frac is computed from them)")
+    ap.add_argument("--split", action="store_true", help="config 2 / 3 as ONE stream split over the ranks by sample range (SURVEY 8(e), second clause: "
+                    "gr_lora_amd.gather.split_stream_ranges - margins on both sides of every cut, frames de-duplicated by header position): strong scaling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -274,9 +281,22 @@ def main():
         wkey = "cfg4-sf%d-%gs" % (sf, args.seconds)
     else:
         packets = args.packets if args.packets is not None else (1024 if args.config == 2 else 256)
-        cfg, iq, offs, lens, expect = make_workload(sf, args.cr, packets, args.payload, min(args.streams, packets), seed=(2 if args.config == 2 else 100 * sf + 4) + 1000 * rank)
+        if args.split:
+            args.streams = 1
+        cfg, iq, offs, lens, expect = make_workload(sf, args.cr, packets, args.payload, min(args.streams, packets), seed=(2 if args.config == 2 else 100 * sf + 4) + (0 if args.split else 1000 * rank))
         wl = "SF%d CR4/%d BW125k fs1M, %d packets x %d B payload per GPU, %d stream(s)" % (sf, 4 + args.cr, packets, args.payload, min(args.streams, packets))
         wkey = "cfg%d-sf%d-cr%d-%dx%dB-%dstreams" % (args.config, sf, args.cr, packets, args.payload, min(args.streams, packets))
+    if args.demod != 2:
+        wkey += "-demod%d" % args.demod        # (profiles/*pmc_traffic*.json are keyed by workload AND demodulator: another kernel)
+    split_ranges = None
+    if args.split and args.config != 4:
+        # every rank holds the same capture and decodes its sample range of it (+ margins); frames are owned by header position
+        split_ranges = gather.split_stream_ranges(int(iq.size), world, cfg.sps, max_packet_symbols=8 + synth_payload_symbols(args.payload + 2, cfg))
+        s0, s1, _lo, _hi = split_ranges[rank]
+        whole_items = int(iq.size)
+        iq, offs, lens = np.ascontiguousarray(iq[s0:s1]), [0], [s1 - s0]
+        wl += "; ONE stream of %d items split over %d rank(s) by sample range" % (whole_items, world)
+        wkey += "-split%d" % world
     n_items = int(iq.size)
     n_frames_expected = sum(len(e) for e in expect)
     kw = dict(samp_rate=cfg.samp_rate, bandwidth=cfg.bw, sf=cfg.sf, cr=4, crc=True, reduced_rate=cfg.reduced_rate, device=local_rank, demod=args.demod)
@@ -337,6 +357,15 @@ def main():
     for slots, counts in kept:
         r = rank if len(counts) > 1 else 0
         got, full = {}, {}
+        if split_ranges is not None:   # the union of every rank's OWN frames, in stream order, must be the whole capture's frames
+            own = []
+            for rr in range(len(counts)):
+                st_r, _sp, lo, hi = split_ranges[rr]
+                own += gather.owned(gather.unpack_frames(slots[rr], counts[rr]), st_r, lo, hi)
+            own.sort(key=lambda t: t[2])
+            got[0] = [b[15:] for b, _s, _h in own]
+            verified = verified and check(got, None)
+            continue
         for b, sid, _hp in gather.unpack_frames(slots[r], counts[r]):
             got.setdefault(sid, []).append(b[15:])
             full.setdefault(sid, []).append(b)
@@ -359,12 +388,12 @@ def main():
         elapsed = float(t.item())
         tot = torch.tensor([n_items], dtype=torch.int64, device=dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_items = int(tot.item())
+        total_items = whole_items if split_ranges is not None else int(tot.item())   # (split: the capture counts once, not the margins)
         v = torch.tensor([1 if verified else 0], dtype=torch.int64, device=dev)
         dist.all_reduce(v, op=dist.ReduceOp.MIN)
         verified = bool(v.item())
     else:
-        total_items = n_items
+        total_items = whole_items if split_ranges is not None else n_items
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -377,7 +406,7 @@ def main():
             "metric": "IQ Msamples/s demodulated", "value": round(value, 3), "unit": "Msamples/s",
             "symbols_per_s": round(value * 1e6 / cfg.sps, 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": ("strong" if split_ranges is not None else "weak"), "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "workload_key": wkey, "items_per_gpu": n_items, "demod": ["grad", "fft", "fft_compat"][args.demod],
                        "bit_exact_vs_expected": verified,
                        "expected": ("frames the compiled reference (oracle/_ref, gradient demodulator) published on this IQ: tests/golden/fullsize_ref.json"

@@ -246,3 +246,40 @@ class PassPipeline:
 def shard_streams(n_streams: int, rank: int, world: int) -> List[int]:
     """Static partition: stream c -> rank c mod world."""
     return [c for c in range(n_streams) if c % world == rank]
+
+
+# ---- one long stream over several ranks (SURVEY 8(e), second clause) ---------------------------------------------------
+def split_stream_ranges(n_items: int, world: int, sps: int, max_packet_symbols: int, guard_symbols: int = 16, cuts: Sequence[int] = ()):
+    """Splits ONE stream of n_items over `world` ranks: rank r decodes items [start_r, stop_r) with a decoder of its own
+    and KEEPS the frames whose first header symbol lies in [own_lo_r, own_hi_r).  Returns [(start, stop, own_lo, own_hi)].
+
+    own_hi_r = own_lo_{r+1} = the cut between the ranks: n_items * (r + 1) / world, moved forward to the next of `cuts`
+    (gap starts from the envelope pre-pass, Handle.gap_starts_device) when one lies within a quarter of a share - a cut
+    inside a gap meets the next rank's decoder where the serial decoder is too: idle in DETECT.  A rank starts guard_symbols
+    (>= the 12.25 symbols of preamble + SFD) before its first owned header position, so that it sees the whole preamble of
+    every packet it owns, and runs max_packet_symbols past its last one, so that it sees the end of it; frames decoded in
+    those margins belong to the neighbour and are dropped (`owned`).  Unlike the segment stitcher inside one GPU
+    (lora_stitch.hpp) nothing is probed across ranks: a rank's decoder starts fresh, so the loratap SNR byte (from the last
+    four DETECT windows, decoder_impl.cc:360,:377-383) of its first frames and a header decoded with a stale d_phdr.cr (:655)
+    can differ from the serial decoder's; header positions and frame bytes behind the loratap header are the serial ones."""
+    if world <= 0 or n_items < 0:
+        raise ValueError("bad split")
+    cuts = sorted(int(c) for c in cuts)
+    share = n_items / world
+    bounds = [0]
+    for r in range(1, world):
+        b = int(round(r * share))
+        nxt = [c for c in cuts if b <= c <= b + share / 4]
+        b = nxt[0] if nxt else b
+        bounds.append(max(bounds[-1], min(b, n_items)))
+    bounds.append(n_items)
+    out = []
+    for r in range(world):
+        lo, hi = bounds[r], bounds[r + 1]
+        out.append((max(0, lo - guard_symbols * sps) if r else 0, min(n_items, hi + max_packet_symbols * sps) if r + 1 < world else n_items, lo, hi))
+    return out
+
+
+def owned(frames: Sequence[Tuple[bytes, int, int]], start: int, own_lo: int, own_hi: int) -> List[Tuple[bytes, int, int]]:
+    """frames = (blob, stream, header_pos relative to the rank's range start) -> the rank's own ones with ABSOLUTE header_pos"""
+    return [(b, s, hp + start) for b, s, hp in frames if own_lo <= hp + start < own_hi]

@@ -176,3 +176,54 @@ def test_async_gather_single_process():
     assert g.collect() is None
     with pytest.raises(ValueError):
         g.submit(gather.pack_frames(frames * 3, 6))
+
+
+# ---- one long stream over two ranks (second clause): gather.split_stream_ranges / owned ----------------
+def _split_worker(rank, world, port, q):
+    import numpy as np
+    from gr_lora_amd import synth
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = synth.TxConfig(sf=7, cr=4)
+    rng = np.random.default_rng(77)                       # (the same stream on every rank: what a shared capture is)
+    payloads = [bytes(rng.integers(0, 256, int(rng.integers(4, 60)), dtype=np.uint8)) for _ in range(40)]
+    st = synth.build_stream(payloads, cfg, rng=rng, gap_symbols=(0.0, 7.0))     # back-to-back packets among them: cuts fall inside packets
+    for cuts in ((), [int(p) - 14 * cfg.sps for p in st.header_starts]):         # raw cuts, and cuts snapped to "gap starts"
+        ranges = gather.split_stream_ranges(st.iq.size, world, cfg.sps, max_packet_symbols=8 + 8 * 20, cuts=cuts)
+        start, stop, lo, hi = ranges[rank]
+        o = O.Oracle(sf=7, cr=4, demod=O.DEMOD_FFT_COMPAT)  # the rank's decoder (the device decoder on a GPU; its C restatement here)
+        o.run(st.iq[start:stop])
+        mine = gather.owned([(f, 0, p) for f, p in zip(o.frames(), o.frame_positions())], start, lo, hi)
+        allf = gather.gather_frames(mine, torch.device("cpu"))
+        q.put((rank, bool(cuts), ranges, [[(b[15:], hp) for b, _s, hp in fr] for fr in allf]))
+    dist.destroy_process_group()
+
+
+def test_single_stream_split_over_two_ranks_equals_serial(oracle_mod):
+    import numpy as np
+    from gr_lora_amd import synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_split_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cfg = synth.TxConfig(sf=7, cr=4)
+    rng = np.random.default_rng(77)
+    payloads = [bytes(rng.integers(0, 256, int(rng.integers(4, 60)), dtype=np.uint8)) for _ in range(40)]
+    st = synth.build_stream(payloads, cfg, rng=rng, gap_symbols=(0.0, 7.0))
+    o = oracle_mod.Oracle(sf=7, cr=4, demod=oracle_mod.DEMOD_FFT_COMPAT)
+    o.run(st.iq)
+    serial = [(f[15:], p) for f, p in zip(o.frames(), o.frame_positions())]
+    assert len(serial) == 40
+    for rank, snapped, ranges, per_rank in res:
+        assert ranges[0][3] == ranges[1][2] and ranges[0][1] > ranges[0][3] and ranges[1][0] < ranges[1][2]   # margins on both sides of the cut
+        merged = sorted(per_rank[0] + per_rank[1], key=lambda t: t[1])
+        assert merged == serial, (rank, snapped, len(merged))                 # every frame once, serial bytes, serial positions
+        assert len(per_rank[0]) > 5 and len(per_rank[1]) > 5

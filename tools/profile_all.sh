@@ -11,10 +11,17 @@ PROFILE_STEPS=8 tools/profile_round.sh sf9 --config 3 --sf 9
 PROFILE_STEPS=8 tools/profile_round.sh sf10 --config 3 --sf 10
 PROFILE_STEPS=6 tools/profile_round.sh sf11 --config 3 --sf 11
 PROFILE_STEPS=4 tools/profile_round.sh sf12 --config 3 --sf 12
+# the reference's shipped demodulator (gradient, decoder_impl.cc:499) on the same workloads: its own kernels
+tools/profile_round.sh sf7_grad --demod 0
+PROFILE_STEPS=8 tools/profile_round.sh sf9_grad --config 3 --sf 9 --demod 0
+PROFILE_STEPS=4 tools/profile_round.sh sf12_grad --config 3 --sf 12 --demod 0
 python bench.py 2>/dev/null | tail -1 > gpurun_out/default_line.json
 python bench.py --path work 2>/dev/null | tail -1 > gpurun_out/work_line.json
 python bench.py --config 4 --steps 30 --warmup 5 2>/dev/null | tail -1 > gpurun_out/cfg4_line.json
 python bench.py --config 4 --seconds 8 --steps 30 --warmup 5 2>/dev/null | tail -1 > gpurun_out/cfg4_8s_line.json
+python bench.py --config 4 --seconds 2 --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/cfg4_2s_line.json
+python bench.py --demod 0 2>/dev/null | tail -1 > gpurun_out/default_grad_line.json
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/torchrun1_line.json
 python bench.py --streams 1 --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/streams1_line.json
 } > gpurun_out/profile_all.log 2>&1
 # keep what travels back small: the per-dispatch traces are not needed once summarised... (kernel_stats + counter_collection csv only)
