@@ -230,7 +230,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4])
-    ap.add_argument("--path", default="device", choices=["device", "work"])
+    ap.add_argument("--path", default="device", choices=["device", "work", "mux"])
     ap.add_argument("--sf", type=int, default=None)
     ap.add_argument("--cr", type=int, default=4)
     ap.add_argument("--packets", type=int, default=None)
@@ -329,6 +329,11 @@ def main():
             return all(len(full.get(s, [])) == e["frames"] and _digest(full.get(s, [])) == e["sha256"] for s, e in enumerate(ref_fix["per_stream"]))
         return all(frames_by_stream.get(s, []) == expect[s] for s in range(len(offs)))
 
+    if args.path == "mux":
+        res = run_mux_path(args, torch, capi, cfg, iq, offs, lens, kw, expect, wl)
+        if rank == 0:
+            print(json.dumps(res))
+        return
     if args.path == "work":
         res = run_work_path(args, torch, capi, cfg, iq, offs, lens, kw, expect, wl)
         if rank == 0:
@@ -444,6 +449,74 @@ def main():
         hk.close()
     if use_dist:
         dist.destroy_process_group()
+
+
+def run_mux_path(args, torch, capi, cfg, iq, offs, lens, kw, expect_all, wl):
+    """--path mux: the gateway as a flowgraph runs it - every stream of the workload is a channel of ONE lora_hip_mux, fed
+    round-robin in calls of --chunk items out of page-locked host memory; one device pass per --batch items of every channel.
+    Beside it: the same channels through one lora_hip_work handle each (what N decoder blocks amount to without the mux)."""
+    nch = len(offs)
+    pinned = torch.empty(2 * int(iq.size), dtype=torch.float32, pin_memory=True)
+    pinned.numpy()[:] = iq.view(np.float32)
+    src = pinned.numpy().view(np.complex64)
+    chunk, batch = min(args.chunk, 1 << 18), min(args.batch, 1 << 20)
+
+    def feed(work, drain, flush):
+        got = {c: [] for c in range(nch)}
+        pos = [0] * nch
+        t0 = time.perf_counter()
+        live = True
+        while live:
+            live = False
+            for c in range(nch):
+                if pos[c] < lens[c]:
+                    m = min(chunk, lens[c] - pos[c])
+                    work(c, src[offs[c] + pos[c]:offs[c] + pos[c] + m])
+                    pos[c] += m
+                    live = True
+            for b, i, c in drain():
+                got[c].append(b[15:])
+        flush()
+        for b, i, c in drain():
+            got[c].append(b[15:])
+        return time.perf_counter() - t0, got
+
+    def one_mux():
+        m = capi.Mux(nch, batch_items=batch, **kw)
+        dt, got = feed(m.work, lambda: [(b, i, i.stream) for b, i in m.drain()], m.flush)
+        p = m.passes()
+        m.close()
+        return dt, got, p[0]
+
+    def one_handles():
+        hs = [capi.Handle(batch_items=batch, **kw) for _ in range(nch)]
+        def drain():
+            out = []
+            for c, h in enumerate(hs):
+                out += [(b, i, c) for b, i in h.drain()]
+            return out
+        def flush():
+            for h in hs:
+                h.flush()
+        dt, got = feed(lambda c, a: hs[c].work(a), drain, flush)
+        for h in hs:
+            h.close()
+        return dt, got
+
+    _dt, got, passes = one_mux()
+    verified = all(got[c] == expect_all[c] for c in range(nch))
+    t_mux = float(np.median([one_mux()[0] for _ in range(max(3, min(args.steps, 5)))]))
+    _dt, goth = one_handles()
+    verified_h = all(goth[c] == expect_all[c] for c in range(nch))
+    t_h = float(np.median([one_handles()[0] for _ in range(3)]))
+    n = int(sum(lens))
+    return {"metric": "IQ Msamples/s demodulated through lora_hip_mux (host buffers in, PCIe included)", "value": round(n / t_mux / 1e6, 3), "unit": "Msamples/s",
+            "n_gpus": 1, "steps": max(3, min(args.steps, 5)), "warmup": 1, "ms_per_step": round(t_mux * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl, "path": "mux (%d channels through one lora_hip_mux, %d items per call, device passes of %d items per channel)" % (nch, chunk, batch),
+                       "device_passes": passes, "bit_exact_vs_expected": verified},
+            "one_handle_per_channel": {"value": round(n / t_h / 1e6, 3), "unit": "Msamples/s", "bit_exact_vs_expected": verified_h,
+                                       "note": "the same channels and call pattern through %d lora_hip_work handles: one device pass per channel and chunk" % nch}}
 
 
 def run_work_path(args, torch, capi, cfg, iq, offs, lens, kw, expect_all, wl):

@@ -24,6 +24,8 @@ EXPORTS = [
     "lora_hip_decode_device", "lora_hip_frames_available", "lora_hip_poll_frame", "lora_hip_drain_frames", "lora_hip_drain_slots", "lora_hip_demod_symbols_device", "lora_hip_demod_symbols_ex_device",
     "lora_hip_last_timing", "lora_hip_last_plan", "lora_hip_gap_starts_device", "lora_hip_decode_device_begin", "lora_hip_decode_device_end", "lora_hip_decode_device_prepass", "lora_hip_trace", "lora_hip_trace_clear", "lora_hip_check_frame", "lora_hip_estimate_cfo_device",
     "lora_hip_set_stream_latency", "lora_hip_stream_info", "lora_hip_walker_kernel_name", "lora_hip_window_stats_device", "lora_hip_detect_preambles_device",
+    "lora_hip_mux_create", "lora_hip_mux_destroy", "lora_hip_mux_work", "lora_hip_mux_flush", "lora_hip_mux_set_latency", "lora_hip_mux_frames_available",
+    "lora_hip_mux_poll_frame", "lora_hip_mux_passes", "lora_hip_mux_last_error",
 ]
 
 
@@ -147,6 +149,18 @@ def load():
     L.lora_hip_detect_preambles_device.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_uint32, C.c_float, C.POINTER(Preamble), C.c_size_t, C.POINTER(C.c_size_t), vp]
     L.lora_hip_walker_kernel_name.argtypes = [vp]
     L.lora_hip_walker_kernel_name.restype = C.c_char_p
+    L.lora_hip_mux_create.argtypes = [C.POINTER(Config), C.c_uint32, C.POINTER(vp)]
+    L.lora_hip_mux_destroy.argtypes = [vp]
+    L.lora_hip_mux_destroy.restype = None
+    L.lora_hip_mux_work.argtypes = [vp, C.c_uint32, vp, C.c_size_t]
+    L.lora_hip_mux_flush.argtypes = [vp]
+    L.lora_hip_mux_set_latency.argtypes = [vp, C.c_float]
+    L.lora_hip_mux_frames_available.argtypes = [vp]
+    L.lora_hip_mux_frames_available.restype = C.c_size_t
+    L.lora_hip_mux_poll_frame.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(FrameInfo)]
+    L.lora_hip_mux_passes.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.lora_hip_mux_last_error.argtypes = [vp]
+    L.lora_hip_mux_last_error.restype = C.c_char_p
     L.lora_hip_set_stream_latency.argtypes = [vp, C.c_float]
     L.lora_hip_stream_info.argtypes = [vp, C.POINTER(StreamInfo)]
     L.lora_hip_check_frame.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(FrameCheck)]
@@ -391,6 +405,58 @@ class Handle:
 
     def trace_clear(self):
         self.L.lora_hip_trace_clear(self.h)
+
+
+class Mux:
+    """lora_hip_mux_*: n_channels independent decoders fed in any order, decoded by ONE device pass per chunk (the gateway flowgraph)."""
+
+    def __init__(self, n_channels, samp_rate=1e6, bandwidth=125000, sf=7, implicit=False, cr=4, crc=True, reduced_rate=False,
+                 disable_drift_correction=False, device=0, demod=DEMOD_FFT_COMPAT, flags=0, segment_symbols=0, batch_items=0):
+        self.L = load()
+        cfg = Config(struct_size=C.sizeof(Config), samp_rate=float(samp_rate), bandwidth=int(bandwidth), sf=int(sf), implicit=int(bool(implicit)), cr=int(cr),
+                     crc=int(bool(crc)), reduced_rate=int(bool(reduced_rate)), disable_drift_correction=int(bool(disable_drift_correction)), device=int(device),
+                     demod=int(demod), flags=int(flags), segment_symbols=int(segment_symbols), batch_items=int(batch_items))
+        self.h = C.c_void_p()
+        st = self.L.lora_hip_mux_create(C.byref(cfg), int(n_channels), C.byref(self.h))
+        if st != 0:
+            raise LoraHipError(st, "%s (%s)" % (self.L.lora_hip_strerror(st).decode(), self.L.lora_hip_last_error(None).decode()))
+        self.n_channels = int(n_channels)
+
+    def _check(self, st):
+        if st != 0:
+            raise LoraHipError(st, "%s (%s)" % (self.L.lora_hip_strerror(st).decode(), (self.L.lora_hip_mux_last_error(self.h) or b"").decode()))
+
+    def work(self, channel: int, iq: np.ndarray):
+        a = np.ascontiguousarray(iq, dtype=np.complex64)
+        self._check(self.L.lora_hip_mux_work(self.h, int(channel), a.ctypes.data, a.size))
+
+    def flush(self):
+        self._check(self.L.lora_hip_mux_flush(self.h))
+
+    def set_latency(self, ms: float):
+        self._check(self.L.lora_hip_mux_set_latency(self.h, float(ms)))
+
+    def passes(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._check(self.L.lora_hip_mux_passes(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def drain(self) -> List[Tuple[bytes, FrameInfo]]:
+        out = []
+        buf = (C.c_uint8 * 320)()
+        while self.L.lora_hip_mux_frames_available(self.h):
+            n = C.c_size_t(0)
+            info = FrameInfo()
+            self._check(self.L.lora_hip_mux_poll_frame(self.h, buf, 320, C.byref(n), C.byref(info)))
+            out.append((bytes(buf[: n.value]), info))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lora_hip_mux_destroy(self.h)
+            self.h = None
+
+    __del__ = close
 
 
 class Channelizer:

@@ -1118,6 +1118,257 @@ lora_hip_status lora_hip_flush(lora_hip_decoder_t *h)
     return LORA_HIP_OK;
 }
 
+// ---- lora_hip_mux: many channels, one pass (the gateway flowgraph; see include/lora_hip.h) ------------------------------
+// Device layout: two buffers of n_channels regions [ tail area (tailcap items, right-aligned) | chunk (batch items) ]; the
+// pass over buffer b decodes n_channels streams (region c: the last tail_len[c] items of the tail area + the chunk's fill[c]
+// items), while the channels go on filling buffer b ^ 1.  What a pass did not consume of a channel (an unfinished packet) is
+// copied in front of that channel's next chunk when the pass is collected.  Decoder state crossing passes (d_phdr.cr, power
+// queue, absolute position) is carried per channel exactly as lora_hip_work carries it for its one stream.
+struct lora_hip_mux {
+    lora_hip_decoder *h = nullptr;   // tables, kernels, scheduler, frame queue
+    uint32_t n = 0;
+    size_t batch = 0, tailcap = 0, region = 0;
+    DevBuf<float2> dbuf[2];
+    int cur = 0;
+    struct Chan { size_t fill = 0, tail_len = 0; uint32_t cr = 0; PwrState pwr; int64_t host_base = 0; std::vector<float2> ahead; size_t fl_off = 0, fl_len = 0; bool in_pass = false; };
+    std::vector<Chan> ch;
+    hipStream_t copy_st = nullptr, comp_st = nullptr;
+    hipEvent_t up_ev = nullptr, tail_ev = nullptr;
+    bool inflight = false;
+    float max_latency_ms = 50.0f;
+    std::chrono::steady_clock::time_point t_first;
+    bool have_first = false;
+    uint64_t passes = 0, passes_by_latency = 0;
+    std::string err;
+};
+
+#define MUX_TRY(m, expr)                                                                                   \
+    do {                                                                                                   \
+        hipError_t e__ = (expr);                                                                           \
+        if (e__ != hipSuccess) { (m)->err = std::string(#expr) + ": " + hipGetErrorString(e__); return LORA_HIP_ERR_HIP; } \
+    } while (0)
+
+lora_hip_status lora_hip_mux_create(const lora_hip_config_t *cfg, uint32_t n_channels, lora_hip_mux_t **out)
+{
+    if (!cfg || !out || n_channels == 0 || n_channels > 4096) return LORA_HIP_ERR_ARG;
+    *out = nullptr;
+    lora_hip_decoder *h = nullptr;
+    lora_hip_status s = lora_hip_create(cfg, &h);
+    if (s != LORA_HIP_OK) return s;
+    lora_hip_mux *m = new (std::nothrow) lora_hip_mux();
+    if (!m) { lora_hip_destroy(h); return LORA_HIP_ERR_NOMEM; }
+    m->h = h; m->n = n_channels;
+    m->batch = cfg->batch_items ? cfg->batch_items : std::max<size_t>(1u << 18, 64ull * h->P.sps); // (n channels share a pass: smaller chunks than one stream's)
+    m->tailcap = std::max<size_t>(m->batch, 4u * (size_t)h->P.sps);
+    m->region = m->tailcap + m->batch;
+    m->ch.resize(n_channels);
+    for (auto &c : m->ch) c.cr = h->P.ctor_cr;
+    bool ok = hipSetDevice(h->device) == hipSuccess && hipStreamCreateWithFlags(&m->copy_st, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&m->comp_st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&m->up_ev, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&m->tail_ev, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < 2; i++) ok = m->dbuf[i].reserve((size_t)n_channels * m->region) == hipSuccess;
+    if (!ok) { lora_hip_mux_destroy(m); return LORA_HIP_ERR_HIP; }
+    *out = m;
+    return LORA_HIP_OK;
+}
+
+void lora_hip_mux_destroy(lora_hip_mux_t *m)
+{
+    if (!m) return;
+    if (m->h) (void)hipSetDevice(m->h->device);
+    if (m->copy_st) { (void)hipStreamSynchronize(m->copy_st); }
+    if (m->comp_st) { (void)hipStreamSynchronize(m->comp_st); }
+    for (int i = 0; i < 2; i++) m->dbuf[i].release();
+    if (m->up_ev) (void)hipEventDestroy(m->up_ev);
+    if (m->tail_ev) (void)hipEventDestroy(m->tail_ev);
+    if (m->copy_st) (void)hipStreamDestroy(m->copy_st);
+    if (m->comp_st) (void)hipStreamDestroy(m->comp_st);
+    if (m->h) { m->h->pass_open = false; lora_hip_destroy(m->h); }
+    delete m;
+}
+
+const char *lora_hip_mux_last_error(const lora_hip_mux_t *m) { return m ? (m->err.empty() ? m->h->err.c_str() : m->err.c_str()) : g_create_err.c_str(); }
+
+// collects the pass in flight: per channel its decoder state, its frames (published through the handle's queue) and its tail
+static lora_hip_status mux_collect(lora_hip_mux *m)
+{
+    if (!m->inflight) return LORA_HIP_OK;
+    lora_hip_decoder *h = m->h;
+    m->inflight = false;
+    h->pass_open = false;
+    h->err.clear();
+    DeviceEnv env{h, h->pass_iq, h->pass_st};
+    const int rc = lora_hip::decode_end(env, h->pass_streams, h->pass);
+    if (rc != 0) { h->pending.open = false; m->err = h->err.empty() ? "scheduler failed" : h->err; return LORA_HIP_ERR_INTERNAL; }
+    const int prev = m->cur ^ 1; // the buffer the pass ran on
+    bool any_tail = false;
+    for (const StreamDesc &sd : h->pass_streams) {
+        lora_hip_mux::Chan &c = m->ch[sd.id];
+        c.in_pass = false;
+        c.cr = sd.cr_out; c.pwr = sd.pwr;
+        const size_t keep_from = (size_t)std::min<int64_t>(std::max<int64_t>(sd.final_pos, 0), (int64_t)c.fl_len);
+        const size_t tail = c.fl_len - keep_from;
+        c.host_base += (int64_t)keep_from;
+        if (tail > m->tailcap) { m->err = "a packet longer than the tail area of a mux channel: raise batch_items"; return LORA_HIP_ERR_OVERFLOW; }
+        if (tail) {
+            MUX_TRY(m, hipMemcpyAsync(m->dbuf[m->cur].p + (size_t)sd.id * m->region + m->tailcap - tail, m->dbuf[prev].p + c.fl_off + keep_from, tail * sizeof(float2),
+                                      hipMemcpyDeviceToDevice, m->comp_st));
+            any_tail = true;
+        }
+        c.tail_len = tail;
+    }
+    if (any_tail) { // the sources sit in chunk areas the next uploads overwrite: they wait for these copies
+        MUX_TRY(m, hipEventRecord(m->tail_ev, m->comp_st));
+        MUX_TRY(m, hipStreamWaitEvent(m->copy_st, m->tail_ev, 0));
+    }
+    return LORA_HIP_OK;
+}
+
+static lora_hip_status mux_upload(lora_hip_mux *m, uint32_t c, const float2 *src, size_t n)
+{
+    lora_hip_mux::Chan &C = m->ch[c];
+    MUX_TRY(m, hipMemcpyAsync(m->dbuf[m->cur].p + (size_t)c * m->region + m->tailcap + C.fill, src, n * sizeof(float2), hipMemcpyHostToDevice, m->copy_st));
+    C.fill += n;
+    return LORA_HIP_OK;
+}
+
+// launches a pass over what every channel holds (collecting the pass before it), then refills the new chunk from the surplus
+static lora_hip_status mux_rotate(lora_hip_mux *m, bool by_latency)
+{
+    lora_hip_decoder *h = m->h;
+    MUX_TRY(m, hipEventRecord(m->up_ev, m->copy_st));
+    lora_hip_status s = mux_collect(m);
+    if (s != LORA_HIP_OK) return s;
+    std::vector<StreamDesc> &sds = h->pass_streams;
+    sds.clear();
+    uint64_t items = 0;
+    for (uint32_t c = 0; c < m->n; c++) {
+        lora_hip_mux::Chan &C = m->ch[c];
+        const size_t len = C.tail_len + C.fill;
+        if (len < 2u * (size_t)h->P.sps) continue; // (:91: not a work() call's worth yet; it stays where it is)
+        StreamDesc sd{};
+        sd.off = (uint64_t)c * m->region + m->tailcap - C.tail_len; sd.len = len; sd.id = c;
+        sd.cr_in = C.cr; sd.pwr = C.pwr; sd.abs_base = C.host_base;
+        sds.push_back(sd);
+        C.fl_off = (size_t)sd.off; C.fl_len = len; C.in_pass = true;
+        items += len;
+    }
+    if (sds.empty()) return LORA_HIP_OK;
+    MUX_TRY(m, hipStreamWaitEvent(m->comp_st, m->up_ev, 0));
+    h->timing = lora_hip_timing_t{};
+    h->timing.items = items;
+    h->pass_iq = m->dbuf[m->cur].p; h->pass_st = m->comp_st;
+    h->err.clear();
+    DeviceEnv env{h, h->pass_iq, h->pass_st};
+    if (lora_hip::decode_begin(env, sds, h->pass) != 0) { h->pending.open = false; m->err = h->err.empty() ? "scheduler failed" : h->err; return LORA_HIP_ERR_INTERNAL; }
+    h->pass_open = true;
+    m->inflight = true;
+    m->passes++; m->passes_by_latency += by_latency ? 1u : 0u;
+    const int old = m->cur;
+    m->cur ^= 1;
+    m->have_first = false;
+    for (uint32_t c = 0; c < m->n; c++) {
+        lora_hip_mux::Chan &C = m->ch[c];
+        if (!C.in_pass) { // too short to be decoded yet: its samples move along to the new buffer
+            const size_t len = C.tail_len + C.fill;
+            if (len) MUX_TRY(m, hipMemcpyAsync(m->dbuf[m->cur].p + (size_t)c * m->region + m->tailcap - len, m->dbuf[old].p + (size_t)c * m->region + m->tailcap - C.tail_len, len * sizeof(float2),
+                                               hipMemcpyDeviceToDevice, m->copy_st));
+            C.tail_len = len; C.fill = 0;
+        } else { C.fill = 0; C.tail_len = 0; }
+        if (!C.ahead.empty()) { // what the channel delivered beyond its chunk
+            const size_t k = std::min(C.ahead.size(), m->batch);
+            s = mux_upload(m, c, C.ahead.data(), k);
+            if (s != LORA_HIP_OK) return s;
+            MUX_TRY(m, hipStreamSynchronize(m->copy_st)); // (the vector is about to change)
+            C.ahead.erase(C.ahead.begin(), C.ahead.begin() + (ptrdiff_t)k);
+            if (!m->have_first) { m->have_first = true; m->t_first = std::chrono::steady_clock::now(); }
+        }
+    }
+    return LORA_HIP_OK;
+}
+
+lora_hip_status lora_hip_mux_work(lora_hip_mux_t *m, uint32_t channel, const float *iq, size_t n_items)
+{
+    if (!m || channel >= m->n || (!iq && n_items)) return LORA_HIP_ERR_ARG;
+    lora_hip_decoder *h = m->h;
+    MUX_TRY(m, hipSetDevice(h->device));
+    m->err.clear();
+    lora_hip_status s;
+    if (m->inflight && h->pending.open && hipEventQuery(h->ev_done) == hipSuccess) { // finished: publish now
+        s = mux_collect(m);
+        if (s != LORA_HIP_OK) return s;
+    }
+    (void)hipGetLastError();
+    lora_hip_mux::Chan &C = m->ch[channel];
+    const float2 *src = reinterpret_cast<const float2 *>(iq);
+    size_t left = n_items;
+    if (left && C.ahead.empty()) {
+        const size_t k = std::min(left, m->batch - C.fill);
+        if (k) {
+            s = mux_upload(m, channel, src, k);
+            if (s != LORA_HIP_OK) return s;
+            if (!m->have_first) { m->have_first = true; m->t_first = std::chrono::steady_clock::now(); }
+            src += k; left -= k;
+        }
+    }
+    if (left) C.ahead.insert(C.ahead.end(), src, src + left); // this channel is a chunk ahead of the slowest one
+    MUX_TRY(m, hipStreamSynchronize(m->copy_st)); // the caller may reuse its buffer
+    for (;;) { // a pass when every channel's chunk is full (again, while the surplus refills whole chunks)
+        bool all_full = true;
+        for (const auto &c : m->ch) all_full = all_full && c.fill == m->batch;
+        if (!all_full) break;
+        s = mux_rotate(m, false);
+        if (s != LORA_HIP_OK) return s;
+    }
+    if (m->max_latency_ms > 0.0f && m->have_first &&
+        std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - m->t_first).count() >= m->max_latency_ms) {
+        bool any = false;
+        for (const auto &c : m->ch) any = any || (c.fill != 0 && c.tail_len + c.fill >= 2u * (size_t)h->P.sps);
+        if (any) { s = mux_rotate(m, true); if (s != LORA_HIP_OK) return s; }
+    }
+    return LORA_HIP_OK;
+}
+
+lora_hip_status lora_hip_mux_flush(lora_hip_mux_t *m)
+{
+    if (!m) return LORA_HIP_ERR_ARG;
+    MUX_TRY(m, hipSetDevice(m->h->device));
+    lora_hip_status s;
+    for (int guard = 0; guard < 1 << 20; guard++) { // until nothing waits in host memory either
+        s = mux_rotate(m, false);
+        if (s != LORA_HIP_OK) return s;
+        bool more = false;
+        for (const auto &c : m->ch) more = more || !c.ahead.empty() || c.fill != 0;
+        if (!more) break;
+    }
+    s = mux_collect(m);
+    if (s != LORA_HIP_OK) return s;
+    MUX_TRY(m, hipStreamSynchronize(m->comp_st));
+    return LORA_HIP_OK;
+}
+
+lora_hip_status lora_hip_mux_set_latency(lora_hip_mux_t *m, float max_latency_ms)
+{
+    if (!m || !(max_latency_ms >= 0.0f)) return LORA_HIP_ERR_ARG;
+    m->max_latency_ms = max_latency_ms;
+    return LORA_HIP_OK;
+}
+
+size_t lora_hip_mux_frames_available(const lora_hip_mux_t *m) { return m ? m->h->frames.size() : 0; }
+
+lora_hip_status lora_hip_mux_poll_frame(lora_hip_mux_t *m, uint8_t *buf, size_t cap, size_t *len, lora_hip_frame_info_t *info)
+{
+    return m ? lora_hip_poll_frame(m->h, buf, cap, len, info) : LORA_HIP_ERR_ARG;
+}
+
+lora_hip_status lora_hip_mux_passes(const lora_hip_mux_t *m, uint64_t *passes, uint64_t *passes_by_latency)
+{
+    if (!m) return LORA_HIP_ERR_ARG;
+    if (passes) *passes = m->passes;
+    if (passes_by_latency) *passes_by_latency = m->passes_by_latency;
+    return LORA_HIP_OK;
+}
+
 size_t lora_hip_frames_available(const lora_hip_decoder_t *h) { return h ? h->frames.size() : 0; }
 
 lora_hip_status lora_hip_poll_frame(lora_hip_decoder_t *h, uint8_t *buf, size_t cap, size_t *len, lora_hip_frame_info_t *info)

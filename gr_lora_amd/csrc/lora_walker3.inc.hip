@@ -63,10 +63,10 @@
 #define LORA_W3_REPLAY_STATS 1  // LORA_HIP_DEBUG accounting of thread 0's replay inside the decode rounds
 #endif
 #ifndef LORA_W3_T512_MASK
-#define LORA_W3_T512_MASK 11    // bit (SF - 9): that SF's kernels as 512-thread workgroups at a 256-register budget - every thread does the work of two
+#define LORA_W3_T512_MASK 15    // bit (SF - 9): that SF's kernels as 512-thread workgroups at a 256-register budget - every thread does the work of two
                                 // (2 / 2 / 2 / 4 sample chunks in pass 1, two units of passes 2 and 3): 8 wavefronts per CU instead of 16 and no spill
                                 // left in the demodulator (tools/scratch_where.py).  Same-box A/B against 1024 x 128 (256 packets, round 3):
-                                // SF9 +8 %, SF10 +9 %, SF12 +22 % (its eight held rows now ARE registers), SF11 -1 %: on for SF9, SF10, SF12
+                                // SF9 +7 %, SF10 +5 ... 9 %, SF11 +4 %, SF12 +22 ... 28 % (its eight held rows now ARE registers)
 #endif
 #ifndef LORA_W3_EARLY_F_MASK
 #define LORA_W3_EARLY_F_MASK 0  // bit 3: SF12 keeps fine_sync's ifreq from pass 1 (needs the T512 register budget)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LORA_HIP_ABI_VERSION 2   /* 2: lora_hip_set_stream_latency, lora_hip_stream_info, lora_hip_walker_kernel_name, lora_hip_window_stats_device, lora_hip_detect_preambles_device */
+#define LORA_HIP_ABI_VERSION 2   /* 2: lora_hip_set_stream_latency, lora_hip_stream_info, lora_hip_walker_kernel_name, lora_hip_window_stats_device, lora_hip_detect_preambles_device, lora_hip_mux_* */
 
 typedef enum lora_hip_status {
     LORA_HIP_OK = 0,
@@ -149,6 +149,27 @@ typedef struct lora_hip_stream_info {
     uint32_t pass_in_flight;
 } lora_hip_stream_info_t;
 lora_hip_status lora_hip_stream_info(const lora_hip_decoder_t *h, lora_hip_stream_info_t *out);
+
+/* ---- streaming, many channels through ONE decoder: the gateway flowgraph ---------------------------------------------
+ * The reference decodes one channel per block (README.md:13, channelizer_impl.cc:47): a 64-channel gateway is 64 decoder
+ * blocks.  As 64 lora_hip_work handles that is 64 near-empty device passes per chunk; a mux feeds all channels' chunks to ONE
+ * pass (lora_hip_decode_device over n_channels streams).  Every channel is an independent gr::lora::decoder instance
+ * (constructor arguments from cfg; own d_phdr.cr, power queue, position), fed by lora_hip_mux_work(channel, ...) in any order
+ * and chunking; a pass over every channel's buffered samples is launched when ALL channels hold batch_items (cfg) or when
+ * the oldest unlaunched sample has waited the latency bound (lora_hip_mux_set_latency, default 50 ms) and is collected by
+ * the next call that finds it finished.  A channel may run ahead of the slowest one by any amount (the surplus waits in
+ * host memory).  Frames come out of one queue, info.stream = channel; per channel they are what that channel's own
+ * lora_hip_work handle would publish.  One mux = one caller thread at a time.                                            */
+typedef struct lora_hip_mux lora_hip_mux_t;
+lora_hip_status lora_hip_mux_create(const lora_hip_config_t *cfg, uint32_t n_channels, lora_hip_mux_t **out);
+void            lora_hip_mux_destroy(lora_hip_mux_t *m);
+lora_hip_status lora_hip_mux_work(lora_hip_mux_t *m, uint32_t channel, const float *iq, size_t n_items);
+lora_hip_status lora_hip_mux_flush(lora_hip_mux_t *m);
+lora_hip_status lora_hip_mux_set_latency(lora_hip_mux_t *m, float max_latency_ms);
+size_t          lora_hip_mux_frames_available(const lora_hip_mux_t *m);
+lora_hip_status lora_hip_mux_poll_frame(lora_hip_mux_t *m, uint8_t *buf, size_t cap, size_t *len, lora_hip_frame_info_t *info);
+lora_hip_status lora_hip_mux_passes(const lora_hip_mux_t *m, uint64_t *passes, uint64_t *passes_by_latency);
+const char     *lora_hip_mux_last_error(const lora_hip_mux_t *m);
 
 /* ---- batched, device-resident: many independent streams in one pass ------------------------------------- */
 /* d_iq: device pointer to cf32 items; stream i occupies items [stream_off[i], stream_off[i]+stream_len[i]).
