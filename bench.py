@@ -249,6 +249,7 @@ def main():
     ap.add_argument("--split", action="store_true", help="config 2 / 3 as ONE stream split over the ranks by sample range (SURVEY 8(e), second clause: "
                     "gr_lora_amd.gather.split_stream_ranges - margins on both sides of every cut, frames de-duplicated by header position): strong scaling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-grad-line", action="store_true", help="skip the second measurement (the reference's shipped gradient demodulator on the same workload; --no-cpu-baseline, the tools' quick mode, skips it too)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -400,6 +401,45 @@ def main():
     else:
         total_items = whole_items if split_ranges is not None else n_items
 
+    # The same workload through the reference's SHIPPED demodulator (max_frequency_gradient_idx, decoder_impl.cc:499; --demod 0
+    # makes it the headline): its own kernels (walker2/3_*_grad), verified against what the compiled reference published on this IQ
+    # (tests/golden/fullsize_ref.json).  A second, shorter measurement after the timed region of the headline; single process only.
+    grad_line = None
+    if rank == 0 and world == 1 and args.config in (2, 3) and args.demod != 0 and not (args.no_grad_line or args.no_cpu_baseline) and split_ranges is None:
+        try:
+            fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_ref.json")))
+            wantk = dict(sf=sf, cr=args.cr, packets=packets, payload=args.payload, streams=min(args.streams, packets), seed=(2 if args.config == 2 else 100 * sf + 4))
+            gfix = next((e for e in fx.values() if all(e[k] == v for k, v in wantk.items())), None)
+        except (OSError, ValueError):
+            gfix = None
+        ghs = [capi.Handle(**dict(kw, demod=0)) for _ in range(depth)]
+        gpipe = gather.PassPipeline(ghs, gather.AsyncSlotGather(dev, max(64, 2 * n_frames_expected)), d_iq.data_ptr(), n_items, offs, lens, stream)
+        gkept = []
+        gpipe.run(depth, gkept)
+        gver = None
+        if gfix is not None:
+            gver = len(gkept) == depth
+            for slots, counts in gkept:
+                full = {}
+                for b, sid, _hp in gather.unpack_frames(slots[0], counts[0]):
+                    full.setdefault(sid, []).append(b)
+                gver = gver and all(len(full.get(k, [])) == e["frames"] and _digest(full.get(k, [])) == e["sha256"] for k, e in enumerate(gfix["per_stream"]))
+        gpipe.run(20 if n_items < 4e8 else 2)
+        gsteps = max(5, args.steps // 2)
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        gw_ms, _gl = gpipe.run(gsteps)
+        torch.cuda.synchronize()
+        gel = time.perf_counter() - g0
+        gk_ms = gw_ms / gsteps
+        grad_line = {"what": "the same workload through the reference's shipped demodulator (max_frequency_gradient_idx, decoder_impl.cc:499): bench.py --demod 0",
+                     "value": round(n_items * gsteps / gel / 1e6, 3), "unit": "Msamples/s", "steps": gsteps, "ms_per_step": round(gel / gsteps * 1e3, 4),
+                     "kernel": ghs[0].kernel_name(), "kernel_ms_per_pass": round(gk_ms, 4),
+                     "frac": round(8.0 * n_items / (gk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if gk_ms > 0 else None,
+                     "bit_exact_vs_compiled_reference_frames": gver}
+        for hk in ghs:
+            hk.close()
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_items * args.steps / elapsed / 1e6
@@ -432,6 +472,8 @@ def main():
                          "launches_per_pass": launches / max(1, args.steps),
                          "algorithmic_bytes_per_pass": 8 * n_items},
         }
+        if grad_line is not None:
+            res["reference_default_demodulator"] = grad_line
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(cfg, iq, offs, lens)
             res["cpu_baseline"] = {"value": round(cb["grad"][0], 3), "unit": "Msamples/s", "cores": 1, "kind": "port",

@@ -1209,7 +1209,22 @@ static lora_hip_status mux_collect(lora_hip_mux *m)
         const size_t keep_from = (size_t)std::min<int64_t>(std::max<int64_t>(sd.final_pos, 0), (int64_t)c.fl_len);
         const size_t tail = c.fl_len - keep_from;
         c.host_base += (int64_t)keep_from;
-        if (tail > m->tailcap) { m->err = "a packet longer than the tail area of a mux channel: raise batch_items"; return LORA_HIP_ERR_OVERFLOW; }
+        if (tail > m->tailcap) { // a packet longer than the tail area: grow both buffers, every region keeps its chunk and the right end of its tail area
+            const size_t ncap = std::max(2u * m->tailcap, tail + (size_t)h->P.sps), nregion = ncap + m->batch;
+            MUX_TRY(m, hipStreamSynchronize(m->copy_st));
+            MUX_TRY(m, hipStreamSynchronize(m->comp_st));
+            for (int i = 0; i < 2; i++) {
+                DevBuf<float2> nb;
+                MUX_TRY(m, nb.reserve((size_t)m->n * nregion));
+                for (uint32_t q = 0; q < m->n; q++)
+                    MUX_TRY(m, hipMemcpyAsync(nb.p + (size_t)q * nregion + (ncap - m->tailcap), m->dbuf[i].p + (size_t)q * m->region, m->region * sizeof(float2), hipMemcpyDeviceToDevice, m->comp_st));
+                MUX_TRY(m, hipStreamSynchronize(m->comp_st));
+                std::swap(m->dbuf[i], nb);
+                nb.release();
+            }
+            for (auto &cc : m->ch) cc.fl_off = (cc.fl_off / m->region) * nregion + (cc.fl_off % m->region) + (ncap - m->tailcap);
+            m->tailcap = ncap; m->region = nregion;
+        }
         if (tail) {
             MUX_TRY(m, hipMemcpyAsync(m->dbuf[m->cur].p + (size_t)sd.id * m->region + m->tailcap - tail, m->dbuf[prev].p + c.fl_off + keep_from, tail * sizeof(float2),
                                       hipMemcpyDeviceToDevice, m->comp_st));
