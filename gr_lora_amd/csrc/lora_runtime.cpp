@@ -500,7 +500,7 @@ lora_hip_status run_jobs_end(lora_hip_decoder *h, RunOut &out)
                 ms * 1e3, us(hp2, hp3), nj * sizeof(JobResult), (size_t)nj * eager * sizeof(AttemptRec));
     }
     h->timing.walker_ms += ms;
-    h->timing.total_device_ms += ms; // (+ the pre-pass, added where it is timed)
+    h->timing.total_device_ms += ms; // (the walker launches only: the envelope pre-pass runs on its own stream beside the previous pass and is not part of this figure)
     h->timing.walker_launches++;
     return LORA_HIP_OK;
 }

@@ -95,7 +95,7 @@ typedef struct lora_hip_step {
  * measured with HIP events on the launch stream.                                                               */
 typedef struct lora_hip_timing {
     float    walker_ms;              /* sum over the walker (decoder state-machine) kernel launches          */
-    float    total_device_ms;        /* device time of the pass: the walker launches (HIP events around each)   */
+    float    total_device_ms;        /* = walker_ms (the walker launches, HIP events around each; the envelope pre-pass runs beside the previous pass and is not counted) */
     uint32_t walker_launches;
     uint32_t jobs;                   /* workgroups launched in the main pass                                  */
     uint32_t probes;                 /* stitch probes launched                                                */
@@ -321,7 +321,11 @@ lora_hip_status lora_hip_detect_preambles_device(lora_hip_decoder_t *h, const vo
  *           data (decoder_impl.cc:643), so the received value is first XORed with the whitening bytes of its
  *           two positions (x^8 + x^6 + x^5 + x^4 + 1, seed 0xff: the sequence lib/tables.h:30-44 decodes to).
  * Known answer: the README frame 04 90 40 de ad be ef 70 0d passes both.  Implicit-header frames carry no
- * header on air: has_header = 0 and only blobs whose length agrees with their PHY header are checked.        */
+ * header on air (the 3 PHY bytes of their blob are synthesised from the constructor's cr / crc, decoder_impl.cc:588-600):
+ * has_header is inferred from the blob length agreeing with those bytes, which an implicit frame can match by
+ * coincidence - it is then reported with has_header = 1, header_checksum_ok = 0 and a crc_ok computed from a length that
+ * was never on air.  The result is only meaningful for explicit-header decoders; a caller that runs implicit mode knows
+ * so and should not ask.                                                                                             */
 typedef struct lora_hip_frame_check {
     uint8_t  has_header;          /* blob length agrees with the PHY header's length / has_crc fields        */
     uint8_t  header_checksum_ok;

@@ -102,3 +102,14 @@ def test_bench_under_torchrun_world1_matches_plain_run():
     # that has just been leased: clocks differ by a few per cent between them)
     ratio = launched["value"] / plain["value"]
     assert 0.85 < ratio < 1.18, (plain["value"], launched["value"])
+
+
+def test_bench_split_under_torchrun_world1():
+    """bench.py --split (one capture over the ranks by sample range, SURVEY 8(e) second clause) under a launcher with one rank: the
+    range is the whole capture, the frames go through the RCCL gather and the ownership filter, and must be the capture's frames."""
+    env = _env()
+    port = env.pop("MASTER_PORT")
+    line = _bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", port,
+                   "bench.py", "--gpus", "1", "--split", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"], env=env)
+    assert line["scaling"] == "strong" and line["config"]["bit_exact_vs_expected"] and line["config"]["process_group"] == "nccl (RCCL), world 1"
+    assert "split over 1 rank(s)" in line["config"]["workload"]

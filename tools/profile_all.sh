@@ -23,6 +23,12 @@ python bench.py --config 4 --seconds 2 --steps 30 --warmup 5 --no-cpu-baseline 2
 python bench.py --demod 0 2>/dev/null | tail -1 > gpurun_out/default_grad_line.json
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/torchrun1_line.json
 python bench.py --streams 1 --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/streams1_line.json
+tools/pmc_walker.sh sq_sf7
+tools/pmc_walker.sh sq_sf9 --config 3 --sf 9
+tools/pmc_walker.sh sq_sf12 --config 3 --sf 12
+for t in sq_sf7 sq_sf9 sq_sf12; do python tools/pmc_summary.py gpurun_out/$t > gpurun_out/$t.json; rm -rf gpurun_out/$t; done
+python bench.py --path mux --config 4 --seconds 2 --steps 5 2>/dev/null | tail -1 > gpurun_out/mux_cfg4_2s_line.json
+python bench.py --split --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/split1_line.json
 } > gpurun_out/profile_all.log 2>&1
 # keep what travels back small: the per-dispatch traces are not needed once summarised... (kernel_stats + counter_collection csv only)
 find gpurun_out/prof_* -type f ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" ! -name "*.log" ! -name "line.json" -delete 2>/dev/null
