@@ -71,6 +71,11 @@
 #ifndef LORA_W3_EARLY_F_MASK
 #define LORA_W3_EARLY_F_MASK 0  // bit 3: SF12 keeps fine_sync's ifreq from pass 1 (needs the T512 register budget)
 #endif
+#ifndef LORA_W3_P1_PIPE
+#define LORA_W3_P1_PIPE 0       // bit (SF - 9), 512-thread geometry only: pass 1 requests a pair's predecessors and dechirp factors together with its
+                                // samples, and the NEXT pair's samples before it computes on this one (pass 1 is half of a round and was a chain of
+                                // dependent load -> use stages: 2 x (samples, 2 x predecessors, 2 x dechirp factors))
+#endif
 #ifndef LORA_W3_PRELOAD
 #define LORA_W3_PRELOAD 0       // bit (SF - 9): decode rounds: the first 16 samples per thread of the NEXT round's window (zero drift assumed) are requested right
                                 // behind this round's last reduction and stay in flight under thread 0's replay and the plan barrier (32 registers)
@@ -374,6 +379,80 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
     float en = 0.0f;
 
     // ---- pass 1 ----
+    constexpr bool P1_PIPE = G::T512 && ((LORA_W3_P1_PIPE >> (SF - 9)) & 1);
+    if constexpr (P1_PIPE) {
+    if (valid) {
+        v2f nxt[16];
+        if (use_pre) {
+#pragma unroll
+            for (int c = 0; c < 16; c++) nxt[c] = pre[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 16; c++) nxt[c] = w3_ld2(xb, 8u * tu, (uint32_t)(c * CH * 8));
+        }
+#pragma unroll
+        for (int p = 0; p < PAIRS; p++) {
+            const int base = p * TG + t;
+            const uint32_t ob = 8u * ((uint32_t)(p * TG) + tu);
+            v2f a[16], ap[G::LATE_F ? 1 : 16], d[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) a[c] = nxt[c];
+            if (p + 1 < PAIRS) { // the next pair's samples: in flight under this pair's arithmetic
+                const uint32_t obn = 8u * ((uint32_t)((p + 1) * TG) + tu);
+#pragma unroll
+                for (int c = 0; c < 16; c++) nxt[c] = w3_ld2(xb, obn, (uint32_t)(c * CH * 8));
+            }
+            if constexpr (!G::LATE_F) {
+                if (want_fine) {
+                    ap[0] = w3_ld2(xb, (p == 0) ? (ob >= 8u ? ob - 8u : 0u) : ob - 8u, 0u);
+#pragma unroll
+                    for (int c = 1; c < 16; c++) ap[c] = w3_ld2(xb, ob, (uint32_t)(c * CH * 8 - 8));
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 16; c++) d[c] = w3_ld2(db, ob, (uint32_t)(c * CH * 8));
+            __builtin_amdgcn_sched_barrier(0); // every request of this pair (and the next pair's samples) is out before the first use
+            if (want_energy) {
+#pragma unroll
+                for (int c = 0; c < 16; c++) en += a[c].x * a[c].x + a[c].y * a[c].y;
+            }
+            if constexpr (!G::LATE_F) {
+                if (want_fine) {
+#pragma unroll
+                    for (int q = 0; q < 16; q += 4) {
+                        v2f im0, re0, im1, re1, o0, o1;
+                        im0 = (v2f){a[q].y * ap[q].x - a[q].x * ap[q].y, a[q + 1].y * ap[q + 1].x - a[q + 1].x * ap[q + 1].y};
+                        re0 = (v2f){a[q].x * ap[q].x + a[q].y * ap[q].y, a[q + 1].x * ap[q + 1].x + a[q + 1].y * ap[q + 1].y};
+                        im1 = (v2f){a[q + 2].y * ap[q + 2].x - a[q + 2].x * ap[q + 2].y, a[q + 3].y * ap[q + 3].x - a[q + 3].x * ap[q + 3].y};
+                        re1 = (v2f){a[q + 2].x * ap[q + 2].x + a[q + 2].y * ap[q + 2].y, a[q + 3].x * ap[q + 3].x + a[q + 3].y * ap[q + 3].y};
+                        w3_atan2_x4(im0, re0, im1, re1, o0, o1);
+                        f[G::LATE_F ? 0 : p][q] = (p == 0 && q == 0 && t == 0) ? 0.0f : o0.x; // n = 0 has no predecessor in the window
+                        f[G::LATE_F ? 0 : p][q + 1] = o0.y; f[G::LATE_F ? 0 : p][q + 2] = o1.x; f[G::LATE_F ? 0 : p][q + 3] = o1.y;
+                    }
+                }
+            }
+            cmul_batch<8>(a, d); // dechirp (:437)
+            cmul_batch<8>(a + 8, d + 8);
+            fft_inlane_dif_pk<16>(a);
+            const int q0 = base >> 3;
+            {
+                v2f w[8];
+#pragma unroll
+                for (int m = 1; m < 8; m++) w[m] = w3_tw<SF>(L, (uint32_t)(q0 * brev_bits(m, 4)));
+                cmul_batch<7>(a + 1, w + 1);
+#pragma unroll
+                for (int m = 8; m < 16; m++) w[m - 8] = w3_tw<SF>(L, (uint32_t)(q0 * brev_bits(m, 4)));
+                cmul_batch<8>(a + 8, w);
+            }
+#pragma unroll
+            for (int m = 0; m < AR; m++) data[m * SA + q0 * 8 + r] = a[m];
+            if constexpr (ROUNDS > 1) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) hold[p][i] = a[8 + i];
+            }
+        }
+    }
+    } else
     if (valid) {
 #pragma unroll
         for (int p = 0; p < PAIRS; p++) {
@@ -863,6 +942,18 @@ __device__ __forceinline__ void w3_detect_round(const float2 *__restrict__ x0, i
 // A = [i0, i0 + LEN) and on B = [i0 + n, i0 + n + LEN) straight from the samples, the workgroup scans the A and B sums,
 // and the thread slides over its shifts.  Returns the best correlation and its (first) shift.
 struct W3SyncOut { float bv; int bi; int slot; };
+// ifreq[base .. base + 16) straight from the samples: f[j] = arg(x[base + j + 1] conj(x[base + j]))
+__device__ __forceinline__ void w3_sync_ifreq16(const __attribute__((address_space(1))) v2f *xv, int base, float (&f)[16])
+{
+    v2f xs[17];
+#pragma unroll
+    for (int j = 0; j <= 16; j++) xs[j] = xv[base + j];
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+        const v2f fp = ifreq_prod_pk(xs[j], xs[j + 1], xs[j + 1], xs[j + 2]);
+        f[j] = fp.x; f[j + 1] = fp.y;
+    }
+}
 template <int SF>
 __device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double sync_b, const float2 *__restrict__ x, W3Shared *wsp, int slot)
 {
@@ -874,7 +965,25 @@ __device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double syn
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int i0 = t * LEN;
     double s0A = 0.0, gA = 0.0, s0B = 0.0, gB = 0.0; // sums of f and of (pos - sps) f over A and B
-    float fa[LEN], fb[LEN];
+    // More than 16 shifts per thread (the 512-thread geometry at SF11 / SF12): the two ifreq segments are not kept (2 x 32 / 2 x 64
+    // floats beside as many samples: a 0.5-1.1 KB stack frame per lane, 60-180 spilled registers) but computed twice, 16 at a time -
+    // once for the sums the scan needs, once for the slide; same values, same order of every sum.
+    constexpr bool CHUNKED = LEN > 16;
+    float fa[CHUNKED ? 16 : LEN], fb[CHUNKED ? 16 : LEN];
+    float f_last_a = 0.0f;
+    if constexpr (CHUNKED) {
+#pragma unroll 1
+        for (int q = 0; q < LEN; q += 16) {
+            w3_sync_ifreq16(xv, i0 + q, fa);
+            w3_sync_ifreq16(xv, i0 + n + q, fb);
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                s0A += (double)fa[j]; gA += (double)(i0 + q + j - SPS) * (double)fa[j];
+                s0B += (double)fb[j]; gB += (double)(i0 + n + q + j - SPS) * (double)fb[j];
+            }
+            f_last_a = fa[15];
+        }
+    } else {
     {
         v2f xa[LEN + 1];
 #pragma unroll
@@ -896,9 +1005,11 @@ __device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double syn
         }
     }
 #pragma unroll
-    for (int j = 0; j < LEN; j++) {
+    for (int j = 0; j < (CHUNKED ? 0 : LEN); j++) {
         s0A += (double)fa[j]; gA += (double)(i0 + j - SPS) * (double)fa[j];
         s0B += (double)fb[j]; gB += (double)(i0 + n + j - SPS) * (double)fb[j];
+    }
+    f_last_a = fa[LEN - 1];
     }
     // block-wide exclusive scans of the four sums
     double in[4] = {s0A, gA, s0B, gB}, ex[4], tot[4];
@@ -914,7 +1025,7 @@ __device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double syn
         ex[q] = v - in[q];
         if (lane == 63) dr[wave * 4 + q] = v;
     }
-    if (t == G::T - 1) dr[64] = (double)fa[LEN - 1]; // f[sps-1]: the last element of the last A segment
+    if (t == G::T - 1) dr[64] = (double)f_last_a; // f[sps-1]: the last element of the last A segment
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -929,6 +1040,21 @@ __device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double syn
     double s0 = F1 - F0, s1 = (G1 - G0) + (double)(SPS - i0) * s0;
     float bv = 0.0f; // max_correlation = 0 (:400)
     int bi = 0x7fffffff;
+    if constexpr (CHUNKED) {
+#pragma unroll 1
+        for (int q = 0; q < LEN; q += 16) {
+            w3_sync_ifreq16(xv, i0 + q, fa);
+            w3_sync_ifreq16(xv, i0 + n + q, fb);
+#pragma unroll
+            for (int rr = 0; rr < 16; rr++) {
+                const float c = (float)(sync_a * s0 + sync_b * s1);
+                if (c > bv) { bv = c; bi = i0 + q + rr; }
+                const double fin = (double)fb[rr], fout = (double)fa[rr];
+                s0 += fin - fout;
+                s1 += (double)n * fin - s0;
+            }
+        }
+    } else {
 #pragma unroll
     for (int rr = 0; rr < LEN; rr++) {
         const float c = (float)(sync_a * s0 + sync_b * s1);
@@ -936,6 +1062,7 @@ __device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double syn
         const double fin = (double)fb[rr], fout = (double)fa[rr];
         s0 += fin - fout;
         s1 += (double)n * fin - s0;
+    }
     }
     // first maximum over the workgroup
     float *red = ws.red[slot][0];
