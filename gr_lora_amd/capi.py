@@ -23,7 +23,7 @@ EXPORTS = [
     "lora_hip_get_geometry", "lora_hip_set_sf", "lora_hip_set_samp_rate", "lora_hip_work", "lora_hip_flush",
     "lora_hip_decode_device", "lora_hip_frames_available", "lora_hip_poll_frame", "lora_hip_drain_frames", "lora_hip_drain_slots", "lora_hip_demod_symbols_device", "lora_hip_demod_symbols_ex_device",
     "lora_hip_last_timing", "lora_hip_last_plan", "lora_hip_gap_starts_device", "lora_hip_decode_device_begin", "lora_hip_decode_device_end", "lora_hip_decode_device_prepass", "lora_hip_trace", "lora_hip_trace_clear", "lora_hip_check_frame", "lora_hip_estimate_cfo_device",
-    "lora_hip_set_stream_latency", "lora_hip_stream_info", "lora_hip_walker_kernel_name", "lora_hip_window_stats_device", "lora_hip_detect_preambles_device",
+    "lora_hip_set_stream_latency", "lora_hip_stream_info", "lora_hip_walker_kernel_name", "lora_hip_window_stats_device", "lora_hip_detect_preambles_device", "lora_hip_decode_at_headers_device",
     "lora_hip_mux_create", "lora_hip_mux_destroy", "lora_hip_mux_work", "lora_hip_mux_flush", "lora_hip_mux_set_latency", "lora_hip_mux_frames_available",
     "lora_hip_mux_poll_frame", "lora_hip_mux_passes", "lora_hip_mux_last_error",
 ]
@@ -147,6 +147,7 @@ def load():
     L.lora_hip_estimate_cfo_device.restype = C.c_int
     L.lora_hip_window_stats_device.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(WindowStats), vp]
     L.lora_hip_detect_preambles_device.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_uint32, C.c_float, C.POINTER(Preamble), C.c_size_t, C.POINTER(C.c_size_t), vp]
+    L.lora_hip_decode_at_headers_device.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_uint32, C.POINTER(Preamble), C.c_size_t, vp]
     L.lora_hip_walker_kernel_name.argtypes = [vp]
     L.lora_hip_walker_kernel_name.restype = C.c_char_p
     L.lora_hip_mux_create.argtypes = [C.POINTER(Config), C.c_uint32, C.POINTER(vp)]
@@ -320,6 +321,17 @@ class Handle:
         self._check(self.L.lora_hip_detect_preambles_device(self.h, dev_ptr, total_items, o.ctypes.data, l.ctypes.data, o.size, float(threshold), out, cap, C.byref(n), stream))
         return [dict(header_pos=p.header_pos, run_pos=p.run_pos, stream=p.stream, run_len=p.run_len, bin=p.bin, sfd_index=p.sfd_index, pmr=p.pmr,
                      cfo_bins=p.cfo_bins, cfo_hz=p.cfo_hz) for p in out[: n.value]]
+
+    def decode_at_headers_device(self, dev_ptr: int, total_items: int, offs: Sequence[int], lens: Sequence[int], preambles, stream: int = 0):
+        """lora_hip_decode_at_headers_device: decodes the packets at the detector's header positions (dicts of detect_preambles_device, or
+        (stream, header_pos) pairs); frames go to the handle's queue."""
+        o = np.ascontiguousarray(offs, dtype=np.uint64)
+        l = np.ascontiguousarray(lens, dtype=np.uint64)
+        arr = (Preamble * max(len(preambles), 1))()
+        for i, p in enumerate(preambles):
+            st, hp = (p["stream"], p["header_pos"]) if isinstance(p, dict) else p
+            arr[i].stream, arr[i].header_pos = int(st), int(hp)
+        self._check(self.L.lora_hip_decode_at_headers_device(self.h, dev_ptr, total_items, o.ctypes.data, l.ctypes.data, o.size, arr, len(preambles), stream))
 
     def frames_available(self) -> int:
         return self.L.lora_hip_frames_available(self.h)

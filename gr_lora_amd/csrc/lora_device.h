@@ -70,6 +70,9 @@ struct Job {
     uint32_t stop_at_header; // probe mode
     int64_t  probe_limit;  // > scan_limit: having reached scan_limit, the job goes on as its successor's probe (stop at the
                            // next header, no new DETECT step at pos >= probe_limit) and reports that part as the "tail"; 0: off
+    uint32_t start_at_header; // 1: `start` is the first header symbol of a packet acquired elsewhere (lora_hip_decode_at_headers_device, after
+                           // the FFT-domain preamble detector): the job begins in DECODE_HEADER with an attempt open instead of in DETECT
+    uint32_t rsv0;
 };
 
 struct AttemptRec {

@@ -1350,11 +1350,17 @@ lora_hip_status lora_hip_mux_flush(lora_hip_mux_t *m)
     MUX_TRY(m, hipSetDevice(m->h->device));
     lora_hip_status s;
     for (int guard = 0; guard < 1 << 20; guard++) { // until nothing waits in host memory either
+        const uint64_t before = m->passes;
         s = mux_rotate(m, false);
         if (s != LORA_HIP_OK) return s;
         bool more = false;
-        for (const auto &c : m->ch) more = more || !c.ahead.empty() || c.fill != 0;
-        if (!more) break;
+        for (const auto &c : m->ch) more = more || !c.ahead.empty();
+        if (!more && m->passes == before) break; // nothing launched and nothing left to upload: what remains is shorter than a work() call (:91)
+        if (!more) { // the last uploads are in: one more pass takes them
+            bool any = false;
+            for (const auto &c : m->ch) any = any || (c.fill != 0 && c.tail_len + c.fill >= 2u * (size_t)m->h->P.sps);
+            if (!any) break;
+        }
     }
     s = mux_collect(m);
     if (s != LORA_HIP_OK) return s;
@@ -1613,6 +1619,40 @@ lora_hip_status lora_hip_detect_preambles_device(lora_hip_decoder_t *h, const vo
     }
     *n_found = n_out;
     return overflow ? LORA_HIP_ERR_OVERFLOW : LORA_HIP_OK;
+}
+
+lora_hip_status lora_hip_decode_at_headers_device(lora_hip_decoder_t *h, const void *d_iq, size_t total_items, const uint64_t *stream_off,
+                                                  const uint64_t *stream_len, uint32_t n_streams, const lora_hip_preamble_t *pre, size_t n, void *hip_stream)
+{
+    if (!h || !d_iq || !n_streams || !stream_off || !stream_len || (n && !pre)) return LORA_HIP_ERR_ARG;
+    if (h->pass_open) return fail(h, LORA_HIP_ERR_ARG, "lora_hip_decode_at_headers_device: a pass is open on this handle");
+    if (h->P.implicit) return fail(h, LORA_HIP_ERR_BAD_CONFIG, "decode at given headers needs an explicit header (the implicit mode's energy threshold comes from DETECT)");
+    if (n == 0) return LORA_HIP_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    std::vector<Job> jobs(n, Job{});
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t s = pre[i].stream;
+        if (s >= n_streams || stream_off[s] > total_items || stream_len[s] > total_items - stream_off[s]) return fail(h, LORA_HIP_ERR_ARG, "entry %zu: bad stream", i);
+        if (pre[i].header_pos < 0 || (uint64_t)pre[i].header_pos + 2u * h->P.sps > stream_len[s]) return fail(h, LORA_HIP_ERR_ARG, "entry %zu: header position outside its stream", i);
+        Job &j = jobs[i];
+        j.stream_off = stream_off[s]; j.stream_len = stream_len[s]; j.stream_id = s;
+        j.start = pre[i].header_pos; j.scan_limit = pre[i].header_pos; // (no DETECT step once the packet is done)
+        j.cr_prev = h->P.ctor_cr; j.max_attempts = 1; j.start_at_header = 1;
+    }
+    h->err.clear();
+    h->timing = lora_hip_timing_t{};
+    RunOut &out = h->run_out[0];
+    const lora_hip_status rc = run_jobs(h, (const float2 *)d_iq, jobs, 2, 0, (hipStream_t)hip_stream, out);
+    if (rc != LORA_HIP_OK) return rc;
+    for (size_t i = 0; i < n; i++) {
+        if (out.res[i].n_attempts == 0 || out.rpj == 0) continue;
+        const AttemptRec &r = out.rec(i, 0);
+        if (r.status != kAttemptFrame) continue; // (ran out of data mid-packet)
+        StreamDesc sd{};
+        sd.id = jobs[i].stream_id; sd.abs_base = 0;
+        publish(h, r, sd);
+    }
+    return LORA_HIP_OK;
 }
 
 lora_hip_status lora_hip_last_plan(const lora_hip_decoder_t *h, uint32_t *burst_aware, uint32_t *segments)

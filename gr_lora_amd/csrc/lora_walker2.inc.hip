@@ -600,6 +600,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         S.state = kDetect; S.pos = job.start; S.cr = job.cr_prev; S.has_crc = P.ctor_crc;
         S.phdr[1] = (uint8_t)((P.ctor_cr << 5) | (P.ctor_crc << 4));
         S.att_start = job.start; S.att_trig = -1; S.att_hdr = -1; S.att_cr_prev = job.cr_prev;
+        if (job.start_at_header && phase == 0) { S.state = kDecodeHeader; S.in_attempt = 1; S.att_trig = job.start; S.att_hdr = job.start; } // (acquired elsewhere)
         if (phase == 0) W.stats = W2Stats{};
         W.stats.prev_state = -1;
         W.det_streak = 0u;

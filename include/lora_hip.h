@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LORA_HIP_ABI_VERSION 2   /* 2: lora_hip_set_stream_latency, lora_hip_stream_info, lora_hip_walker_kernel_name, lora_hip_window_stats_device, lora_hip_detect_preambles_device, lora_hip_mux_* */
+#define LORA_HIP_ABI_VERSION 2   /* 2: lora_hip_set_stream_latency, lora_hip_stream_info, lora_hip_walker_kernel_name, lora_hip_window_stats_device, lora_hip_detect_preambles_device, lora_hip_decode_at_headers_device, lora_hip_mux_* */
 
 typedef enum lora_hip_status {
     LORA_HIP_OK = 0,
@@ -307,6 +307,17 @@ lora_hip_status lora_hip_detect_preambles_device(lora_hip_decoder_t *h, const vo
                                                  const uint64_t *stream_off, const uint64_t *stream_len, uint32_t n_streams,
                                                  float threshold, lora_hip_preamble_t *out, size_t cap, size_t *n_found,
                                                  void *hip_stream);
+
+/* Decodes the packets whose first header symbol the caller already knows - the detector's output - without the reference's own
+ * acquisition: one job per entry starts in DECODE_HEADER at pre[i].header_pos of stream pre[i].stream (decoder_impl.cc:826 onwards:
+ * header, payload, fine_sync as configured, the integer chain) and publishes its frame to the handle's queue (info.stream,
+ * info.header_pos; the loratap SNR byte is 0: no DETECT step fed the power queue).  Explicit header only.  With
+ * lora_hip_detect_preambles_device in front this is a receive path that works where the reference's acquires nothing: BASELINE
+ * config 5 (SF12, 255 bytes, carrier offset, -10 dB in-band) decodes end to end (tests/test_gpu_detect.py).  Use an FFT demodulator;
+ * the gradient estimator and fine_sync's ifreq correlation need tens of dB (disable_drift_correction = 1 below ~10 dB).          */
+lora_hip_status lora_hip_decode_at_headers_device(lora_hip_decoder_t *h, const void *d_iq, size_t total_items,
+                                                  const uint64_t *stream_off, const uint64_t *stream_len, uint32_t n_streams,
+                                                  const lora_hip_preamble_t *pre, size_t n, void *hip_stream);
 
 /* ---- frame validity (beyond the reference) -------------------------------------------------
  * The reference publishes every frame it demodulates and checks nothing: "CRC checks of the payload and header"

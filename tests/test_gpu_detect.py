@@ -119,3 +119,48 @@ def test_config5_end_to_end_without_ground_truth(reduced_rate):
     e = np.abs(got - truth)
     e = np.minimum(e, cfg.nbins - e)
     assert (e <= 1).mean() >= 0.98 and (e <= 2).all(), (np.nonzero(e > 1)[0][:10], e.max())
+
+
+@pytest.mark.parametrize("sf,demod", [(7, 2), (7, 0), (8, 1), (9, 2), (10, 0), (12, 2)])
+def test_decode_at_given_headers_equals_normal_decode(oracle_mod, sf, demod):
+    """lora_hip_decode_at_headers_device on clean packets at their true header positions (the positions the normal receive path
+    reports): same frames (behind the loratap header: its SNR byte needs DETECT), every kernel family."""
+    from gr_lora_amd import capi
+    cfg = synth.TxConfig(sf=sf, cr=4, reduced_rate=(sf > 10))
+    rng = np.random.default_rng(40 + sf)
+    payloads = [bytes(rng.integers(0, 256, int(rng.integers(3, 40)), dtype=np.uint8)) for _ in range(4)]
+    st = synth.build_stream(payloads, cfg, rng=rng, gap_symbols=(2.0, 6.0))
+    dev = _dev(st.iq)
+    kw = dict(sf=sf, cr=4, reduced_rate=(sf > 10), demod=demod)
+    h = capi.Handle(**kw)
+    h.decode_device(dev.data_ptr(), st.iq.size, [0], [st.iq.size], 0)
+    normal = [(b[15:], i.header_pos) for b, i in h.drain()]
+    assert len(normal) == 4
+    h.decode_at_headers_device(dev.data_ptr(), st.iq.size, [0], [st.iq.size], [(0, p) for _b, p in normal])
+    got = [(b[15:], i.header_pos) for b, i in h.drain()]
+    h.close()
+    assert got == normal
+
+
+@pytest.mark.parametrize("reduced_rate", [False, True])
+def test_config5_frames_end_to_end(reduced_rate):
+    """BASELINE config 5 all the way to bytes: detector -> lora_hip_decode_at_headers_device (FFT demodulator, drift correction off:
+    fine_sync's ifreq correlation is a time-domain estimator like the reference's gates) -> the 255-byte payload 00..fe, at -10 dB
+    in-band with a carrier offset, where the reference's receive path publishes nothing."""
+    from gr_lora_amd import capi
+    cfg = synth.TxConfig(sf=12, cr=4, reduced_rate=reduced_rate)
+    rng = np.random.default_rng(5)
+    cfo = float(rng.uniform(-cfg.bw / 4, cfg.bw / 4))
+    st = synth.build_stream([bytes(range(255))], cfg, gaps=[3 * cfg.sps + 4321], rng=rng, noise_sigma=synth.awgn_sigma_for_snr(-10.0, cfg), cfo_hz=cfo, tail_symbols=2.5)
+    dev = _dev(st.iq)
+    h = capi.Handle(sf=12, cr=4, reduced_rate=reduced_rate, demod=capi.DEMOD_FFT, disable_drift_correction=True)
+    det = h.detect_preambles_device(dev.data_ptr(), st.iq.size, [0], [st.iq.size])
+    assert len(det) == 1
+    h.decode_at_headers_device(dev.data_ptr(), st.iq.size, [0], [st.iq.size], det)
+    frames = h.drain()
+    h.close()
+    assert len(frames) == 1
+    body = frames[0][0][15:]
+    want = synth.expected_frame_tail(bytes(range(255)), cfg)
+    wrong = sum(a != b for a, b in zip(body, want)) + abs(len(body) - len(want))
+    assert wrong == 0, (wrong, len(body), len(want))
