@@ -82,7 +82,7 @@ class WindowStats(C.Structure):
 
 class Preamble(C.Structure):
     _fields_ = [("header_pos", C.c_int64), ("run_pos", C.c_int64), ("stream", C.c_uint32), ("run_len", C.c_uint32), ("bin", C.c_int32), ("sfd_index", C.c_int32),
-                ("pmr", C.c_float), ("cfo_bins", C.c_float), ("cfo_hz", C.c_float), ("reserved", C.c_uint32)]
+                ("pmr", C.c_float), ("cfo_bins", C.c_float), ("cfo_hz", C.c_float), ("delta", C.c_int32)]
 
 
 class LoraHipError(RuntimeError):
@@ -320,7 +320,7 @@ class Handle:
         n = C.c_size_t(0)
         self._check(self.L.lora_hip_detect_preambles_device(self.h, dev_ptr, total_items, o.ctypes.data, l.ctypes.data, o.size, float(threshold), out, cap, C.byref(n), stream))
         return [dict(header_pos=p.header_pos, run_pos=p.run_pos, stream=p.stream, run_len=p.run_len, bin=p.bin, sfd_index=p.sfd_index, pmr=p.pmr,
-                     cfo_bins=p.cfo_bins, cfo_hz=p.cfo_hz) for p in out[: n.value]]
+                     cfo_bins=p.cfo_bins, cfo_hz=p.cfo_hz, delta=p.delta) for p in out[: n.value]]
 
     def decode_at_headers_device(self, dev_ptr: int, total_items: int, offs: Sequence[int], lens: Sequence[int], preambles, stream: int = 0):
         """lora_hip_decode_at_headers_device: decodes the packets at the detector's header positions (dicts of detect_preambles_device, or

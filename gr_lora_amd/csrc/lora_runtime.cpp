@@ -1595,10 +1595,14 @@ lora_hip_status lora_hip_detect_preambles_device(lora_hip_decoder_t *h, const vo
     std::vector<lora_hip_window_stats_t> B;
     rc = window_stats_abs(h, (const float2 *)d_iq, boffs, B, st);
     if (rc != LORA_HIP_OK) return rc;
-    size_t n_out = 0;
-    bool overflow = false;
+    // the SFD of every candidate (stage B), then stage C: sub-bin timing of the ones that have one
+    struct Hit { size_t cand; int64_t found; size_t c_first, c_n; int64_t j0, j1; };
+    std::vector<Hit> hits;
+    std::vector<int64_t> coffs;
+    constexpr int64_t kRefineWindows = 6;
     int64_t skip_until = -1; uint32_t skip_stream = 0xffffffffu;
-    for (const Cand &c : cands) {
+    for (size_t ci = 0; ci < cands.size(); ci++) {
+        const Cand &c = cands[ci];
         if (c.stream == skip_stream && c.k < skip_until) continue; // (a run that begins inside the packet just reported)
         const lora_hip_window_stats_t *W = B.data() + c.b_first;
         int64_t found = -1;
@@ -1607,15 +1611,48 @@ lora_hip_status lora_hip_detect_preambles_device(lora_hip_decoder_t *h, const vo
                 W[j + 1].peak_up > W[j + 1].peak_down) { found = (int64_t)j; break; }
         }
         if (found < 0) continue;
+        Hit hit{ci, found, coffs.size(), 0, std::max<int64_t>(0, found - 2 - kRefineWindows), found - 2};
+        while (hit.j0 < hit.j1 && c.a0 + hit.j0 * sps - D / 2 < 0) hit.j0++;
+        for (int64_t dl = -(D / 2); dl <= D / 2 && hit.j0 < hit.j1; dl++)
+            for (int64_t j = hit.j0; j < hit.j1; j++) { coffs.push_back((int64_t)stream_off[c.stream] + c.a0 + j * sps + dl); hit.c_n++; }
+        hits.push_back(hit);
+        skip_stream = c.stream; skip_until = (c.a0 + (found + 2) * sps) / sps;
+    }
+    std::vector<lora_hip_window_stats_t> Cst;
+    rc = window_stats_abs(h, (const float2 *)d_iq, coffs, Cst, st);
+    if (rc != LORA_HIP_OK) return rc;
+    size_t n_out = 0;
+    bool overflow = false;
+    for (const Hit &hit : hits) {
+        const Cand &c = cands[hit.cand];
+        const lora_hip_window_stats_t *W = B.data() + c.b_first;
+        int64_t delta = 0;
+        if (hit.c_n) { // P(delta) = power of bin 0 over the preamble windows moved by delta; the delta with the largest 3-point sum
+            const int64_t nj = hit.j1 - hit.j0, nd = D + 1;
+            std::vector<double> P((size_t)nd, 0.0);
+            for (int64_t i = 0; i < nd; i++)
+                for (int64_t j = 0; j < nj; j++) {
+                    const lora_hip_window_stats_t &w = Cst[hit.c_first + (size_t)(i * nj + j)];
+                    if (w.bin_down == 0) P[(size_t)i] += (double)w.peak_down;
+                }
+            double best = -1.0;
+            for (int64_t i = 0; i < nd; i++) {
+                const double v = P[(size_t)i] + (i >= 1 ? P[(size_t)i - 1] : 0.0) + (i + 1 < nd ? P[(size_t)i + 1] : 0.0);
+                const int64_t d = i - D / 2;
+                const bool closer = std::llabs(d) < std::llabs(delta) || (std::llabs(d) == std::llabs(delta) && d < delta);
+                if (v > best || (v == best && closer)) { best = v; delta = d; }
+            }
+            if (!(best > 0.0)) delta = 0;
+        }
+        const int64_t found = hit.found;
         const int32_t bu = W[found].bin_up, sb = bu < N / 2 ? bu : bu - (int32_t)N;
         if (n_out < cap) {
             lora_hip_preamble_t &o = out[n_out];
-            o.header_pos = c.a0 + found * sps + 2 * sps + sps / 4; o.run_pos = c.k * sps; o.stream = c.stream; o.run_len = (uint32_t)(c.e - c.k);
+            o.header_pos = c.a0 + delta + found * sps + 2 * sps + sps / 4; o.run_pos = c.k * sps; o.stream = c.stream; o.run_len = (uint32_t)(c.e - c.k);
             o.bin = c.bin; o.sfd_index = (int32_t)found; o.pmr = c.pmr; o.cfo_bins = -0.5f * (float)sb;
-            o.cfo_hz = o.cfo_bins * (float)h->cfg.bandwidth / (float)N; o.reserved = 0;
+            o.cfo_hz = o.cfo_bins * (float)h->cfg.bandwidth / (float)N; o.delta = (int32_t)delta;
         } else overflow = true;
         n_out++;
-        skip_stream = c.stream; skip_until = (c.a0 + (found + 2) * sps) / sps;
     }
     *n_found = n_out;
     return overflow ? LORA_HIP_ERR_OVERFLOW : LORA_HIP_OK;

@@ -283,7 +283,9 @@ lora_hip_status lora_hip_estimate_cfo_device(lora_hip_decoder_t *h, const void *
  * windows whose peak-to-mean ratio peak (N-1) / (total - peak) reaches `threshold` (0: ln N + 3) with peak bins agreeing
  * within +-1; the symbol clock is aligned to the run (a carrier offset is absorbed into the alignment exactly as the
  * reference's SYNC step absorbs it, :392-413), the SFD is the first pair of aligned windows dominated by downchirps, and
- * header_pos = SFD + 2.25 symbols (:820-824): feed it to lora_hip_demod_symbols_device at header_pos + k * sps.
+ * the clock is then moved by up to half a bin so that the preamble sits at the CENTRE of bin 0 (what is left of the timing would
+ * otherwise split every data symbol's peak between two bins), and header_pos = SFD + 2.25 symbols (:820-824): feed it to
+ * lora_hip_demod_symbols_device at header_pos + k * sps, or to lora_hip_decode_at_headers_device.
  * cfo_hz: from the opposite displacement of up- and downchirps (resolution bw / 2N).  LORA_HIP_ERR_OVERFLOW when cap is
  * too small (*n_found = what was found).                                                                            */
 typedef struct lora_hip_window_stats {
@@ -301,7 +303,7 @@ typedef struct lora_hip_preamble {
     int32_t  sfd_index;           /* aligned window, counted from the run's first, where the SFD begins                   */
     float    pmr;                 /* mean peak-to-mean ratio over the run                                                  */
     float    cfo_bins, cfo_hz;    /* carrier offset estimate                                                               */
-    uint32_t reserved;
+    int32_t  delta;               /* sub-bin timing refinement applied to header_pos, samples (-D/2 .. D/2)               */
 } lora_hip_preamble_t;
 lora_hip_status lora_hip_detect_preambles_device(lora_hip_decoder_t *h, const void *d_iq, size_t total_items,
                                                  const uint64_t *stream_off, const uint64_t *stream_len, uint32_t n_streams,

@@ -20,7 +20,12 @@ Definition (sps samples per symbol, N = 2^SF bins, D = sps / N; |X|^2 is the pru
            SYNC step does, :392-413.)
   stage B  aligned windows a0 + j * sps over the run and SFD_REACH symbols past it, both references.  The SFD is the first j
            with pmr_up >= thr, peak_up > peak_down, and the same for j + 1 (two whole downchirps).
-  result   header_pos = a_j + 2 sps + sps / 4 (the 2.25 downchirps, :820-824), peak-to-mean ratio of the run, cfo_bins =
+  stage C  sub-bin timing: the alignment above is good to one bin (D samples); what is left - up to half a bin - splits every data
+           symbol's peak between two bins.  For delta = -D/2 .. D/2 samples, P(delta) = the power of BIN 0 (peak_down where
+           bin_down == 0, else 0) summed over the last (up to REFINE_WINDOWS) aligned preamble windows in front of the sync word
+           (j < sfd - 2), moved by delta; delta* maximises P(delta-1) + P(delta) + P(delta+1) (ties: smallest |delta|, then
+           the negative one): the symbol clock moves by it, the upchirps sit at the CENTRE of bin 0.
+  result   header_pos = a_j + delta* + 2 sps + sps / 4 (the 2.25 downchirps, :820-824), peak-to-mean ratio of the run, cfo_bins =
            signed(bin_up at the SFD) / 2 (up- and downchirps move in opposite directions under a carrier offset).
 """
 from __future__ import annotations
@@ -29,6 +34,19 @@ import numpy as np
 
 MIN_RUN = 4
 SFD_REACH = 6
+REFINE_WINDOWS = 6
+
+
+def refine_delta(P, D):
+    """P[i] = summed power of BIN 0 at delta = i - D/2, i = 0 .. D (0 where another bin is the window's peak): the delta whose
+    3-point sum P[i-1] + P[i] + P[i+1] is largest; ties: the smallest |delta|, then the negative one"""
+    best, bd = -1.0, 0
+    for i in range(D + 1):
+        v = float(P[i]) + (float(P[i - 1]) if i >= 1 else 0.0) + (float(P[i + 1]) if i + 1 <= D else 0.0)
+        d = i - D // 2
+        if v > best or (v == best and (abs(d), d) < (abs(bd), bd)):
+            best, bd = v, d
+    return int(bd) if best > 0.0 else 0
 
 
 def default_threshold(nbins: int) -> float:
@@ -65,7 +83,7 @@ def _circ(a, b, n):
     return min(d, n - d)
 
 
-def detect(iq: np.ndarray, down: np.ndarray, nbins: int, threshold: float | None = None):
+def detect(iq: np.ndarray, down: np.ndarray, nbins: int, threshold: float | None = None, refine: bool = True):
     """-> list of dicts: header_pos, run_start (window index), run_len, bin, pmr, sfd_index, cfo_bins"""
     iq = np.asarray(iq)
     sps = down.size
@@ -109,8 +127,19 @@ def detect(iq: np.ndarray, down: np.ndarray, nbins: int, threshold: float | None
             if found is not None:
                 bu = B[found][3]
                 sb = bu if bu < nbins // 2 else bu - nbins
-                out.append(dict(header_pos=int(a0 + found * sps + 2 * sps + sps // 4), run_start=k, run_len=e - k, bin=int(b), pmr=pmr_run,
-                                sfd_index=int(found), cfo_bins=-0.5 * sb))
+                delta = 0
+                js = [j for j in range(max(0, found - 2 - REFINE_WINDOWS), found - 2) if a0 + j * sps - D // 2 >= 0]
+                if refine and js:
+                    P = []
+                    for dl in range(-(D // 2), D // 2 + 1):
+                        acc = 0.0
+                        for j in js:
+                            ws = window_stats(iq, a0 + j * sps + dl, down, nbins)
+                            acc += ws[1] if ws[0] == 0 else 0.0
+                        P.append(acc)
+                    delta = refine_delta(P, D)
+                out.append(dict(header_pos=int(a0 + delta + found * sps + 2 * sps + sps // 4), run_start=k, run_len=e - k, bin=int(b), pmr=pmr_run,
+                                sfd_index=int(found), cfo_bins=-0.5 * sb, delta=int(delta)))
                 k = max(e, (a0 + (found + 2) * sps) // sps)                  # go on behind the SFD
                 continue
         k = e

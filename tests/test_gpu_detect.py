@@ -51,7 +51,7 @@ def test_window_stats_and_detection_equal_the_definition(oracle_mod, sf, snr_db)
     have = h.detect_preambles_device(dev.data_ptr(), st.iq.size, [0], [st.iq.size])
     h.close()
     assert len(want) == 3
-    assert [(d["header_pos"], d["bin"], d["sfd_index"], d["run_len"]) for d in have] == [(d["header_pos"], d["bin"], d["sfd_index"], d["run_len"]) for d in want]
+    assert [(d["header_pos"], d["bin"], d["sfd_index"], d["run_len"], d["delta"]) for d in have] == [(d["header_pos"], d["bin"], d["sfd_index"], d["run_len"], d["delta"]) for d in want]
     for a, b in zip(have, want):
         assert a["cfo_bins"] == b["cfo_bins"] and abs(a["pmr"] - b["pmr"]) <= 5e-3 * b["pmr"] and abs(a["cfo_hz"] - b["cfo_bins"] * cfg.bw / cfg.nbins) < 1e-2
 
@@ -118,7 +118,7 @@ def test_config5_end_to_end_without_ground_truth(reduced_rate):
     truth = np.array((st.shifts[0][0] + st.shifts[0][1])[:n_sym])     # on the aligned clock the carrier offset is gone: the bins ARE the shifts
     e = np.abs(got - truth)
     e = np.minimum(e, cfg.nbins - e)
-    assert (e <= 1).mean() >= 0.98 and (e <= 2).all(), (np.nonzero(e > 1)[0][:10], e.max())
+    assert (e == 0).mean() >= 0.97 and (e <= 1).all(), (np.nonzero(e > 0)[0][:10], e.max())   # (with the sub-bin refinement: the bins themselves)
 
 
 @pytest.mark.parametrize("sf,demod", [(7, 2), (7, 0), (8, 1), (9, 2), (10, 0), (12, 2)])
