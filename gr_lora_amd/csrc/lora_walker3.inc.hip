@@ -722,7 +722,8 @@ __device__ __forceinline__ void w3_demod_round_grad(const W3DemodArgs &P, const 
     float *edge = reinterpret_cast<float *>(L.data + (size_t)grp * G::data_entries); // [(p 16 + c) GW + wave]: the last bin of every wavefront
     const uint32_t tu = (uint32_t)t;
 
-    float f[PAIRS][16], A[PAIRS][16];
+    float f[PAIRS][16]; // (the bin averages are formed twice - for the boundary values before the barrier, for the differences behind it - rather
+                         // than kept: 64 more live registers per thread at SF12 were 137 spilled ones)
     float en = 0.0f;
     if (valid) {
 #pragma unroll
@@ -764,8 +765,7 @@ __device__ __forceinline__ void w3_demod_round_grad(const W3DemodArgs &P, const 
             for (int c = 0; c < 16; c++) {
                 float v = f[p][c];
                 v += dpp_f<kDppQuadXor1>(v); v += dpp_f<kDppQuadXor2>(v); v += dpp_f<kDppRowHalfMirror>(v); // the 8 samples of the bin (:475)
-                A[p][c] = v * 0.125f; // / d_decim_factor (:476)
-                if (lane == 63) edge[(p * 16 + c) * GW + gwave] = A[p][c];
+                if (lane == 63) edge[(p * 16 + c) * GW + gwave] = v * 0.125f; // / d_decim_factor (:476)
             }
     }
     __syncthreads();
@@ -777,14 +777,17 @@ __device__ __forceinline__ void w3_demod_round_grad(const W3DemodArgs &P, const 
         for (int c = 0; c < 16; c++)
 #pragma unroll
             for (int p = 0; p < PAIRS; p++) { // (c, p) ascending = bin index ascending
-                const float perm = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm_addr, __builtin_bit_cast(int, A[p][c])));
+                float Apc = f[p][c];
+                Apc += dpp_f<kDppQuadXor1>(Apc); Apc += dpp_f<kDppQuadXor2>(Apc); Apc += dpp_f<kDppRowHalfMirror>(Apc);
+                Apc *= 0.125f;
+                const float perm = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm_addr, __builtin_bit_cast(int, Apc)));
                 float left = perm;
                 if (lane < 8) { // the bin to the left lives in the previous wavefront / pair / chunk
                     const int pp = (gwave > 0) ? p : (p > 0 ? p - 1 : PAIRS - 1), cc = (gwave > 0 || p > 0) ? c : c - 1;
                     const int ww = (gwave > 0) ? gwave - 1 : GW - 1;
                     left = (cc >= 0) ? edge[(pp * 16 + cc) * GW + ww] : 0.0f;
                 }
-                const float g = left - A[p][c]; // samples_ifreq_avg[i - 1] - samples_ifreq_avg[i] (:482)
+                const float g = left - Apc; // samples_ifreq_avg[i - 1] - samples_ifreq_avg[i] (:482)
                 const int i = (c * CH + p * TG + t) >> 3;
                 if (i >= 1 && g > bv) { bv = g; bi = i; } // strict '>' and ascending i: the first maximum
             }
