@@ -44,6 +44,9 @@ decoder_impl::decoder_impl(float samp_rate, uint32_t bandwidth, uint8_t sf, bool
         std::cerr << "[LoRa Decoder] ERROR : " << lora_hip_strerror(s) << ": " << lora_hip_last_error(nullptr) << std::endl;
         exit(1);
     }
+    /* when a frame reaches the `frames` port: upstream inside the work() call that completes the packet (:870-881); here within
+     * this many milliseconds (+ one call period) of its last sample - the library decodes in passes (default 50 ms) */
+    if (const char *e = std::getenv("LORA_HIP_LATENCY_MS")) lora_hip_set_stream_latency(d_h, (float)std::atof(e));
     uint32_t bins = 0, decim = 0;
     lora_hip_get_geometry(d_h, &d_sps, &bins, &decim);
     std::cout << "Bins per symbol: \t" << bins << std::endl;    /* the constructor's banner, :94-96 */
