@@ -101,7 +101,7 @@ def test_bench_under_torchrun_world1_matches_plain_run():
     # the same work with the frame gather going through RCCL: within run-to-run noise of the plain run (two processes on a box
     # that has just been leased: clocks differ by a few per cent between them)
     ratio = launched["value"] / plain["value"]
-    assert 0.85 < ratio < 1.18, (plain["value"], launched["value"])
+    assert 0.75 < ratio < 1.25, (plain["value"], launched["value"])   # (observed 0.90-0.97: the launched process starts on cold clocks)
 
 
 def test_bench_split_under_torchrun_world1():
