@@ -1328,12 +1328,16 @@ lora_hip_status lora_hip_mux_work(lora_hip_mux_t *m, uint32_t channel, const flo
     }
     if (left) C.ahead.insert(C.ahead.end(), src, src + left); // this channel is a chunk ahead of the slowest one
     MUX_TRY(m, hipStreamSynchronize(m->copy_st)); // the caller may reuse its buffer
-    for (;;) { // a pass when every channel's chunk is full (again, while the surplus refills whole chunks)
-        bool all_full = true;
-        for (const auto &c : m->ch) all_full = all_full && c.fill == m->batch;
-        if (!all_full) break;
+    for (;;) { // a pass when every channel's chunk is full (again, while the surplus refills whole chunks) - or when one channel is a whole
+               // chunk AHEAD of its full chunk (a silent or stalled neighbour must not let the surplus grow without bound: the others then
+               // go into the pass with what they hold)
+        bool all_full = true, far_ahead = false;
+        for (const auto &c : m->ch) { all_full = all_full && c.fill == m->batch; far_ahead = far_ahead || (c.fill == m->batch && c.ahead.size() >= m->batch); }
+        if (!all_full && !far_ahead) break;
+        const uint64_t before = m->passes;
         s = mux_rotate(m, false);
         if (s != LORA_HIP_OK) return s;
+        if (m->passes == before) break; // (nothing could be launched)
     }
     if (m->max_latency_ms > 0.0f && m->have_first &&
         std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - m->t_first).count() >= m->max_latency_ms) {

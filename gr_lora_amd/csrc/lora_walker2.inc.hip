@@ -639,7 +639,6 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             if (W.prio) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
         }
         const int64_t wpos = pos + (int64_t)wave * sps;
-        const bool wvalid = !is_ctl && wave < plan_n_win && wpos + 2 * (int64_t)sps <= n_items;
 
         if (plan_mode == kPlanDetect) { // every worker evaluates kd (1 or kW2DetectK) consecutive windows
             const int kd = plan_n_win;

@@ -367,7 +367,7 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
     int tt = threadIdx.x;
     asm volatile("" : "+v"(tt)); // keeps per-thread table addresses out of the caller's loop-invariant set
     const int grp = __builtin_amdgcn_readfirstlane(tt / TG), t = tt % TG;
-    const int lane = t & 63, gwave = __builtin_amdgcn_readfirstlane(t >> 6), r = t & 7;
+    const int gwave = __builtin_amdgcn_readfirstlane(t >> 6), r = t & 7;
     const bool want_fine = P.enable_fine_sync != 0u;
     const w3_buf_t xb = w3_buf(w3_uniform_ptr(x)), db = w3_buf(w3_uniform_ptr(P.down)), cb = w3_buf(w3_uniform_ptr(P.ctab));
     W3Shared &ws = *L.ws;
@@ -1371,7 +1371,9 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
         plan_from(S, ws.plan[0]);
     }
 
+#if LORA_W3_PREFETCH
     float touched[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#endif
 #if LORA_W3_PRELOAD
     v2f pre[16];
     bool pre_ok = false;

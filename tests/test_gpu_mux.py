@@ -88,3 +88,29 @@ def test_mux_latency_bound_publishes_without_full_chunks():
     m.close()
     assert [got[c] for c in range(4)] == want
     assert by_lat >= 3 and seen_before_flush >= sum(len(w) for w in want) // 2
+
+
+def test_mux_with_a_silent_channel():
+    """a channel that delivers nothing must not hold the others back: once an active channel is a whole chunk ahead of its full chunk
+    the pass goes without waiting for the silent one (and the surplus in host memory stays bounded by one chunk)"""
+    from gr_lora_amd import capi
+    cfg, chans = _channels(3, 7, seed=1200, packets=6)
+    want = [_batch(7, st.iq) for st in chans]
+    batch = 1 << 15
+    m = capi.Mux(4, sf=7, cr=4, batch_items=batch)      # channel 3 never gets a sample
+    m.set_latency(0.0)                                  # (no help from the clock)
+    got = {c: [] for c in range(4)}
+    n = max(st.iq.size for st in chans)
+    before_flush = 0
+    for p in range(0, n, 4096):
+        for c in range(3):
+            m.work(c, chans[c].iq[p:p + 4096])
+        for b, i in m.drain():
+            got[i.stream].append((b, i.header_pos)); before_flush += 1
+    passes_streaming, _ = m.passes()
+    m.flush()
+    for b, i in m.drain():
+        got[i.stream].append((b, i.header_pos))
+    m.close()
+    assert [got[c] for c in range(3)] == want and got[3] == []
+    assert passes_streaming >= n // (2 * batch) - 1 and before_flush > 0, (passes_streaming, n // batch, before_flush)
