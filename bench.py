@@ -348,7 +348,7 @@ def main():
     if args.overlap:
         second = torch.cuda.Stream(device=dev)
         stream = [stream, second.cuda_stream]
-    gat = gather.AsyncSlotGather(dev, max(64, 2 * n_frames_expected))
+    gat = gather.AsyncSlotGather(dev, n_frames_expected + 64)
 
     # One step = one full pass over the batch, software-pipelined the way a streaming receiver runs them
     # (gr_lora_amd.gather.PassPipeline: begin(k+1) before end(k) on one HIP stream, the frames of step k in an asynchronous
@@ -413,7 +413,7 @@ def main():
         except (OSError, ValueError):
             gfix = None
         ghs = [capi.Handle(**dict(kw, demod=0)) for _ in range(depth)]
-        gpipe = gather.PassPipeline(ghs, gather.AsyncSlotGather(dev, max(64, 2 * n_frames_expected)), d_iq.data_ptr(), n_items, offs, lens, stream)
+        gpipe = gather.PassPipeline(ghs, gather.AsyncSlotGather(dev, n_frames_expected + 64), d_iq.data_ptr(), n_items, offs, lens, stream)
         gkept = []
         gpipe.run(depth, gkept)
         gver = None
