@@ -24,7 +24,7 @@ EXPORTS = [
     "lora_hip_decode_device", "lora_hip_frames_available", "lora_hip_poll_frame", "lora_hip_drain_frames", "lora_hip_drain_slots", "lora_hip_demod_symbols_device", "lora_hip_demod_symbols_ex_device",
     "lora_hip_last_timing", "lora_hip_last_plan", "lora_hip_gap_starts_device", "lora_hip_decode_device_begin", "lora_hip_decode_device_end", "lora_hip_decode_device_prepass", "lora_hip_trace", "lora_hip_trace_clear", "lora_hip_check_frame", "lora_hip_estimate_cfo_device",
     "lora_hip_set_stream_latency", "lora_hip_stream_info", "lora_hip_walker_kernel_name", "lora_hip_window_stats_device", "lora_hip_detect_preambles_device", "lora_hip_decode_at_headers_device",
-    "lora_hip_mux_create", "lora_hip_mux_destroy", "lora_hip_mux_work", "lora_hip_mux_flush", "lora_hip_mux_set_latency", "lora_hip_mux_frames_available",
+    "lora_hip_mux_create", "lora_hip_mux_destroy", "lora_hip_mux_work", "lora_hip_mux_flush", "lora_hip_mux_set_latency", "lora_hip_mux_set_max_ahead", "lora_hip_mux_frames_available",
     "lora_hip_mux_poll_frame", "lora_hip_mux_passes", "lora_hip_mux_last_error",
 ]
 
@@ -156,6 +156,7 @@ def load():
     L.lora_hip_mux_work.argtypes = [vp, C.c_uint32, vp, C.c_size_t]
     L.lora_hip_mux_flush.argtypes = [vp]
     L.lora_hip_mux_set_latency.argtypes = [vp, C.c_float]
+    L.lora_hip_mux_set_max_ahead.argtypes = [vp, C.c_size_t]
     L.lora_hip_mux_frames_available.argtypes = [vp]
     L.lora_hip_mux_frames_available.restype = C.c_size_t
     L.lora_hip_mux_poll_frame.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(FrameInfo)]
@@ -447,6 +448,9 @@ class Mux:
 
     def set_latency(self, ms: float):
         self._check(self.L.lora_hip_mux_set_latency(self.h, float(ms)))
+
+    def set_max_ahead(self, items: int):
+        self._check(self.L.lora_hip_mux_set_max_ahead(self.h, int(items)))
 
     def passes(self):
         a, b = C.c_uint64(0), C.c_uint64(0)

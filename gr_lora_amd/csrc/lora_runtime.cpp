@@ -1136,6 +1136,7 @@ struct lora_hip_mux {
     hipEvent_t up_ev = nullptr, tail_ev = nullptr;
     bool inflight = false;
     float max_latency_ms = 50.0f;
+    size_t max_ahead = 0;            // surplus of one channel (items in host memory) at which a pass goes without waiting for the others
     std::chrono::steady_clock::time_point t_first;
     bool have_first = false;
     uint64_t passes = 0, passes_by_latency = 0;
@@ -1161,6 +1162,7 @@ lora_hip_status lora_hip_mux_create(const lora_hip_config_t *cfg, uint32_t n_cha
     m->batch = cfg->batch_items ? cfg->batch_items : std::max<size_t>(1u << 18, 64ull * h->P.sps); // (n channels share a pass: smaller chunks than one stream's)
     m->tailcap = std::max<size_t>(m->batch, 4u * (size_t)h->P.sps);
     m->region = m->tailcap + m->batch;
+    m->max_ahead = std::max<size_t>(8u * m->batch, (size_t)1 << 22);
     m->ch.resize(n_channels);
     for (auto &c : m->ch) c.cr = h->P.ctor_cr;
     bool ok = hipSetDevice(h->device) == hipSuccess && hipStreamCreateWithFlags(&m->copy_st, hipStreamNonBlocking) == hipSuccess &&
@@ -1328,11 +1330,11 @@ lora_hip_status lora_hip_mux_work(lora_hip_mux_t *m, uint32_t channel, const flo
     }
     if (left) C.ahead.insert(C.ahead.end(), src, src + left); // this channel is a chunk ahead of the slowest one
     MUX_TRY(m, hipStreamSynchronize(m->copy_st)); // the caller may reuse its buffer
-    for (;;) { // a pass when every channel's chunk is full (again, while the surplus refills whole chunks) - or when one channel is a whole
-               // chunk AHEAD of its full chunk (a silent or stalled neighbour must not let the surplus grow without bound: the others then
-               // go into the pass with what they hold)
+    for (;;) { // a pass when every channel's chunk is full (again, while the surplus refills whole chunks) - or when one channel's surplus
+               // has reached max_ahead (a silent or stalled neighbour must not let it grow without bound when the latency bound is off:
+               // the others then go into the pass with what they hold)
         bool all_full = true, far_ahead = false;
-        for (const auto &c : m->ch) { all_full = all_full && c.fill == m->batch; far_ahead = far_ahead || (c.fill == m->batch && c.ahead.size() >= m->batch); }
+        for (const auto &c : m->ch) { all_full = all_full && c.fill == m->batch; far_ahead = far_ahead || (c.fill == m->batch && c.ahead.size() >= m->max_ahead); }
         if (!all_full && !far_ahead) break;
         const uint64_t before = m->passes;
         s = mux_rotate(m, false);
@@ -1376,6 +1378,13 @@ lora_hip_status lora_hip_mux_set_latency(lora_hip_mux_t *m, float max_latency_ms
 {
     if (!m || !(max_latency_ms >= 0.0f)) return LORA_HIP_ERR_ARG;
     m->max_latency_ms = max_latency_ms;
+    return LORA_HIP_OK;
+}
+
+lora_hip_status lora_hip_mux_set_max_ahead(lora_hip_mux_t *m, size_t max_ahead_items)
+{
+    if (!m) return LORA_HIP_ERR_ARG;
+    m->max_ahead = max_ahead_items ? max_ahead_items : std::max<size_t>(8u * m->batch, (size_t)1 << 22);
     return LORA_HIP_OK;
 }
 

@@ -157,8 +157,10 @@ lora_hip_status lora_hip_stream_info(const lora_hip_decoder_t *h, lora_hip_strea
  * (constructor arguments from cfg; own d_phdr.cr, power queue, position), fed by lora_hip_mux_work(channel, ...) in any order
  * and chunking; a pass over every channel's buffered samples is launched when ALL channels hold batch_items (cfg) or when
  * the oldest unlaunched sample has waited the latency bound (lora_hip_mux_set_latency, default 50 ms) and is collected by
- * the next call that finds it finished.  A channel may run ahead of the slowest one by any amount (the surplus waits in
- * host memory).  Frames come out of one queue, info.stream = channel; per channel they are what that channel's own
+ * the next call that finds it finished.  A channel may run ahead of the slowest one (the surplus waits in host memory) by up
+ * to lora_hip_mux_set_max_ahead items (default: 8 chunks, at least 4 Mi items); beyond that the pass goes with what the
+ * others hold - a silent or stalled channel cannot let the surplus grow without bound when the latency bound is off.
+ * Frames come out of one queue, info.stream = channel; per channel they are what that channel's own
  * lora_hip_work handle would publish.  One mux = one caller thread at a time.                                            */
 typedef struct lora_hip_mux lora_hip_mux_t;
 lora_hip_status lora_hip_mux_create(const lora_hip_config_t *cfg, uint32_t n_channels, lora_hip_mux_t **out);
@@ -166,6 +168,7 @@ void            lora_hip_mux_destroy(lora_hip_mux_t *m);
 lora_hip_status lora_hip_mux_work(lora_hip_mux_t *m, uint32_t channel, const float *iq, size_t n_items);
 lora_hip_status lora_hip_mux_flush(lora_hip_mux_t *m);
 lora_hip_status lora_hip_mux_set_latency(lora_hip_mux_t *m, float max_latency_ms);
+lora_hip_status lora_hip_mux_set_max_ahead(lora_hip_mux_t *m, size_t max_ahead_items);   /* 0: the default */
 size_t          lora_hip_mux_frames_available(const lora_hip_mux_t *m);
 lora_hip_status lora_hip_mux_poll_frame(lora_hip_mux_t *m, uint8_t *buf, size_t cap, size_t *len, lora_hip_frame_info_t *info);
 lora_hip_status lora_hip_mux_passes(const lora_hip_mux_t *m, uint64_t *passes, uint64_t *passes_by_latency);

@@ -91,14 +91,15 @@ def test_mux_latency_bound_publishes_without_full_chunks():
 
 
 def test_mux_with_a_silent_channel():
-    """a channel that delivers nothing must not hold the others back: once an active channel is a whole chunk ahead of its full chunk
-    the pass goes without waiting for the silent one (and the surplus in host memory stays bounded by one chunk)"""
+    """a channel that delivers nothing must not hold the others back, even with the latency bound off: once an active channel's surplus
+    in host memory reaches max_ahead the pass goes without waiting for the silent one (default 8 chunks / 4 Mi items; one chunk here)"""
     from gr_lora_amd import capi
     cfg, chans = _channels(3, 7, seed=1200, packets=6)
     want = [_batch(7, st.iq) for st in chans]
     batch = 1 << 15
     m = capi.Mux(4, sf=7, cr=4, batch_items=batch)      # channel 3 never gets a sample
     m.set_latency(0.0)                                  # (no help from the clock)
+    m.set_max_ahead(batch)
     got = {c: [] for c in range(4)}
     n = max(st.iq.size for st in chans)
     before_flush = 0
