@@ -28,6 +28,7 @@ tools/pmc_walker.sh sq_sf9 --config 3 --sf 9
 tools/pmc_walker.sh sq_sf12 --config 3 --sf 12
 for t in sq_sf7 sq_sf9 sq_sf12; do python tools/pmc_summary.py gpurun_out/$t > gpurun_out/$t.json; rm -rf gpurun_out/$t; done
 python bench.py --path mux --config 4 --seconds 2 --steps 5 2>/dev/null | tail -1 > gpurun_out/mux_cfg4_2s_line.json
+python bench.py --config 3 --sf 9 --packets 1024 --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/sf9_1024_line.json
 python bench.py --split --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/split1_line.json
 } > gpurun_out/profile_all.log 2>&1
 # keep what travels back small: the per-dispatch traces are not needed once summarised... (kernel_stats + counter_collection csv only)
