@@ -48,6 +48,11 @@ struct DevParams {
     double   sync_a, sync_b;    // least-squares line a + b*k through d_upchirp_ifreq[0 .. sps-2] (closed-form SYNC)
     uint32_t sync_closed_form;  // use the O(sps) SYNC (sps >= 4096)
     uint32_t samples_per_second; // d_samples_per_second (:74), for the CFO estimate's Hz scale
+    // fine_sync (:300-338) decided in closed form by the wave demodulator (SF7 / SF8; lora_wave_demod.inc.hip, FMODE 2): d_upchirp_ifreq_v
+    // is a ramp of slope ffs_alpha with ONE step of ffs_jump - ffs_alpha inside any window fine_sync looks at (bin_idx < N-1), so
+    // c(lag+1) - c(lag) = ffs_alpha * sum(ifreq) + ffs_jump * ifreq[at the step]; what the table's float noise adds is at most ffs_tol
+    uint32_t ffs_on;
+    float    ffs_alpha, ffs_jump, ffs_tol;
     const float2 *down;         // d_downchirp
     const float  *up_ifreq;     // d_upchirp_ifreq
     const float  *down_ifreq;   // d_downchirp_ifreq

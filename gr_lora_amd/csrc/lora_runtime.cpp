@@ -285,6 +285,23 @@ lora_hip_status build_tables(lora_hip_decoder *h)
         // guard tail for bin_idx = N-1 (reference indexes past the vector there, :301,:310)
         for (size_t i = 3u * (size_t)sps; i < up3.size(); i++) up3[i] = up3[3u * (size_t)sps - 1u];
     }
+    { // closed-form fine_sync of the wave demodulator (DevParams::ffs_*): slope, step and noise bound of d_upchirp_ifreq_v as built above
+        P.ffs_on = 0u; P.ffs_alpha = 0.0f; P.ffs_jump = 0.0f; P.ffs_tol = 0.0f;
+        if (D == 8u && (c.sf == 7u || c.sf == 8u) && !getenv("LORA_HIP_NO_FFS")) {
+            const size_t S = sps, lo = S + 7u, hi = 3u * S - 8u; // every dV index a lag difference can touch for bin_idx < N-1: [S+7, 3S-9]
+            auto dV = [&](size_t m) { return (double)up3[m + 1u] - (double)up3[m]; };
+            double sum = 0.0;
+            bool ok = std::fabs(dV(2u * S - 1u)) > 0.5;
+            for (size_t m = lo; m < hi; m++) if (m != 2u * S - 1u) { sum += dV(m); ok = ok && std::fabs(dV(m)) < 0.01; }
+            const double alpha = sum / (double)(hi - lo - 1u);
+            std::vector<double> cs(hi - lo + 1u, 0.0); // prefix sums of the squared deviations from the slope
+            for (size_t m = lo; m < hi; m++) { const double e = (m == 2u * S - 1u) ? 0.0 : dV(m) - alpha; cs[m - lo + 1u] = cs[m - lo] + e * e; }
+            double worst = 0.0;
+            for (size_t o = lo; o + S <= hi; o++) worst = std::max(worst, cs[o + S - lo] - cs[o - lo]);
+            const double tol = 1.05 * M_PI * std::sqrt((double)S) * std::sqrt(worst) + 1.0e-4; // Cauchy-Schwarz with |ifreq| <= pi, + the evaluation's own rounding
+            if (ok && tol < 0.1) { P.ffs_on = 1u; P.ffs_alpha = (float)alpha; P.ffs_jump = (float)(dV(2u * S - 1u) - alpha); P.ffs_tol = (float)tol; }
+        }
+    }
     { // chirp_avg and stddev of the ideal downchirp ifreq over sps-1 points (:287-289, :415-425)
         const uint32_t n = sps - 1u;
         float s = 0.0f;

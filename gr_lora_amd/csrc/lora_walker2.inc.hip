@@ -509,6 +509,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     float *ddl = vl + NV;
     v4f *tab4 = reinterpret_cast<v4f *>(ddl + SPS);
     double *pre = reinterpret_cast<double *>(tab4 + (GRAD ? 0u : WaveGeom<SF>::n_v4f)); // SYNC: chunk prefix sums (2 x 256) + per-wavefront totals
+    v2f *zsv = reinterpret_cast<v2f *>(pre + 2 * 256 + 8); // closed-form fine_sync: one scratch area per worker (wave_demod_symbol FMODE 2)
 
     const uint32_t jid = blockIdx.x;
     if (jid >= C.n_jobs) return;
@@ -897,7 +898,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 float wen = 0.0f;
                 if (dvalid) {
                     if constexpr (GRAD) wave_demod_symbol_grad<SF>(P, FT.v, X + dwpos, P.implicit != 0u, ws, wfine, wen); // ws = bin_idx itself
-                    else wave_demod_symbol<SF, (SF == 7) || LORA_W2_EARLY_F_SF8>(P, FT, X + dwpos, ws, wfine, P.implicit != 0u ? &wen : nullptr);
+                    else wave_demod_symbol<SF, kWaveFmode<SF>>(P, FT, X + dwpos, ws, wfine, P.implicit != 0u ? &wen : nullptr, zsv + wave * kWaveFfsEntries<SF>);
                 }
                 if (lane == 0) { W.speci[plan_buf][widx][0] = dvalid ? (int32_t)ws : -1; W.speci[plan_buf][widx][1] = wfine; W.speci[plan_buf][widx][2] = __builtin_bit_cast(int32_t, wen); }
             }
@@ -1050,5 +1051,6 @@ static uint32_t walker2_lds_bytes(uint32_t sf, bool grad = false)
     const uint32_t sps = 8u << sf;
     const uint32_t nv = (3u * sps + 40u + 3u) & ~3u;
     return (uint32_t)((sizeof(W2Shared) + 15) & ~(size_t)15) + (2u * sps + nv + sps) * (uint32_t)sizeof(float) +
-           (grad ? 0u : wave_tables_floats(sf) * (uint32_t)sizeof(float)) + (2u * 256u + 8u) * (uint32_t)sizeof(double);
+           (grad ? 0u : wave_tables_floats(sf) * (uint32_t)sizeof(float)) + (2u * 256u + 8u) * (uint32_t)sizeof(double) +
+           (grad ? 0u : (uint32_t)(kW2MaxWaves - 1) * (sps / 4u + 4u) * (uint32_t)sizeof(float2)); // (+ the workers' closed-form fine_sync scratch)
 }

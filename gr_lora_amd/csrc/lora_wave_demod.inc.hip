@@ -30,6 +30,9 @@
 // v_fma/mul/add_f32 2.4-3.0, v_pk_{fma,mul,add}_f32 4.3, DPP moves and v_*_dpp 4.3, v_cndmask/v_cmp/v_max 4.3,
 // v_rcp_f32 and v_permlane*_swap 8.2.
 
+#ifndef LORA_W2_FFS
+#define LORA_W2_FFS 3 // bit 0: SF7, bit 1: SF8: fine_sync in closed form (wave_demod_symbol FMODE 2) instead of from sps arctangents
+#endif
 #ifndef LORA_W2_EARLY_F_SF8
 #define LORA_W2_EARLY_F_SF8 1 // SF8: fine_sync's ifreq from the registers loaded for the dechirp (as SF7) instead of a second, cache-hot read:
                               // at the kernel's 256-register budget it fits without a spill (227 VGPRs) and measures +6.5 %
@@ -222,11 +225,34 @@ __device__ __forceinline__ v2f ifreq_prod_pk(v2f p0, v2f c0, v2f p1, v2f c1)
 
 // Demodulates the symbol window x[0 .. sps): s_out = get_shift_fft's return value, fine_out = d_fine_sync after
 // fine_sync(bin_idx, 2) (0 when drift correction is disabled).  Must be called by a whole wavefront.
-template <int SF, bool EARLY_F>
+// FMODE: where fine_sync's instantaneous frequency comes from - 0: a second, cache-hot read of the window behind the FFT; 1: the registers
+// loaded for the dechirp (16 / 32 values per lane kept through the FFT); 2: not computed at all for most windows - the CLOSED FORM (below),
+// with mode 0 as the fall-back when the closed form cannot vouch for the reference's decision.  zs: this wavefront's LDS scratch for
+// mode 2 (kWaveFfsEntries<SF> v2f entries; unused otherwise).
+//
+// The closed form.  fine_sync picks the first maximum > 0 of c(i) = sum_k ifreq[k] v[o + i + k], i = -1, 0, 1 (:306-313; o = shift_ref + sps,
+// ifreq[sps-1] = ifreq[sps-2] :243).  v = d_upchirp_ifreq_v is a ramp of slope alpha with one step J at index 2 sps - 1 inside every
+// stretch fine_sync can look at for bin_idx < N - 1 (DevParams::ffs_*, checked on the table itself at lora_hip_create), so
+//     c(i+1) - c(i) = alpha F + J ifreq[2 sps - 1 - (o + i)] + (table noise, |.| <= ffs_tol),    F = sum_k ifreq[k],
+// and F telescopes: ifreq[k] = theta[k+1] - theta[k] + 2 pi w[k] (:231-240), w[k] = -1 / +1 when the step crosses the negative real axis
+// upwards / downwards - read off the signs of Im x[k], Im x[k+1] and Im(x[k+1] conj x[k]).  So the ORDER of the three correlations needs
+// the window's winding number (two v_cmp per sample and scalar popcounts), arg x[0], arg x[sps-1], ifreq[sps-2] and the ifreq at two
+// samples next to a bin boundary, instead of sps arctangents and 3 sps multiply-adds.  The differences are accepted when they exceed the
+// noise bound.  The SIGN of the maximum (a window without a matching chirp has c <= 0 and the reference then leaves lag = 0) is checked on
+// a uniform quarter of the sum's own terms - the samples n = 0, 1 (mod 8), whose x[n] conj x[n-1] go through LDS; the step sample is
+// always one of them: that partial correlation must reach half of the table's energy over the same terms, and at most sps / 128 samples
+// may turn by more than pi / 2 (noise floor).  Anything else - and bin_idx = N - 1, where the window runs into the table's tail - takes
+// the exact path.  tools/ffs_model.py holds the same rule in numpy against the oracle's fine_sync (0 differing decisions in 7 x 10^5
+// windows: clean, noisy down to -6 dB, interferers, carrier offsets, partial windows); tests/test_gpu_ffs.py holds the kernel to the oracle.
+template <int SF> constexpr int kWaveFfsEntries = (8 << SF) / 4 + 4;
+template <int SF> constexpr int kWaveFmode = ((LORA_W2_FFS >> (SF - 7)) & 1) ? 2 : ((SF == 7) || LORA_W2_EARLY_F_SF8) ? 1 : 0;
+template <int SF, int FMODE>
 __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const WaveTabs &T, const float2 *__restrict__ x, uint32_t &s_out, int32_t &fine_out,
                                                   float *en_out = nullptr /* implicit header: the window's energy (determine_energy, :368-375) */,
+                                                  v2f *zs = nullptr /* FMODE 2: LDS scratch of this wavefront */,
                                                   long long *stamps = nullptr /* tools/probe_phases.hip */)
 {
+    constexpr bool EARLY_F = FMODE == 1;
 #define LORA_WSTAMP(i) do { if (stamps) stamps[i] = clock64(); } while (0)
     LORA_WSTAMP(0);
     using G = WaveGeom<SF>;
@@ -269,6 +295,36 @@ __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const Wave
             const v2f fp = ifreq_prod_pk(p0, a[j], p1, a[j + 1]);
             f[j] = (j == 0 && lane == 0) ? 0.0f : fp.x; // n = 0 has no predecessor in the window
             f[j + 1] = fp.y;
+        }
+    }
+    int ffs_w = 0, ffs_back = 0; // FMODE 2: winding number of the window, samples turning by more than pi / 2 (uniform)
+    if constexpr (FMODE == 2) {
+        if (want_fine && P.ffs_on != 0u) {
+            v2f bprev = (v2f){0.0f, 0.0f}, zlast = (v2f){0.0f, 0.0f};
+            unsigned long long a_prev = 0ull;
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                const v2f b = dpp2<kDppWaveRor1>(a[j]);
+                const v2f p = (lane == 0) ? bprev : b; // sample n - 1 (n = 0: none, z = 0)
+                bprev = b;
+                const v2f z = cmul_conj(a[j], p);      // (re, im) of x[n] conj x[n-1]: ifreq[n-1] = arg z
+                const unsigned long long A = __builtin_amdgcn_ballot_w64(a[j].y < 0.0f), Cm = __builtin_amdgcn_ballot_w64(z.y < 0.0f),
+                                         R = __builtin_amdgcn_ballot_w64(z.x < 0.0f);
+                const unsigned long long B = (A << 1) | (a_prev >> 63); // Im x[n-1] < 0
+                const unsigned long long M = j == 0 ? ~1ull : ~0ull;    // n = 0 has no predecessor
+                ffs_w += __builtin_popcountll(A & ~B & ~Cm & M) - __builtin_popcountll(~A & B & Cm & M);
+                ffs_back += __builtin_popcountll(R & M);
+                a_prev = A;
+                if ((lane & 6) == 0) zs[j * 16 + ((lane >> 3) << 1) + (lane & 1)] = z; // n = 0, 1 (mod 8): entry (n >> 3) * 2 + (n & 1)
+                if (j == J - 1) zlast = z;
+                asm volatile("" : "+s"(ffs_w), "+s"(ffs_back)); // (the counts are needed here: left alone the popcounts sink to their use behind the FFT
+                                                                 // and 6 J scalar registers of lane masks wait for them in VGPR lanes)
+            }
+            // arg x[0] (lane 0), arg x[sps-1] and ifreq[sps-2] = arg z[sps-1] (lane 63): one packed evaluation
+            const v2f sel = (lane == 63) ? zlast : a[0];
+            const v2f r = lean_atan2_pk((v2f){sel.y, a[J - 1].y}, (v2f){sel.x, a[J - 1].x});
+            if (lane == 0) zs[SPS / 4] = (v2f){r.x, 0.0f};
+            if (lane == 63) zs[SPS / 4 + 1] = r; // (ifreq[sps-2], arg x[sps-1])
         }
     }
     LORA_WSTAMP(1);
@@ -344,7 +400,7 @@ __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const Wave
     }
     // late ifreq: second read of the window, pinned behind the reduce-scatter so that the loads are not
     // hoisted above the FFT (where they would hold 4 J more registers)
-    if (!EARLY_F && want_fine) {
+    if (FMODE == 0 && want_fine) {
         int zero = 0;
         asm volatile("; fine-sync reload after the reduce-scatter" : "+v"(zero) : "v"(b1[0].x));
         const int nl2 = nl + zero;
@@ -376,6 +432,55 @@ __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const Wave
     // fine_sync (:300-338) with search = max(D/4, 2) = 2 -> lags -1, 0, +1
     const uint32_t bin_idx = (s == 0u && P.demod_mode == 2u) ? 0u : (s + (uint32_t)N - 1u) % (uint32_t)N;
     const float *__restrict__ v = T.v + ((int)(bin_idx + 1u) * 8 + SPS);
+    if constexpr (FMODE == 2) {
+        bool exact = P.ffs_on == 0u || bin_idx == (uint32_t)N - 1u || ffs_back > SPS / 128;
+        if (!exact) {
+            constexpr int EPL = SPS / 4 / 64; // entries per lane (4 / 8)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the entries were written by other lanes of this wavefront
+            float fe[EPL], cs = 0.0f, es = 0.0f;
+#pragma unroll
+            for (int i = 0; i < EPL; i += 2) {
+                const int e0 = lane + 64 * i, e1 = e0 + 64;
+                const v2f z0 = zs[e0], z1 = zs[e1];
+                const v2f fp = lean_atan2_pk((v2f){z0.y, z1.y}, (v2f){z0.x, z1.x});
+                fe[i] = fp.x; fe[i + 1] = fp.y;
+                const float v0 = v[(e0 >> 1) * 8 + (e0 & 1) - 1], v1 = v[(e1 >> 1) * 8 + (e1 & 1) - 1]; // entry e <-> n = (e >> 1) 8 + (e & 1), ifreq[n-1]
+                cs += fp.x * v0 + fp.y * v1;
+                es += ((i == 0 && lane == 0) ? 0.0f : v0 * v0) + v1 * v1; // (n = 0 is not a term of the sum)
+            }
+            cs = wave_sum_u(cs); es = wave_sum_u(es);
+            const int ea = (int)((uint32_t)SPS - 8u * (bin_idx + 1u)) >> 2; // entry of n = ka = sps - 8 (bin_idx + 1): ifreq[ka-1]; its neighbour n = ka + 1: ifreq[ka]
+            float fb = 0.0f, fa = 0.0f;
+#pragma unroll
+            for (int i = 0; i < EPL; i++)
+                if (i == (ea >> 6)) {
+                    fb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fe[i]), ea & 63));
+                    fa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fe[i]), (ea & 63) + 1));
+                }
+            const v2f e0 = zs[SPS / 4], e1 = zs[SPS / 4 + 1];
+            const float F = (e1.y - e0.x) + 6.28318530717958648f * (float)ffs_w + e1.x;
+            const float D0 = P.ffs_alpha * F + P.ffs_jump * fa, D1 = P.ffs_alpha * F + P.ffs_jump * fb; // c(0) - c(-1), c(1) - c(0)
+            const float tol = P.ffs_tol;
+            int32_t lag;
+            bool sure = fabsf(D0) > tol;
+            if (D0 > 0.0f) { sure = sure && fabsf(D1) > tol; lag = D1 > 0.0f ? 1 : 0; }
+            else { sure = sure && fabsf(D0 + D1) > 2.0f * tol; lag = (D0 + D1) > 0.0f ? 1 : -1; }
+            sure = sure && cs >= 0.5f * es; // (NaN: not sure)
+            if (__builtin_amdgcn_readfirstlane(sure ? 1 : 0) != 0) {
+                fine_out = __builtin_amdgcn_readfirstlane(-lag);
+                LORA_WSTAMP(7);
+                return;
+            }
+        }
+        // the exact path: the window's ifreq from a second, cache-hot read
+#pragma unroll
+        for (int j = 0; j < J; j += 2) {
+            const int n0 = j * 64 + nl, n1 = n0 + 64;
+            const v2f fp = ifreq_prod_pk(xv[n0 >= 1 ? n0 - 1 : 0], xv[n0], xv[n1 - 1], xv[n1]);
+            f[j] = (n0 >= 1) ? fp.x : 0.0f;
+            f[j + 1] = fp.y;
+        }
+    }
     // sample n = 64 j + lane carries ifreq[k], k = n - 1, against v[k - 1], v[k], v[k + 1]: one lane-dependent base and
     // immediate offsets.  (Lane 0, j = 0 has no k: its f is 0 and it reads the finite table entries in front of v.)
     const float *__restrict__ vp = v + (nl - 2);
@@ -564,10 +669,11 @@ __global__ __launch_bounds__(256) void demod_symbols_wave_kernel(DevParams P, co
     const WaveTabs T = wave_tabs_to_lds<SF>(P, lds4, lds_v, 256u);
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6;
+    v2f *zs = reinterpret_cast<v2f *>(lds_v + ((3u * G::SPS + 40u + 3u) & ~3u)) + wave * kWaveFfsEntries<SF>;
     for (uint32_t s = blockIdx.x * 4u + wave; s < n; s += gridDim.x * 4u) {
         uint32_t b;
         int32_t fs;
-        wave_demod_symbol<SF, (SF == 7) || LORA_W2_EARLY_F_SF8>(P, T, iq + offsets[s], b, fs);
+        wave_demod_symbol<SF, kWaveFmode<SF>>(P, T, iq + offsets[s], b, fs, nullptr, zs);
         if ((threadIdx.x & 63u) == 0u) { bins[s] = b; if (fine) fine[s] = fs; }
     }
 }
@@ -593,5 +699,6 @@ __global__ __launch_bounds__(256) void demod_symbols_wave_grad_kernel(DevParams 
 static uint32_t wave_tabs_lds_bytes(uint32_t sf)
 {
     const uint32_t sps = 8u << sf;
-    return wave_tables_floats(sf) * (uint32_t)sizeof(float) + ((3u * sps + 40u + 3u) & ~3u) * (uint32_t)sizeof(float);
+    return wave_tables_floats(sf) * (uint32_t)sizeof(float) + ((3u * sps + 40u + 3u) & ~3u) * (uint32_t)sizeof(float) +
+           4u * (sps / 4u + 4u) * (uint32_t)sizeof(float2); // + demod_symbols_wave_kernel's four closed-form scratch areas
 }

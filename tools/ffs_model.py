@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""The closed-form fine_sync of the wave demodulator (gr_lora_amd/csrc/lora_wave_demod.inc.hip, FMODE 2) in numpy, against the oracle's
+fine_sync (lib/decoder_impl.cc:300-338) on synthetic windows of many kinds: what the rule is, and the evidence that it reproduces the
+reference's decision whenever it claims to (CPU only).
+
+    python tools/ffs_model.py [sf ...] [--n N] [--seed S]
+
+fine_sync picks the first maximum > 0 of c(i) = sum_k ifreq[k] v[o + i + k], i = -1, 0, 1.  v (d_upchirp_ifreq_v) is a ramp of slope
+alpha with one step J at index 2 sps - 1 in every stretch the sum can cover for bin_idx < N - 1, so
+    c(i+1) - c(i) = alpha F + J ifreq[2 sps - 1 - (o + i)] + eta,   F = sum_k ifreq[k],   |eta| <= tol  (table noise, Cauchy-Schwarz)
+and F = arg x[sps-1] - arg x[0] + 2 pi W + ifreq[sps-2] with W the window's winding number (sign tests only).  The sign of the maximum is
+checked on the terms n = 0, 1 (mod 8) of the sum (a uniform quarter): their partial correlation must reach half of the table's energy over
+the same terms, and at most sps / 128 samples may turn by more than pi / 2.  `fast` returns None where the kernel takes the exact path."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gr_lora_amd import synth  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def tables(o):
+    """alpha, J, tol from the table itself - the same computation as lora_hip_create (lora_runtime.cpp, DevParams::ffs_*)"""
+    V = o.table(4).astype(np.float64)
+    S = o.sps
+    dV = np.diff(V)
+    lo, hi = S + 7, 3 * S - 8
+    reg = np.ones(hi - lo, bool)
+    reg[2 * S - 1 - lo] = False
+    alpha = dV[lo:hi][reg].mean()
+    eps = np.where(reg, dV[lo:hi] - alpha, 0.0)
+    cs = np.concatenate([[0.0], np.cumsum(eps ** 2)])
+    worst = max(cs[s + S] - cs[s] for s in range(0, hi - lo - S + 1))
+    tol = 1.05 * np.pi * np.sqrt(S) * np.sqrt(worst) + 1e-4
+    return V, np.float32(alpha), np.float32(dV[2 * S - 1] - alpha), np.float32(tol)
+
+
+def fast(x, bin_idx, S, N, V, alpha, J, tol):
+    """the kernel's rule: (lag, None) or (None, reason for the exact path)"""
+    x = x.astype(np.complex64)
+    if bin_idx == N - 1:
+        return None, "edge"
+    z = (x[1:] * np.conj(x[:-1])).astype(np.complex64)  # z[k] <-> ifreq[k] = arg z[k], k = 0 .. S-2
+    if int((z.real < 0).sum()) > S // 128:
+        return None, "noise"
+    a, b, c = x.imag[1:] < 0, x.imag[:-1] < 0, z.imag < 0
+    W = int((a & ~b & ~c).sum()) - int((~a & b & c).sum())
+    F = np.float32(np.angle(x[-1]) - np.angle(x[0]) + np.float32(2 * np.pi * W) + np.angle(z[S - 2]))
+    o = (bin_idx + 1) * 8 + S
+    k = np.arange(S - 1)
+    sel = k[((k % 8) == 7) | ((k % 8) == 0)]           # samples n = k + 1 = 0, 1 (mod 8)
+    f = np.angle(z[sel]).astype(np.float32)
+    vv = V[o + sel].astype(np.float32)
+    if not float(np.dot(f, vv)) >= 0.5 * float(np.dot(vv, vv)):
+        return None, "sign"
+    ka = S - 8 * (bin_idx + 1)
+    D0 = alpha * F + J * np.float32(np.angle(z[ka]))       # c(0) - c(-1)
+    D1 = alpha * F + J * np.float32(np.angle(z[ka - 1]))   # c(1) - c(0)
+    if abs(D0) <= tol:
+        return None, "D0"
+    if D0 > 0:
+        return (1 if D1 > 0 else 0, None) if abs(D1) > tol else (None, "D1")
+    return (1 if D0 + D1 > 0 else -1, None) if abs(D0 + D1) > 2 * tol else (None, "D01")
+
+
+KINDS = [(40, "up1"), (20, "up1"), (12, "up1"), (8, "up1"), (5, "up1"), (0, "up1"), (-6, "up1"), (None, "noise"), (30, "up6"), (30, "down"), (30, "tone"),
+         (30, "tonechirp"), (20, "halfn"), (None, "halfz"), (30, "two"), (30, "cfo"), (30, "cfot"), (15, "cfot"), (30, "dc"), (30, "burst"), (30, "clip")]
+
+
+def make_window(kind, snr, rng, up, S, N):
+    """one symbol window: the middle chirp of three random ones, cut -1..1 samples off (up6: -6..6), then what `kind` does to it"""
+    s = int(rng.integers(0, N))
+    dt = int(rng.integers(-6, 7)) if kind == "up6" else int(rng.integers(-1, 2))
+    ar = np.arange(S)
+    stream = np.concatenate([up[(ar + int(rng.integers(0, N)) * 8) % S], up[(ar + s * 8) % S], up[(ar + int(rng.integers(0, N)) * 8) % S]])
+    if kind == "cfo":    # carrier offset absorbed as a timing shift
+        c = rng.uniform(-N / 3, N / 3)
+        stream = stream * np.exp(2j * np.pi * c / S * np.arange(3 * S))
+        dt -= int(round(8 * c))
+    if kind == "cfot":   # carrier offset at true timing: the bin moves, the window does not
+        stream = stream * np.exp(2j * np.pi * rng.uniform(-N / 3, N / 3) / S * np.arange(3 * S))
+    w = stream[S + dt:2 * S + dt] * np.exp(1j * rng.uniform(0, 2 * np.pi))
+    if kind == "down":
+        w = np.conj(w)
+    if kind == "tone":
+        w = np.exp(2j * np.pi * rng.uniform(-0.06, 0.06) * ar)
+    if kind == "tonechirp":
+        w = w + rng.uniform(0.1, 3.0) * np.exp(2j * np.pi * rng.uniform(-0.06, 0.06) * ar)
+    if kind == "dc":
+        w = w + rng.uniform(0.1, 3.0) * np.exp(1j * rng.uniform(0, 2 * np.pi))
+    if kind in ("halfn", "halfz"):
+        w = w.copy()
+        w[int(rng.integers(0, S)):] = 0
+    if kind == "two":
+        w = w + rng.uniform(0.1, 1.5) * up[(ar + int(rng.integers(0, N)) * 8 + int(rng.integers(0, 8))) % S] * np.exp(1j * rng.uniform(0, 2 * np.pi))
+    if kind == "burst":
+        w = w.copy()
+        a0 = int(rng.integers(0, S - 64))
+        L = min(int(rng.integers(8, 200)), S - a0)
+        w[a0:a0 + L] += rng.uniform(1, 5) * (rng.standard_normal(L) + 1j * rng.standard_normal(L))
+    if kind == "clip":
+        w = np.clip(w.real, -0.5, 0.5) + 1j * np.clip(w.imag, -0.5, 0.5)
+    if kind == "noise":
+        w = 0 * w
+        sig = 1 / np.sqrt(2)
+    else:
+        sig = 0.0 if snr is None else 10 ** (-snr / 20) / np.sqrt(2)
+    return (w + sig * (rng.standard_normal(S) + 1j * rng.standard_normal(S))).astype(np.complex64)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("sf", nargs="*", type=int, default=[7, 8])
+    ap.add_argument("--n", type=int, default=1000)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    for sf in a.sf:
+        o = O.Oracle(sf=sf)
+        S, N = o.sps, 1 << sf
+        V, alpha, J, tol = tables(o)
+        up = synth.base_upchirp(synth.TxConfig(sf=sf, cr=4))
+        rng = np.random.default_rng(a.seed)
+        print("SF%d: alpha %.6g, J %.6g, tol %.4g" % (sf, alpha, J, tol))
+        total = bad = 0
+        for snr, kind in KINDS:
+            n_fast = n_bad = 0
+            why = {}
+            for _ in range(a.n):
+                w = make_window(kind, snr, rng, up, S, N)
+                bin_idx = (o.get_shift_fft(w) + N - 1) % N
+                ref = -o.fine_sync(w, bin_idx, 2)
+                lag, r = fast(w, bin_idx, S, N, V, alpha, J, tol)
+                if lag is None:
+                    why[r] = why.get(r, 0) + 1
+                else:
+                    n_fast += 1
+                    n_bad += lag != ref
+            total += n_fast
+            bad += n_bad
+            print("  %-9s %5s dB: closed form %5.1f %%, differing %d; exact path for %s" % (kind, snr, 100.0 * n_fast / a.n, n_bad, why))
+        print("SF%d: %d closed-form decisions, %d differ from the oracle's fine_sync" % (sf, total, bad))
+
+
+if __name__ == "__main__":
+    main()

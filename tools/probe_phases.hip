@@ -22,7 +22,7 @@ __global__ __launch_bounds__(1024) void probe(DevParams P, const float2 *iq, uin
     const long long t0 = clock64();
     for (int r = 0; r < reps; r++) {
         const size_t sym = ((size_t)blockIdx.x * nw + wave) * reps + r;
-        wave_demod_symbol<SF, SF == 7>(P, T, iq + sym * G::SPS, s, f, nullptr, (blockIdx.x == 0 && wave == 0 && r == reps - 1) ? st : nullptr);
+        wave_demod_symbol<SF, SF == 7 ? 1 : 0>(P, T, iq + sym * G::SPS, s, f, nullptr, nullptr, (blockIdx.x == 0 && wave == 0 && r == reps - 1) ? st : nullptr);
     }
     const long long t1 = clock64();
     if ((threadIdx.x & 63) == 0) { out[(blockIdx.x * nw + wave) * 2] = s; out[(blockIdx.x * nw + wave) * 2 + 1] = (uint32_t)f; }
