@@ -509,7 +509,9 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     float *ddl = vl + NV;
     v4f *tab4 = reinterpret_cast<v4f *>(ddl + SPS);
     double *pre = reinterpret_cast<double *>(tab4 + (GRAD ? 0u : WaveGeom<SF>::n_v4f)); // SYNC: chunk prefix sums (2 x 256) + per-wavefront totals
-    v2f *zsv = reinterpret_cast<v2f *>(pre + 2 * 256 + 8); // closed-form fine_sync: one scratch area per worker (wave_demod_symbol FMODE 2)
+    // closed-form fine_sync (wave_demod_symbol FMODE 2): one scratch area per worker.  SYNC's two work areas (f2, pre) are idle in decode rounds
+    // and take the first workers; the others get an area behind `pre`.  (All seven behind `pre` made the SF7 workgroup 80.4 KB: one per CU.)
+    constexpr int kZsN = kWaveFfsEntries<SF>, kZsF2 = (2 * SPS * 4) / (kZsN * 8), kZsPre = ((2 * 256 + 8) * 8) / (kZsN * 8);
 
     const uint32_t jid = blockIdx.x;
     if (jid >= C.n_jobs) return;
@@ -521,6 +523,9 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     AttemptRec *recs = C.recs + (size_t)jid * C.recs_per_job;
     StepRec *trace = C.trace ? C.trace + (size_t)jid * C.trace_cap : nullptr;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    v2f *zs_mine = (wave < kZsF2)            ? reinterpret_cast<v2f *>(f2) + wave * kZsN
+                   : (wave < kZsF2 + kZsPre) ? reinterpret_cast<v2f *>(pre) + (wave - kZsF2) * kZsN
+                                              : reinterpret_cast<v2f *>(pre + 2 * 256 + 8) + (wave - kZsF2 - kZsPre) * kZsN;
     const bool is_ctl = wave == kW2Workers;                 // control wavefront
     const bool t0 = threadIdx.x == kW2Workers * 64;         // the control thread: sole owner of the decoder state S
     if (is_ctl) __builtin_amdgcn_s_setprio(2);              // its serial bookkeeping is on every round's critical path
@@ -898,7 +903,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 float wen = 0.0f;
                 if (dvalid) {
                     if constexpr (GRAD) wave_demod_symbol_grad<SF>(P, FT.v, X + dwpos, P.implicit != 0u, ws, wfine, wen); // ws = bin_idx itself
-                    else wave_demod_symbol<SF, kWaveFmode<SF>>(P, FT, X + dwpos, ws, wfine, P.implicit != 0u ? &wen : nullptr, zsv + wave * kWaveFfsEntries<SF>);
+                    else wave_demod_symbol<SF, kWaveFmode<SF>>(P, FT, X + dwpos, ws, wfine, P.implicit != 0u ? &wen : nullptr, zs_mine);
                 }
                 if (lane == 0) { W.speci[plan_buf][widx][0] = dvalid ? (int32_t)ws : -1; W.speci[plan_buf][widx][1] = wfine; W.speci[plan_buf][widx][2] = __builtin_bit_cast(int32_t, wen); }
             }
@@ -1046,11 +1051,17 @@ __global__ __launch_bounds__(64 * kW2WavesSf8, LORA_W2_EU_GRAD_SF8) void walker2
 
 static uint32_t walker2_threads(uint32_t sf) { return 64u * (uint32_t)(sf == 7u ? kW2WavesSf7 : kW2WavesSf8); }
 
+static uint32_t w2_ffs_extra_workers(uint32_t sps)
+{
+    const uint32_t zb = (sps / 4u + 4u) * (uint32_t)sizeof(float2), fit = (2u * sps * 4u) / zb + ((2u * 256u + 8u) * 8u) / zb, workers = (uint32_t)kW2MaxWaves - 1u;
+    return workers > fit ? workers - fit : 0u;
+}
+
 static uint32_t walker2_lds_bytes(uint32_t sf, bool grad = false)
 {
     const uint32_t sps = 8u << sf;
     const uint32_t nv = (3u * sps + 40u + 3u) & ~3u;
     return (uint32_t)((sizeof(W2Shared) + 15) & ~(size_t)15) + (2u * sps + nv + sps) * (uint32_t)sizeof(float) +
            (grad ? 0u : wave_tables_floats(sf) * (uint32_t)sizeof(float)) + (2u * 256u + 8u) * (uint32_t)sizeof(double) +
-           (grad ? 0u : (uint32_t)(kW2MaxWaves - 1) * (sps / 4u + 4u) * (uint32_t)sizeof(float2)); // (+ the workers' closed-form fine_sync scratch)
+           (grad ? 0u : w2_ffs_extra_workers(sps) * (sps / 4u + 4u) * (uint32_t)sizeof(float2)); // (+ closed-form fine_sync scratch of the workers that do not fit SYNC's idle areas)
 }
