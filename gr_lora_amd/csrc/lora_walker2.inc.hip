@@ -1053,6 +1053,7 @@ static uint32_t walker2_threads(uint32_t sf) { return 64u * (uint32_t)(sf == 7u 
 
 static uint32_t w2_ffs_extra_workers(uint32_t sps)
 {
+    if (!((LORA_W2_FFS >> (sps == 1024u ? 0 : 1)) & 1)) return 0u;
     const uint32_t zb = (sps / 4u + 4u) * (uint32_t)sizeof(float2), fit = (2u * sps * 4u) / zb + ((2u * 256u + 8u) * 8u) / zb, workers = (uint32_t)kW2MaxWaves - 1u;
     return workers > fit ? workers - fit : 0u;
 }

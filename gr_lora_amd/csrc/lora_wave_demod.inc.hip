@@ -31,7 +31,9 @@
 // v_rcp_f32 and v_permlane*_swap 8.2.
 
 #ifndef LORA_W2_FFS
-#define LORA_W2_FFS 3 // bit 0: SF7, bit 1: SF8: fine_sync in closed form (wave_demod_symbol FMODE 2) instead of from sps arctangents
+#define LORA_W2_FFS 0 // bit 0: SF7, bit 1: SF8: fine_sync in closed form (wave_demod_symbol FMODE 2) instead of from sps arctangents.  Built, held to the
+                      // oracle on the GPU (tests/test_gpu_ffs.py with the switch on: 221 passed) and measured: 16 % fewer VALU instructions per symbol, but the
+                      // lane-mask bookkeeping is scalar work of the same wavefront - SF7 -4 %, SF8 -1 % (profiles/r03_ab_closed_form_fine_sync.txt): off
 #endif
 #ifndef LORA_W2_EARLY_F_SF8
 #define LORA_W2_EARLY_F_SF8 1 // SF8: fine_sync's ifreq from the registers loaded for the dechirp (as SF7) instead of a second, cache-hot read:
@@ -700,5 +702,5 @@ static uint32_t wave_tabs_lds_bytes(uint32_t sf)
 {
     const uint32_t sps = 8u << sf;
     return wave_tables_floats(sf) * (uint32_t)sizeof(float) + ((3u * sps + 40u + 3u) & ~3u) * (uint32_t)sizeof(float) +
-           4u * (sps / 4u + 4u) * (uint32_t)sizeof(float2); // + demod_symbols_wave_kernel's four closed-form scratch areas
+           (((LORA_W2_FFS >> (sps == 1024u ? 0 : 1)) & 1) ? 4u * (sps / 4u + 4u) * (uint32_t)sizeof(float2) : 0u); // + demod_symbols_wave_kernel's four closed-form scratch areas
 }
