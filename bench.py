@@ -348,7 +348,12 @@ def main():
     if args.overlap:
         second = torch.cuda.Stream(device=dev)
         stream = [stream, second.cuda_stream]
-    gat = gather.AsyncSlotGather(dev, n_frames_expected + 64)
+    gather_cap = n_frames_expected + 64
+    if use_dist:  # all_gather_into_tensor needs one shape on every rank (the gateway workload's packet count differs from rank to rank)
+        capt = torch.tensor([gather_cap], dtype=torch.int64, device=dev)
+        dist.all_reduce(capt, op=dist.ReduceOp.MAX)
+        gather_cap = int(capt.item())
+    gat = gather.AsyncSlotGather(dev, gather_cap)
 
     # One step = one full pass over the batch, software-pipelined the way a streaming receiver runs them
     # (gr_lora_amd.gather.PassPipeline: begin(k+1) before end(k) on one HIP stream, the frames of step k in an asynchronous
@@ -413,7 +418,7 @@ def main():
         except (OSError, ValueError):
             gfix = None
         ghs = [capi.Handle(**dict(kw, demod=0)) for _ in range(depth)]
-        gpipe = gather.PassPipeline(ghs, gather.AsyncSlotGather(dev, n_frames_expected + 64), d_iq.data_ptr(), n_items, offs, lens, stream)
+        gpipe = gather.PassPipeline(ghs, gather.AsyncSlotGather(dev, gather_cap), d_iq.data_ptr(), n_items, offs, lens, stream)
         gkept = []
         gpipe.run(depth, gkept)
         gver = None
