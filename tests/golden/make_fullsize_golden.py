@@ -33,6 +33,9 @@ for _sf in (7, 8, 9, 10, 11, 12):
         CASES.append(("config3-sf%d-cr%d" % (_sf, _cr), _sf, _cr, 256, 32, 8, 100 * _sf + _cr))
 
 
+CASES.append(("config3-sf8-cr4-1024packets", 8, 4, 1024, 32, 8, 804))  # the SF8 profile workload (tools/profile_all.sh: 1024 packets fill the device)
+
+
 def digest(frames):
     h = hashlib.sha256()
     for f in frames:

@@ -118,6 +118,11 @@ def test_config3_full_size_grad_vs_reference_fixture(sf, cr):
     _against_reference_fixture("config3-sf%d-cr%d" % (sf, cr))
 
 
+def test_sf8_profile_workload_grad_vs_reference_fixture():
+    """the SF8 workload of the profile set (1024 packets: tools/profile_all.sh) in the reference's shipped mode"""
+    _against_reference_fixture("config3-sf8-cr4-1024packets")
+
+
 @pytest.mark.parametrize("sf", [7, 8, 9, 10, 11, 12])
 def test_config3_full_size(oracle_mod, sf):
     n = 256
