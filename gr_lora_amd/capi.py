@@ -17,12 +17,13 @@ LIB_PATH = os.environ.get("LORA_HIP_LIB") or os.path.join(_HERE, "liblora_hip.so
 DEMOD_GRAD, DEMOD_FFT, DEMOD_FFT_COMPAT = 0, 1, 2
 FLAG_TRACE = 1
 FLAG_PIN_HOST = 2
+FLAG_FAST_SYNC = 4  # keep SYNC's closed-form maximum (no exact re-evaluation of near-tied shifts)
 
 EXPORTS = [
     "lora_hip_abi_version", "lora_hip_strerror", "lora_hip_last_error", "lora_hip_create", "lora_hip_destroy",
     "lora_hip_get_geometry", "lora_hip_set_sf", "lora_hip_set_samp_rate", "lora_hip_work", "lora_hip_flush",
     "lora_hip_decode_device", "lora_hip_frames_available", "lora_hip_poll_frame", "lora_hip_drain_frames", "lora_hip_drain_slots", "lora_hip_demod_symbols_device", "lora_hip_demod_symbols_ex_device",
-    "lora_hip_last_timing", "lora_hip_last_plan", "lora_hip_gap_starts_device", "lora_hip_decode_device_begin", "lora_hip_decode_device_end", "lora_hip_decode_device_prepass", "lora_hip_trace", "lora_hip_trace_clear", "lora_hip_check_frame", "lora_hip_estimate_cfo_device",
+    "lora_hip_last_timing", "lora_hip_last_plan", "lora_hip_gap_starts_device", "lora_hip_decode_device_begin", "lora_hip_decode_device_end", "lora_hip_decode_device_prepass", "lora_hip_trace", "lora_hip_trace_clear", "lora_hip_check_frame", "lora_hip_estimate_cfo_device", "lora_hip_ref_ifreq_device",
     "lora_hip_set_stream_latency", "lora_hip_stream_info", "lora_hip_walker_kernel_name", "lora_hip_window_stats_device", "lora_hip_detect_preambles_device", "lora_hip_decode_at_headers_device",
     "lora_hip_mux_create", "lora_hip_mux_destroy", "lora_hip_mux_work", "lora_hip_mux_flush", "lora_hip_mux_set_latency", "lora_hip_mux_set_max_ahead", "lora_hip_mux_frames_available",
     "lora_hip_mux_poll_frame", "lora_hip_mux_passes", "lora_hip_mux_last_error",
@@ -145,6 +146,8 @@ def load():
     L.lora_hip_trace_clear.restype = None
     L.lora_hip_estimate_cfo_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_int64), C.c_size_t, C.c_int, C.POINTER(C.c_float), vp]
     L.lora_hip_estimate_cfo_device.restype = C.c_int
+    L.lora_hip_ref_ifreq_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float), vp]
+    L.lora_hip_ref_ifreq_device.restype = C.c_int
     L.lora_hip_window_stats_device.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(WindowStats), vp]
     L.lora_hip_detect_preambles_device.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_uint32, C.c_float, C.POINTER(Preamble), C.c_size_t, C.POINTER(C.c_size_t), vp]
     L.lora_hip_decode_at_headers_device.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_uint32, C.POINTER(Preamble), C.c_size_t, vp]
@@ -305,6 +308,14 @@ class Handle:
         self._check(self.L.lora_hip_estimate_cfo_device(self.h, C.c_void_p(dev_ptr), total_items, off.ctypes.data_as(C.POINTER(C.c_int64)), off.size, mode,
                                                         out.ctypes.data_as(C.POINTER(C.c_float)), C.c_void_p(stream)))
         return out
+
+    def ref_ifreq_device(self, dev_ptr: int, n_items: int, stream: int = 0):
+        """(atan2f of every item, instantaneous_frequency of every pair) as the strict SYNC path computes them (decoder_impl.cc:231-240)."""
+        arg = np.zeros(n_items, dtype=np.float32)
+        f = np.zeros(n_items - 1, dtype=np.float32)
+        self._check(self.L.lora_hip_ref_ifreq_device(self.h, C.c_void_p(dev_ptr), n_items, arg.ctypes.data_as(C.POINTER(C.c_float)),
+                                                     f.ctypes.data_as(C.POINTER(C.c_float)), C.c_void_p(stream)))
+        return arg, f
 
     def window_stats_device(self, dev_ptr: int, total_items: int, offsets: Sequence[int], stream: int = 0):
         """lora_hip_window_stats_device: per window (bin_down, peak_down, total_down, bin_up, peak_up, total_up)."""

@@ -47,6 +47,7 @@ struct DevParams {
     float    down_ifreq_dsum;   // sum over sps-1 points of (down_ifreq - down_ifreq_avg): float residue
     double   sync_a, sync_b;    // least-squares line a + b*k through d_upchirp_ifreq[0 .. sps-2] (closed-form SYNC)
     uint32_t sync_closed_form;  // use the O(sps) SYNC (sps >= 4096)
+    uint32_t strict_sync;       // SYNC: shifts within rounding of the closed-form maximum are re-evaluated with the reference's own float sums (lora_strict_sync.inc.hip)
     uint32_t samples_per_second; // d_samples_per_second (:74), for the CFO estimate's Hz scale
     // fine_sync (:300-338) decided in closed form by the wave demodulator (SF7 / SF8; lora_wave_demod.inc.hip, FMODE 2): d_upchirp_ifreq_v
     // is a ramp of slope ffs_alpha with ONE step of ffs_jump - ffs_alpha inside any window fine_sync looks at (bin_idx < N-1), so
@@ -154,6 +155,7 @@ const char *walker_kernel_name(const DevParams &p);                        // th
 int launch_demod_symbols(const DevParams &p, const float2 *iq, const int64_t *d_offsets, uint32_t n,
                          int demod, uint32_t *d_bins, int32_t *d_fine, float *scratch, void *stream);
 int launch_detect_windows(const DevParams &p, const float2 *iq, const int64_t *d_offsets, uint32_t n, void *d_out /* 24 B per window */, void *stream); // N4: lora_detect.inc.hip
+int launch_ref_ifreq(const float2 *x, uint32_t n, float *d_arg, float *d_ifreq, void *stream); // diagnostics: the strict SYNC path's atan2f / ifreq
 int launch_cfo(const DevParams &p, const float2 *iq, const int64_t *d_offsets, uint32_t n, int mode, float *d_out, void *stream); // N4: explicit CFO estimate
 bool walker3_covers(uint32_t sf);                                          // SF9-12: lora_walker3.inc.hip
 uint32_t w3_tw_entries(uint32_t sf);

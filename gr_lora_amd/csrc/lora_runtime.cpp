@@ -321,6 +321,9 @@ lora_hip_status build_tables(lora_hip_decoder *h)
         P.sync_b = (n * sku - sk * su) / (n * skk - sk * sk);
         P.sync_a = (su - P.sync_b * sk) / n;
         P.sync_closed_form = (sps >= 4096u && !getenv("LORA_HIP_SYNC_DIRECT")) ? 1u : 0u;
+        // near-tied SYNC shifts decided by the reference's own float sums (lora_strict_sync.inc.hip): on unless the caller opts out
+        P.strict_sync = (c.flags & LORA_HIP_FLAG_FAST_SYNC) ? 0u : 1u;
+        if (const char *e = getenv("LORA_HIP_STRICT_SYNC")) P.strict_sync = (e[0] != '0') ? 1u : 0u; // (A/B runs)
     }
     for (uint32_t t = 0; t < N / 2u; t++) {
         const double a = -2.0 * M_PI * (double)t / (double)N;
@@ -1524,6 +1527,20 @@ lora_hip_status lora_hip_estimate_cfo_device(lora_hip_decoder_t *h, const void *
     if (launch_cfo(h->P, (const float2 *)d_iq, h->d_offsets.p, (uint32_t)n, mode, reinterpret_cast<float *>(h->d_bins.p), st) != 0)
         return fail(h, LORA_HIP_ERR_HIP, "cfo launch failed: %s", hipGetErrorString(hipGetLastError()));
     HIP_TRY(h, hipMemcpyAsync(cfo_hz_out, h->d_bins.p, n * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    return LORA_HIP_OK;
+}
+
+lora_hip_status lora_hip_ref_ifreq_device(lora_hip_decoder_t *h, const void *d_iq, size_t n_items, float *arg_out, float *ifreq_out, void *hip_stream)
+{
+    if (!h || !d_iq || !arg_out || !ifreq_out || n_items < 2 || n_items > 0x7fffffffu) return LORA_HIP_ERR_ARG;
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, h->d_scratch.reserve(2u * n_items));
+    if (launch_ref_ifreq((const float2 *)d_iq, (uint32_t)n_items, h->d_scratch.p, h->d_scratch.p + n_items, st) != 0)
+        return fail(h, LORA_HIP_ERR_HIP, "ref_ifreq launch failed: %s", hipGetErrorString(hipGetLastError()));
+    HIP_TRY(h, hipMemcpyAsync(arg_out, h->d_scratch.p, n_items * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(ifreq_out, h->d_scratch.p + n_items, (n_items - 1u) * sizeof(float), hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipStreamSynchronize(st));
     return LORA_HIP_OK;
 }

@@ -93,6 +93,7 @@ struct alignas(16) W2Shared {
     uint32_t det_streak;  // consecutive DETECT rounds planned so far (control thread): the first of a streak looks at fewer windows
     uint32_t prio;        // priority of the worker wavefronts for the coming rounds (see the balance exchange in the round loop)
     uint32_t words_pk[2]; // d_words of the current block, one byte per word (words < 256 for SF <= 8); control thread only
+    strict::Cands sc;     // SYNC: near-tied shifts for the exact re-evaluation
 };
 
 struct W2Tabs {
@@ -421,7 +422,7 @@ __device__ __forceinline__ W2SfdOut w2_sfd_window(const float2 *p, const float *
 // ideal upchirp ifreq.  Kept out of line: it runs once per packet and its double-precision temporaries would otherwise
 // raise the register pressure of the whole state machine.
 template <int SF, int WAVES>
-__device__ __attribute__((noinline)) void w2_sync_closed_form(const float *f2, double *pre, double sync_a, double sync_b, float &bv, int &bi)
+__device__ __attribute__((noinline)) void w2_sync_closed_form(const float *f2, double *pre, double sync_a, double sync_b, float &bv, int &bi, float &b2, int &i2)
 {
     constexpr uint32_t sps = 8u << SF, kW2 = 64u * WAVES;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -460,6 +461,8 @@ __device__ __attribute__((noinline)) void w2_sync_closed_form(const float *f2, d
                 const uint32_t i0 = threadIdx.x * R;
                 bv = 0.0f; // max_correlation = 0 (:400)
                 bi = 0x7fffffff;
+                b2 = 0.0f; // second best of this thread: the other half of a near-tie (lora_strict_sync.inc.hip)
+                i2 = 0x7fffffff;
                 if (sps % kW2 != 0u && i0 >= sps) return;
                 auto prefix_at = [&](uint32_t j, double &F, double &G) { // sums over t < j
                     const uint32_t c = j / CH;
@@ -475,11 +478,37 @@ __device__ __attribute__((noinline)) void w2_sync_closed_form(const float *f2, d
                     const uint32_t i = i0 + r;
                     if (sps % kW2 != 0u && i >= sps) break;
                     const float c = (float)(sync_a * s0 + sync_b * s1);
-                    if (c > bv) { bv = c; bi = (int)i; }
+                    if (c > bv) { b2 = bv; i2 = bi; bv = c; bi = (int)i; }
+                    else if (c > b2) { b2 = c; i2 = (int)i; }
                     const double fin = (double)f2[i + n], fout = (double)f2[i];
                     s0 += fin - fout;
                     s1 += (double)n * fin - s0;
                 }
+}
+
+// strict SYNC (lora_strict_sync.inc.hip): the window's instantaneous frequency as the REFERENCE computes it - two atan2f and the unwrap
+// (:231-240), bit for bit - so that the closed form and the re-evaluation of its near-ties share the arctangents (one per sample: every
+// thread's arguments pass through f2 to the neighbour that needs them).  Out of line: it runs once per packet, and its registers must not
+// be the state machine's.
+template <int SF, int WAVES>
+__device__ __attribute__((noinline)) void w2_sync_exact_ifreq(const float2 *__restrict__ x, float *f2)
+{
+    constexpr int SPS = 8 << SF, kW2 = 64 * WAVES, NI = 2 * SPS / kW2;
+    static_assert(NI * kW2 == 2 * SPS, "whole samples per thread");
+    typedef __attribute__((address_space(3))) float lds_f;
+    lds_f *fl = (lds_f *)f2;
+    float2 xv[NI];
+    float am[NI], an[NI];
+#pragma unroll
+    for (int k = 0; k < NI; k++) xv[k] = x[threadIdx.x + (uint32_t)k * kW2];
+#pragma unroll
+    for (int k = 0; k < NI; k++) { am[k] = strict::fd_atan2f(xv[k].y, xv[k].x); fl[threadIdx.x + (uint32_t)k * kW2] = am[k]; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NI; k++) { const uint32_t i = threadIdx.x + (uint32_t)k * kW2; an[k] = fl[i + 1u < 2u * SPS ? i + 1u : i]; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NI; k++) fl[threadIdx.x + (uint32_t)k * kW2] = strict::ref_ifreq(am[k], an[k]); // (the last one, 0, is overwritten by the caller: :243)
 }
 
 // ---- the kernel -----------------------------------------------------------------------------------------
@@ -741,7 +770,9 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
 
         if (plan_mode == kPlanSync) { // :770-783, detect_upchirp :392-413 -- all wavefronts together
             const float2 *__restrict__ x = X + pos;
-            {
+            if (P.strict_sync) {
+                w2_sync_exact_ifreq<SF, WAVES>(x, f2);
+            } else {
                 constexpr int NI = (2 * SPS + kW2 - 1) / kW2; // samples per thread: all loads first, then the arithmetic
                 float2 xb[NI], xa[NI];
 #pragma unroll
@@ -758,12 +789,24 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 }
             }
             __syncthreads();
-            if (t0) f2[2u * sps - 1u] = f2[2u * sps - 2u]; // :243
+            if (t0) { f2[2u * sps - 1u] = f2[2u * sps - 2u]; strict::cands_reset(W.sc); } // :243
             __syncthreads();
-            float bv;
-            int bi;
-            w2_sync_closed_form<SF, WAVES>(f2, pre, P.sync_a, P.sync_b, bv, bi);
+            float bv, b2;
+            int bi, i2;
+            w2_sync_closed_form<SF, WAVES>(f2, pre, P.sync_a, P.sync_b, bv, bi, b2, i2);
+            const float my_bv = bv;
+            const int my_bi = bi;
             w2_block_argmax_first<WAVES>(bv, bi, W.red);
+            if (P.strict_sync) { // shifts within rounding of the maximum: the reference's own float sums decide (:399-407)
+                strict::cands_push(W.sc, bv, my_bv, my_bi, b2, i2);
+                __syncthreads();
+                const int nc = W.sc.n;
+                if (nc >= 2 && nc <= strict::kK) {
+                    float ev;
+                    bi = strict::resolve_lds<kW2>(f2, SPS, vl, &W.sc, reinterpret_cast<float *>(pre), 1024, &ev); // (the closed form's prefix sums are done with: 4160 bytes; vl[k] = d_upchirp_ifreq[k], k < sps-1)
+                    bv = ev;
+                }
+            }
             if (t0) {
                 const int32_t consumed = (bi == 0x7fffffff) ? 0 : bi; // :771
                 W2State L = S;

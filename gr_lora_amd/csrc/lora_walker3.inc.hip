@@ -118,6 +118,7 @@ struct alignas(16) W3Shared {
     int32_t  ibc[8];               // broadcasts (FIND_SFD lag per group)
     W2Plan   plan[2];              // the round plan, double-buffered
     W2State  st;                   // decoder state: thread 0 only
+    strict::Cands sc;              // SYNC: near-tied shifts for the exact re-evaluation
     W2Stats  stats;                // per-state time accounting (LORA_HIP_DEBUG)
     int64_t  ph_start;             // hand-over from the job proper to its tail probe (Job.probe_limit)
     uint32_t ph_go, ph_cr, ph_natt, ph_pad;
@@ -958,7 +959,8 @@ __device__ __forceinline__ void w3_sync_ifreq16(const __attribute__((address_spa
     }
 }
 template <int SF>
-__device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double sync_b, const float2 *__restrict__ x, W3Shared *wsp, int slot)
+__device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double sync_b, const float2 *__restrict__ x, W3Shared *wsp, int slot,
+                                                       const float *__restrict__ strict_u /* d_upchirp_ifreq, or nullptr: closed form only */, float *strict_buf)
 {
     using G = W3Geom<SF>;
     constexpr int SPS = G::SPS, LEN = G::LEN, WAVES = G::T / 64;
@@ -967,6 +969,7 @@ __device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double syn
     const auto xv = (const __attribute__((address_space(1))) v2f *)x;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int i0 = t * LEN;
+    if (t == 0) strict::cands_reset(ws.sc); // (ordered before the pushes by the scan's barrier)
     double s0A = 0.0, gA = 0.0, s0B = 0.0, gB = 0.0; // sums of f and of (pos - sps) f over A and B
     // More than 16 shifts per thread (the 512-thread geometry at SF11 / SF12): the two ifreq segments are not kept (2 x 32 / 2 x 64
     // floats beside as many samples: a 0.5-1.1 KB stack frame per lane, 60-180 spilled registers) but computed twice, 16 at a time -
@@ -1043,6 +1046,8 @@ __device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double syn
     double s0 = F1 - F0, s1 = (G1 - G0) + (double)(SPS - i0) * s0;
     float bv = 0.0f; // max_correlation = 0 (:400)
     int bi = 0x7fffffff;
+    float b2 = 0.0f; // this thread's second-best shift: a near-tie's other half (lora_strict_sync.inc.hip)
+    int i2 = 0x7fffffff;
     if constexpr (CHUNKED) {
 #pragma unroll 1
         for (int q = 0; q < LEN; q += 16) {
@@ -1051,7 +1056,8 @@ __device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double syn
 #pragma unroll
             for (int rr = 0; rr < 16; rr++) {
                 const float c = (float)(sync_a * s0 + sync_b * s1);
-                if (c > bv) { bv = c; bi = i0 + q + rr; }
+                if (c > bv) { b2 = bv; i2 = bi; bv = c; bi = i0 + q + rr; }
+                else if (c > b2) { b2 = c; i2 = i0 + q + rr; }
                 const double fin = (double)fb[rr], fout = (double)fa[rr];
                 s0 += fin - fout;
                 s1 += (double)n * fin - s0;
@@ -1061,7 +1067,8 @@ __device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double syn
 #pragma unroll
     for (int rr = 0; rr < LEN; rr++) {
         const float c = (float)(sync_a * s0 + sync_b * s1);
-        if (c > bv) { bv = c; bi = i0 + rr; }
+        if (c > bv) { b2 = bv; i2 = bi; bv = c; bi = i0 + rr; }
+        else if (c > b2) { b2 = c; i2 = i0 + rr; }
         const double fin = (double)fb[rr], fout = (double)fa[rr];
         s0 += fin - fout;
         s1 += (double)n * fin - s0;
@@ -1070,6 +1077,8 @@ __device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double syn
     // first maximum over the workgroup
     float *red = ws.red[slot][0];
     slot ^= 1;
+    const float my_bv = bv;
+    const int my_bi = bi;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_xor(bv, o, 64);
@@ -1083,6 +1092,16 @@ __device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double syn
         const float ov = red[w];
         const int oi = ((int *)red)[32 + w];
         if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (strict_u) { // shifts within rounding of the maximum: the reference's own float sums decide (:399-407)
+        strict::cands_push(ws.sc, bv, my_bv, my_bi, b2, i2);
+        __syncthreads();
+        const int nc = ws.sc.n;
+        if (nc >= 2 && nc <= strict::kK) {
+            float ev;
+            bi = strict::resolve<G::T, 2048, true>(x, SPS, strict_u, &ws.sc, strict_buf, &ev);
+            bv = ev;
+        }
     }
     return W3SyncOut{bv, bi, slot};
 }
@@ -1449,7 +1468,7 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
         }
 
         if (plan_mode == kPlanSync) { // :770-783
-            const W3SyncOut so = w3_sync<SF>(P.sync_a, P.sync_b, X + pos, &ws, slot);
+            const W3SyncOut so = w3_sync<SF>(P.sync_a, P.sync_b, X + pos, &ws, slot, P.strict_sync ? P.up_ifreq : nullptr, reinterpret_cast<float *>(L.data));
             slot = __builtin_amdgcn_readfirstlane(so.slot);
             if (t0) {
                 W2State St = S;

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LORA_HIP_ABI_VERSION 2   /* 2: lora_hip_set_stream_latency, lora_hip_stream_info, lora_hip_walker_kernel_name, lora_hip_window_stats_device, lora_hip_detect_preambles_device, lora_hip_decode_at_headers_device, lora_hip_mux_* */
+#define LORA_HIP_ABI_VERSION 3   /* 3: LORA_HIP_FLAG_FAST_SYNC (strict SYNC is the default), lora_hip_ref_ifreq_device; 2: lora_hip_set_stream_latency, lora_hip_stream_info, lora_hip_walker_kernel_name, lora_hip_window_stats_device, lora_hip_detect_preambles_device, lora_hip_decode_at_headers_device, lora_hip_mux_* */
 
 typedef enum lora_hip_status {
     LORA_HIP_OK = 0,
@@ -46,6 +46,11 @@ typedef enum lora_hip_demod {
 } lora_hip_demod;
 
 #define LORA_HIP_FLAG_TRACE 0x1u    /* record one lora_hip_step_t per state-machine step (tests / debugging) */
+#define LORA_HIP_FLAG_FAST_SYNC 4u /* SYNC (detect_upchirp, decoder_impl.cc:392-413): keep the closed-form maximum as it is.  Without this flag every shift
+                                      within rounding of that maximum is re-evaluated with the reference's own arithmetic (glibc's atan2f, the unwrap of
+                                      :231-240, one sequential float sum per shift as volk_32f_x2_dot_prod_32f_generic adds) and the FIRST maximum of those
+                                      sums wins, as in :399-407 - on a clean preamble two adjacent shifts tie to ~6 / sps^2 of the peak and the float
+                                      arithmetic alone decides.  Costs 1.5-4 % of a pass; FFT demodulators publish the same bytes either way. */
 #define LORA_HIP_FLAG_PIN_HOST 2u  /* lora_hip_work may page-lock (hipHostRegister) the caller's buffers to DMA straight from them;
                                       only for long-lived buffers the caller uses for nothing else.  Memory that is already
                                       page-locked (hipHostMalloc / registered by the caller) is always used directly. */
@@ -269,6 +274,13 @@ void            lora_hip_trace_clear(lora_hip_decoder_t *h);
 lora_hip_status lora_hip_estimate_cfo_device(lora_hip_decoder_t *h, const void *d_iq, size_t total_items,
                                              const int64_t *offsets, size_t n, int mode, float *cfo_hz_out,
                                              void *hip_stream);
+
+/* Diagnostics of the strict SYNC path (LORA_HIP_FLAG_FAST_SYNC above): the arithmetic it re-evaluates near-tied shifts with, on
+ * caller-given device samples.  arg_out[i] = atan2f(im, re) of item i as glibc's libm computes it (std::arg, decoder_impl.cc:232-233),
+ * ifreq_out[i] = instantaneous_frequency's value for the pair (i, i+1) (:231-240), i < n_items - 1.  Host buffers of n_items and
+ * n_items - 1 floats.  tests/test_gpu_strict_sync.py holds both to the host's libm bit for bit.                                     */
+lora_hip_status lora_hip_ref_ifreq_device(lora_hip_decoder_t *h, const void *d_iq, size_t n_items, float *arg_out, float *ifreq_out,
+                                          void *hip_stream);
 
 /* ---- FFT-domain preamble detection (beyond the reference) --------------------------------------
  * The reference acquires a packet with a time-domain autocorrelation of adjacent symbols (detect_preamble_autocorr,

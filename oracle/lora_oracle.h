@@ -105,6 +105,8 @@ float    lora_oracle_detect_preamble_autocorr(lora_oracle_t *o, const float *iq)
 float    lora_oracle_detect_downchirp(lora_oracle_t *o, const float *iq);           /* :385-390 */
 float    lora_oracle_detect_upchirp(lora_oracle_t *o, const float *iq, int32_t *index); /* :392-413 */
 void     lora_oracle_instantaneous_frequency(const float *iq, float *out, uint32_t window); /* :224-244 */
+float    lora_oracle_fd_atan2f(float y, float x);                  /* fdlibm's atan2f restated (= glibc 2.35's, which std::arg at :232-233 calls) */
+uint64_t lora_oracle_fd_atan2f_mismatches(uint64_t n, uint64_t seed); /* restatement vs the host's libm over n pseudo-random pairs */
 /* per-symbol bins for a list of symbol start offsets (ground-truth timing, config 5) */
 void     lora_oracle_demod_at(lora_oracle_t *o, const float *iq, const int64_t *offsets, size_t n,
                               int mode, uint32_t *bins_out);

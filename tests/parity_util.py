@@ -3,7 +3,9 @@
 `exact=True`: every work() step must match the oracle's - state, input position, consume_each, bin, d_fine_sync - and the
 decision values to 1e-3.
 
-`exact=False` is for the operating points where the REFERENCE'S OWN timing decisions are below the resolution of its float
+`exact=False` is for decoders created with LORA_HIP_FLAG_FAST_SYNC (the closed-form SYNC maximum alone, the only behaviour up to
+round 3; since round 4 the near-tie is decided with the reference's own arithmetic, tests/test_gpu_strict_sync.py, and every test
+compares exactly): the operating points where the REFERENCE'S OWN timing decisions are below the resolution of its float
 sums: the sliding correlation of SYNC (decoder_impl.cc:399-413) ties between adjacent shifts to 1e-6 .. 2e-8 relative
 (SF8 .. SF12: the ideal upchirp's ifreq sums to ~0, so C[t0 + 1] - C[t0] = b sum(u) vanishes), and which shift wins is
 decided by the summation order of VOLK's dot product.  tests/test_ref_pin.py::test_sync_shift_depends_on_volk_summation_order
@@ -13,11 +15,21 @@ of states, every position within one sample, identical frames (checked by the ca
 import numpy as np
 
 
-def assert_trace_parity(tr, otr, exact, tag=None):
+def windows_with_exact_zeros(otr, iq, sps):
+    """decode steps whose symbol window holds a sample that is EXACTLY zero (the silence a synthetic stream ends in): the reference's
+    arg(0) = 0 turns the instantaneous frequency next to it into -arg(x[k]), the kernels' arg(x[k+1] conj x[k]) into 0 - a deviation
+    that exists only on synthetic zeros and that only the gradient estimator can see, in the bin of that one window"""
+    import numpy as np
+    return {i for i, b in enumerate(otr) if b[0] in (4, 5) and bool(np.any(iq[b[1]:b[1] + sps + 1] == 0))}
+
+
+def assert_trace_parity(tr, otr, exact, tag=None, skip_bin=()):
     assert len(tr) == len(otr), (tag, len(tr), len(otr))
     off = 0
     for i, (a, b) in enumerate(zip(tr, otr)):
-        if exact:
+        if exact and i in skip_bin:
+            assert tuple(a[:3]) == tuple(b[:3]) and a[4] == b[4], (tag, i, a, b)
+        elif exact:
             assert tuple(a[:5]) == tuple(b[:5]), (tag, i, a, b)
             if np.isfinite(b[5]):
                 assert abs(a[5] - b[5]) <= 1e-3 * max(1.0, abs(b[5])), (tag, i, a, b)

@@ -33,7 +33,8 @@ def _compare(oracle_mod, iq, demod, exact=True, **kw):
         assert [i.header_pos for _, i in got] == o.frame_positions(), (demod, kw)
     else:
         assert all(abs(i.header_pos - p) <= 1 for (_, i), p in zip(got, o.frame_positions())), (demod, kw)
-    assert_trace_parity(tr, o.trace(), exact, (demod, kw))
+    from parity_util import windows_with_exact_zeros
+    assert_trace_parity(tr, o.trace(), exact, (demod, kw), skip_bin=windows_with_exact_zeros(o.trace(), iq, 8 << kw["sf"]) if demod == 0 else ())
     return len(got)
 
 
@@ -46,10 +47,9 @@ def test_disable_drift_correction(oracle_mod, sf, demod):
         rng = np.random.default_rng(31 * sf + cr)
         payloads = [bytes(rng.integers(0, 256, int(rng.integers(4, 28)), dtype=np.uint8)) for _ in range(n)]
         st = synth.build_stream(payloads, cfg, rng=rng, noise_sigma=synth.awgn_sigma_for_snr(42.0, cfg))
-        # noisy: the SYNC shift may tie (parity_util); without drift correction the one sample is then never pulled back
-        got = _compare(oracle_mod, st.iq, demod, exact=False, sf=sf, cr=cr, reduced_rate=(sf > 10), disable_drift_correction=True)
+        got = _compare(oracle_mod, st.iq, demod, sf=sf, cr=cr, reduced_rate=(sf > 10), disable_drift_correction=True)
         assert got == n
-        if sf <= 10: # clean: exact
+        if True:
             st = synth.build_stream(payloads, cfg, rng=np.random.default_rng(5 * sf + cr))
             assert _compare(oracle_mod, st.iq, demod, exact=True, sf=sf, cr=cr, reduced_rate=(sf > 10), disable_drift_correction=True) == n
 
@@ -64,7 +64,7 @@ def test_implicit_header(oracle_mod, sf, demod):
         rng = np.random.default_rng(17 * sf + cr)
         payloads = [bytes(rng.integers(0, 256, int(rng.integers(6, 24)), dtype=np.uint8)) for _ in range(n)]
         st = synth.build_stream(payloads, cfg, rng=rng)
-        got = _compare(oracle_mod, st.iq, demod, exact=(sf <= 10), sf=sf, cr=cr, crc=crc, reduced_rate=(sf > 10), implicit=True)
+        got = _compare(oracle_mod, st.iq, demod, sf=sf, cr=cr, crc=crc, reduced_rate=(sf > 10), implicit=True)
         assert got >= 1
 
 
@@ -94,4 +94,4 @@ def test_walker3_noisy_mixed_cr_segments(oracle_mod, sf):
             got = h.drain()
             h.close()
             assert [g.hex() for g, _ in got] == [f.hex() for f in o.frames()], (sf, demod, seg)
-            assert all(abs(i.header_pos - p) <= 1 for (_, i), p in zip(got, o.frame_positions())), (sf, demod, seg)  # noisy: parity_util
+            assert [i.header_pos for _, i in got] == o.frame_positions(), (sf, demod, seg)

@@ -1,0 +1,118 @@
+"""detect_upchirp's first-maximum decision (decoder_impl.cc:392-413) reproduced, not approximated.
+
+SYNC's sliding correlation ties between two adjacent shifts to ~6 / sps^2 of its peak on a clean preamble; the reference's
+float arithmetic alone decides which wins.  The kernels find the maximum in closed form (double) and then re-evaluate every
+near-tied shift with the reference's own arithmetic (gr_lora_amd/csrc/lora_strict_sync.inc.hip):
+  * the device's atan2f and instantaneous frequency == the host libm's, bit for bit (it IS the reference's std::arg);
+  * SF7-SF12 traces == the oracle's (which is pinned to the compiled reference, tests/test_ref_pin.py) step for step, clean
+    and noisy, every demodulator - including SF11 / SF12, where the closed form alone lands one sample beside the reference;
+  * with LORA_HIP_FLAG_FAST_SYNC the closed-form maximum stands (the pre-round-4 behaviour: positions within one sample)."""
+import numpy as np
+import pytest
+
+from gr_lora_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(iq):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(iq).view(np.float32)).cuda()
+
+
+def test_device_atan2f_and_ifreq_equal_libm(oracle_mod):
+    """lora_hip_ref_ifreq_device vs the host: atan2f through the oracle's restatement (held to libm in
+    tests/test_atan2f_restatement.py, and again here), ifreq through lora_oracle_instantaneous_frequency (libm's atan2f itself)"""
+    import ctypes as C
+    from gr_lora_amd import capi
+    L = oracle_mod.lib()
+    L.lora_oracle_fd_atan2f_mismatches.restype = C.c_uint64
+    L.lora_oracle_fd_atan2f_mismatches.argtypes = [C.c_uint64, C.c_uint64]
+    assert L.lora_oracle_fd_atan2f_mismatches(5_000_000, 11) == 0           # this host's libm IS the restated algorithm
+    rng = np.random.default_rng(12)
+    cfg = synth.TxConfig(sf=8, cr=4)
+    sig = synth.build_stream([bytes(range(24))], cfg, rng=rng, noise_sigma=synth.awgn_sigma_for_snr(20.0, cfg)).iq
+    bits = rng.integers(0, 2 ** 32, size=(1 << 20, 2), dtype=np.uint64).astype(np.uint32).view(np.float32)
+    bits = bits[np.isfinite(bits).all(axis=1)]
+    wild = (bits[:, 0] + 1j * bits[:, 1]).astype(np.complex64)
+    axes = np.array([0, 1, -1, 1j, -1j, 1e-30, -1e-30 + 1e-30j, 1e30 + 1j, 1 + 1e30j, -0.0, 3e38 + 3e38j, 1 + 1j, -1 - 1j, 0.4375 + 1j, 1 + 0.4375j], dtype=np.complex64)
+    for iq in (sig, wild, axes, np.zeros(64, np.complex64)):
+        h = capi.Handle(sf=8)
+        arg, f = h.ref_ifreq_device(_dev(iq).data_ptr(), iq.size)
+        h.close()
+        want_arg = np.arctan2(iq.imag.astype(np.float64), iq.real.astype(np.float64))  # (only a sanity bound: numpy is not libm)
+        assert np.all(np.abs(arg.astype(np.float64) - want_arg) <= 4e-7 * np.maximum(1.0, np.abs(want_arg)))
+        want_f = oracle_mod.instantaneous_frequency(iq)[:-1]                       # libm atan2f + the reference's unwrap
+        assert f.view(np.uint32).tolist() == want_f.view(np.uint32).tolist()
+        # atan2f itself, bit for bit, against libm through ctypes
+        libm = C.CDLL("libm.so.6")
+        libm.atan2f.restype = C.c_float
+        libm.atan2f.argtypes = [C.c_float, C.c_float]
+        idx = rng.integers(0, iq.size, size=min(iq.size, 4000))
+        for i in idx:
+            assert np.float32(libm.atan2f(float(iq.imag[i]), float(iq.real[i]))).view(np.uint32) == arg[i].view(np.uint32), (i, iq[i])
+
+
+def _traces(oracle_mod, iq, demod, flags=0, **kw):
+    from gr_lora_amd import capi
+    o = oracle_mod.Oracle(demod=demod, **kw)
+    o.enable_trace()
+    o.run(iq)
+    h = capi.Handle(demod=demod, flags=capi.FLAG_TRACE | flags, **kw)
+    dev = _dev(iq)
+    h.decode_device(dev.data_ptr(), iq.size, [0], [iq.size], 0)
+    got = h.drain()
+    tr = h.trace()
+    h.close()
+    return got, tr, o
+
+
+@pytest.mark.parametrize("sf", [7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("demod", [0, 2])
+def test_sync_decision_is_the_reference_s(oracle_mod, sf, demod):
+    """clean and noisy packets: frames, header positions and the complete work() trace equal the oracle's at EVERY spreading
+    factor (no +-1-sample latitude at SF11 / SF12 any more)"""
+    from parity_util import assert_trace_parity
+    n = {7: 6, 8: 5, 9: 4, 10: 3, 11: 3, 12: 2}[sf]
+    for snr in (None, 40.0):
+        cfg = synth.TxConfig(sf=sf, cr=4, reduced_rate=(sf > 10))
+        rng = np.random.default_rng(77 * sf + (0 if snr is None else 1))
+        payloads = [bytes(rng.integers(0, 256, int(rng.integers(4, 20)), dtype=np.uint8)) for _ in range(n)]
+        st = synth.build_stream(payloads, cfg, rng=rng, noise_sigma=0.0 if snr is None else synth.awgn_sigma_for_snr(snr, cfg))
+        kw = dict(sf=sf, cr=4, reduced_rate=(sf > 10))
+        got, tr, o = _traces(oracle_mod, st.iq, demod, **kw)
+        assert [g.hex() for g, _ in got] == [f.hex() for f in o.frames()], (sf, demod, snr)
+        assert [i.header_pos for _, i in got] == o.frame_positions(), (sf, demod, snr)
+        assert_trace_parity(tr, o.trace(), True, (sf, demod, snr))
+        assert len(got) == n
+
+
+@pytest.mark.parametrize("sf", [11, 12])
+def test_fast_sync_flag_keeps_the_closed_form(oracle_mod, sf):
+    """LORA_HIP_FLAG_FAST_SYNC: the double-precision maximum stands - one sample beside the reference's float sums on a clean
+    SF11 / SF12 preamble, same frames from the FFT demodulators"""
+    from gr_lora_amd import capi
+    from parity_util import assert_trace_parity
+    cfg = synth.TxConfig(sf=sf, cr=4, reduced_rate=True)
+    st = synth.build_stream([b"fast sync", bytes(range(12))], cfg, rng=np.random.default_rng(sf))
+    kw = dict(sf=sf, cr=4, reduced_rate=True)
+    got, tr, o = _traces(oracle_mod, st.iq, 2, flags=capi.FLAG_FAST_SYNC, **kw)
+    assert [g.hex() for g, _ in got] == [f.hex() for f in o.frames()]
+    assert all(abs(i.header_pos - p) <= 1 for (_, i), p in zip(got, o.frame_positions()))
+    assert_trace_parity(tr, o.trace(), False, sf)
+
+
+@pytest.mark.parametrize("sf,decim_bw", [(8, 250000), (10, 500000)])
+def test_generic_kernel_sync_decision(oracle_mod, sf, decim_bw):
+    """the generic kernels (decimation 4 / 2: bandwidth 250 / 500 kHz at 1 Msps) take the same strict path"""
+    from parity_util import assert_trace_parity
+    cfg = synth.TxConfig(sf=sf, cr=4, bw=decim_bw)
+    rng = np.random.default_rng(5 + sf)
+    st = synth.build_stream([bytes(rng.integers(0, 256, 9, dtype=np.uint8)) for _ in range(3)], cfg, rng=rng)
+    kw = dict(sf=sf, cr=4, bandwidth=decim_bw)
+    for demod in (0, 2):
+        got, tr, o = _traces(oracle_mod, st.iq, demod, **kw)
+        assert [g.hex() for g, _ in got] == [f.hex() for f in o.frames()], (sf, demod)
+        assert [i.header_pos for _, i in got] == o.frame_positions(), (sf, demod)
+        assert_trace_parity(tr, o.trace(), True, (sf, demod))
+        assert len(got) == 3
