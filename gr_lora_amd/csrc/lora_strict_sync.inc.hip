@@ -10,8 +10,10 @@
 //     restatement to libm bit for bit on the host, tests/test_gpu_strict_sync.py the device to the host),
 //   * the unwrap with its float difference and double correction (:236-237),
 //   * one product and one float add per tap, in tap order, no contraction -
-// by ONE lane per candidate.  The products are made by the whole workgroup, CH taps at a time, into LDS; wave 0 adds them up.
-// 5 shader clocks per tap: 5 k clocks per SYNC at SF7, 164 k at SF12 (1.4-4 % of a job); LORA_HIP_FLAG_FAST_SYNC skips it.
+// by ONE lane per candidate.  The products are made by the whole workgroup, a chunk of taps at a time, into LDS; wave 0 adds them up.
+// Measured (profiles/r04_strict_sync_*): a dependent v_add_f32 chain runs at 8 shader clocks per tap on one wavefront whatever feeds it
+// (8 k clocks per SYNC at SF7, 262 k at SF12), the exact arctangents cost about as much again at SF7: 7-8 % of a pass at every
+// spreading factor.  LORA_HIP_FLAG_FAST_SYNC skips it (the closed-form maximum stands: one sample beside the reference at SF11 / SF12).
 #pragma once
 
 namespace strict {
@@ -147,8 +149,9 @@ __device__ __forceinline__ void cands_push(Cands &C, float gmax, float v1, int i
 }
 
 // The adding lane (one per candidate): acc += p[0], += p[1], ... over GP groups of four taps laid out [group][NC][4] in LDS, in tap order.
-// Two register batches of eight ds_read_b128 (32 taps) alternate: one is in flight while the other is added up - the loop is the serial
-// floor of the whole re-evaluation, ~6 shader clocks per tap (with a wait behind every read it was 25).
+// A ring of four register batches of four ds_read_b128 (16 taps each): three are in flight (~200 clocks of cover for the LDS round trip)
+// while the fourth is added up - the loop is the serial floor of the whole re-evaluation, ~5.5 shader clocks per tap (with a wait behind
+// every read it was 25, with two batches of eight 8).
 template <int NC>
 __device__ __forceinline__ float chain_add(const float *src, int lane, int GP, float acc)
 {
@@ -156,22 +159,24 @@ __device__ __forceinline__ float chain_add(const float *src, int lane, int GP, f
     typedef float v4f __attribute__((ext_vector_type(4))); // (a plain vector type: HIP's float4 has no assignment from an LDS-qualified object)
     typedef __attribute__((address_space(3))) const v4f lds_f4;
     lds_f4 *s4 = (lds_f4 *)(__attribute__((address_space(3))) const float *)src + lane;
-    v4f A[8], B[8];
+    v4f R[4][4];
 #pragma unroll
-    for (int q = 0; q < 8; q++) A[q] = s4[q * NC];
+    for (int b = 0; b < 3; b++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) R[b][q] = s4[(4 * b + q) * NC];
     for (int g = 0; g < GP; g += 16) { // (GP is a multiple of 16: chunks of at least 64 taps)
-        lds_f4 *sb = s4 + (g + 8) * NC;
 #pragma unroll
-        for (int q = 0; q < 8; q++) B[q] = sb[q * NC];
-        asm volatile("" : "+v"(acc) :: "memory"); // the next batch is requested BEFORE this one is added up (the scheduler sinks reads to their use, and hoists the adds, otherwise)
+        for (int b = 0; b < 4; b++) {
+            // request the batch three ahead (wrapping to the chunk's start at its end: read, never added), THEN add this one up; tying the adds to
+            // the barrier keeps the scheduler from sinking the reads to their use or hoisting the adds
+            const int gn = g + 4 * b + 12;
+            lds_f4 *sn = s4 + (gn < GP ? gn : 0) * NC;
 #pragma unroll
-        for (int q = 0; q < 8; q++) { acc = acc + A[q].x; acc = acc + A[q].y; acc = acc + A[q].z; acc = acc + A[q].w; }
-        lds_f4 *sa = s4 + (g + 16 < GP ? g + 16 : 0) * NC;
+            for (int q = 0; q < 4; q++) R[(b + 3) & 3][q] = sn[q * NC];
+            asm volatile("" : "+v"(acc) :: "memory");
 #pragma unroll
-        for (int q = 0; q < 8; q++) A[q] = sa[q * NC];
-        asm volatile("" : "+v"(acc) :: "memory");
-#pragma unroll
-        for (int q = 0; q < 8; q++) { acc = acc + B[q].x; acc = acc + B[q].y; acc = acc + B[q].z; acc = acc + B[q].w; }
+            for (int q = 0; q < 4; q++) { acc = acc + R[b][q].x; acc = acc + R[b][q].y; acc = acc + R[b][q].z; acc = acc + R[b][q].w; }
+        }
     }
     return acc;
 }

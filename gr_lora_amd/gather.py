@@ -215,9 +215,9 @@ class PassPipeline:
         self.gat.submit(hk.drain_slots(SLOT_BYTES))           # step k's frames: one asynchronous all_gather
         return done, hk.timing()
 
-    def run(self, n_steps: int, keep=None):
+    def run(self, n_steps: int, keep=None, check=None):
         """n_steps passes; returns (sum of walker kernel ms, walker launches).  `keep` (a list) receives every step's
-        gathered (slots, counts)."""
+        gathered (slots, counts); `check` (a callable) is handed every step's gathered block as it is collected."""
         wk, ln = 0.0, 0
         if n_steps <= 0:
             return wk, ln
@@ -233,6 +233,8 @@ class PassPipeline:
             done, tm = self._finish(k)
             if keep is not None and done is not None:
                 keep.append(done)
+            if check is not None and done is not None:
+                check(done)
             wk += tm.walker_ms
             ln += tm.walker_launches
             if depth == 1 and k + 1 < n_steps:
@@ -240,6 +242,8 @@ class PassPipeline:
         last = self.gat.collect()                             # the final step's gather belongs to the run too
         if keep is not None and last is not None:
             keep.append(last)
+        if check is not None and last is not None:
+            check(last)
         return wk, ln
 
 
@@ -261,7 +265,9 @@ def split_stream_ranges(n_items: int, world: int, sps: int, max_packet_symbols: 
     those margins belong to the neighbour and are dropped (`owned`).  Unlike the segment stitcher inside one GPU
     (lora_stitch.hpp) nothing is probed across ranks: a rank's decoder starts fresh, so the loratap SNR byte (from the last
     four DETECT windows, decoder_impl.cc:360,:377-383) of its first frames and a header decoded with a stale d_phdr.cr (:655)
-    can differ from the serial decoder's; header positions and frame bytes behind the loratap header are the serial ones."""
+    can differ from the serial decoder's; header positions and frame bytes behind the loratap header are the serial ones WHEN THE CUT LIES
+    IN A GAP (pass `cuts`; bench.py --split does).  A cut inside a packet train has no such guarantee: the fresh decoder may trigger on the
+    neighbour's payload and acquire the first owned packet through another SYNC window."""
     if world <= 0 or n_items < 0:
         raise ValueError("bad split")
     cuts = sorted(int(c) for c in cuts)
