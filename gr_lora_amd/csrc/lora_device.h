@@ -29,8 +29,10 @@ enum AttemptStatus : uint32_t {
     kAttemptFrame = 1,       // packet decoded, frame[] valid
     kAttemptLostSync = 2,    // d_corr_fails > 4 -> back to DETECT (decoder_impl.cc:808-813)
     kAttemptOutOfData = 3,   // fewer than 2*sps items left mid-attempt (scheduler stops calling work())
-    kAttemptAtHeader = 4     // probe mode: stopped on entering DECODE_HEADER
+    kAttemptAtHeader = 4,    // probe mode: stopped on entering DECODE_HEADER
+    kAttemptAtSfd = 5        // tail probe with Job.tail_stop_sfd: stopped behind its first FIND_SFD step; sfd_pos / sfd_fails[n_sfd - 1] = the state it stopped in
 };
+constexpr int kMaxSfdRec = 12; // FIND_SFD steps of an attempt whose entry state is recorded (a preamble of 8 + sync word + SFD: at most 11)
 
 struct DevParams {
     uint32_t sf, nbins, nbins_hdr, sps, decim, log_nbins, delay_after_sync;
@@ -78,7 +80,9 @@ struct Job {
                            // next header, no new DETECT step at pos >= probe_limit) and reports that part as the "tail"; 0: off
     uint32_t start_at_header; // 1: `start` is the first header symbol of a packet acquired elsewhere (lora_hip_decode_at_headers_device, after
                            // the FFT-domain preamble detector): the job begins in DECODE_HEADER with an attempt open instead of in DETECT
-    uint32_t rsv0;
+    uint32_t tail_stop_sfd; // 1: the tail probe (probe_limit) stops behind its FIRST FIND_SFD step instead of at the header (kAttemptAtSfd): two
+                           // trajectories that start a FIND_SFD step at the same sample with the same d_corr_fails are one from there on
+                           // (:785-818 read nothing else), and the successor's attempt records hold every such state it went through
 };
 
 struct AttemptRec {
@@ -93,6 +97,11 @@ struct AttemptRec {
     uint32_t hdr_ambig;    // header bytes differ between the {3,4} and {1,2} FEC branches
     uint32_t frame_len;    // 3 + payload_length
     uint32_t n_symbols;    // header + payload symbols demodulated
+    // the state at the START of each FIND_SFD step of this attempt (walker3; other kernels report n_sfd = 0): what a tail probe that
+    // stopped early (kAttemptAtSfd) is matched against
+    int64_t  sfd_pos[kMaxSfdRec];
+    uint32_t n_sfd;
+    uint8_t  sfd_fails[kMaxSfdRec];
     uint8_t  frame[kMaxFrame + 4];
 };
 

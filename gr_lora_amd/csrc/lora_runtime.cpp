@@ -498,6 +498,21 @@ lora_hip_status run_jobs_end(lora_hip_decoder *h, RunOut &out)
             std::memcpy(&out.recs[(size_t)j * stride + a], src, n);
         }
     }
+    if (dbg_stats && h->P.use_fast) { // acquisitions (SYNC steps) per published frame; tail probes that stopped behind their first FIND_SFD step
+        double sync_rounds = 0; uint32_t frames = 0, tails = 0, early = 0;
+        for (uint32_t j = 0; j < nj; j++) {
+            const JobResult &r = out.res[j];
+            sync_rounds += r.rounds[1];
+            const uint32_t used = std::min(std::min(eager, max_att), r.n_attempts + (r.tail_valid ? r.tail_n_attempts : 0u));
+            for (uint32_t a = 0; a < used; a++) {
+                const AttemptRec &t = out.recs[(size_t)j * stride + a];
+                frames += (a < r.n_attempts && t.status == kAttemptFrame) ? 1u : 0u;
+                if (r.tail_valid && a + 1u == r.n_attempts + r.tail_n_attempts && r.tail_pad) { tails++; early += t.status == kAttemptAtSfd ? 1u : 0u; }
+            }
+        }
+        fprintf(stderr, "[lora_hip] acquisitions: %.0f SYNC rounds for %u frames of this launch (%.2f per frame); %u tail probes reached a packet, %u of them stopped behind their first FIND_SFD step\n",
+                sync_rounds, frames, frames ? sync_rounds / frames : 0.0, tails, early);
+    }
     h->eager_recs = std::min(std::max(max_att, 2u), 8u);
     bool more = false;
     if (max_att > eager) { // rare: some job made more attempts than were fetched with the results
@@ -657,6 +672,13 @@ struct DeviceEnv {
     }
     bool tracing() const { return (h->cfg.flags & LORA_HIP_FLAG_TRACE) != 0; }
     bool implicit() const { return h->P.implicit != 0; }
+    // walker3 (SF9-12 at decimation 8) records the FIND_SFD entry states of every attempt; its tail probes stop behind their first
+    // FIND_SFD step (Job.tail_stop_sfd) and are matched against those (LORA_HIP_NO_EARLY_PROBE=1: probes run to the header, as before)
+    bool early_probe() const
+    {
+        static const bool off = getenv("LORA_HIP_NO_EARLY_PROBE") != nullptr;
+        return !off && h->P.use_fast && h->P.decim == 8u && walker3_covers(h->P.sf);
+    }
     RunOut &run_out(int which) { return h->run_out[which & 1]; }
     bool quiet_edges(const std::vector<StreamDesc> &streams, std::vector<std::vector<int64_t>> &edges)
     {

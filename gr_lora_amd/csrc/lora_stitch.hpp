@@ -11,6 +11,7 @@
 //   bool quiet_edges(const std::vector<StreamDesc> &, std::vector<std::vector<int64_t>> &);   (gap starts per stream, false = none)
 //   void publish(const AttemptRec &, StreamDesc &);   void append_trace(const RunOut &, uint32_t job, uint32_t cap, int64_t base);
 //   void count_jobs(uint32_t), count_probes(uint32_t), count_slow_path(), note_plan(bool burst_aware, size_t n_segments);   double walker_ms();
+//   bool early_probe();   (the jobs record their FIND_SFD entry states and their tail probes may stop behind the first one: Job.tail_stop_sfd)
 #pragma once
 #include <algorithm>
 #include <chrono>
@@ -302,6 +303,7 @@ int decode_begin(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
         const bool has_next = k + 1 < segs.size() && segs[k + 1].stream == segs[k].stream;
         static const bool no_tail = getenv("LORA_HIP_NO_TAIL") != nullptr; // diagnostics: separate probe jobs, as the generic kernels need
         j.probe_limit = (segmenting && has_next && !no_tail) ? std::min<int64_t>((int64_t)sd.len, segs[k + 1].b1 + 16ll * sps) : 0;
+        j.tail_stop_sfd = (j.probe_limit && env.early_probe()) ? 1u : 0u;
         max_span = std::max<uint64_t>(max_span, (uint64_t)(segs[k].b1 - segs[k].b0));
     }
     ctx.rpj1 = recs_for(max_span, sps) + (segmenting ? ctx.rpj2 : 0u);
@@ -491,12 +493,17 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
                 continue;
             }
             const AttemptRec &L = view.recs[pr.n_attempts - 1u];
-            if (L.status != kAttemptAtHeader) { // ran out of data before reaching a header
+            if (L.status != kAttemptAtHeader && L.status != kAttemptAtSfd) { // ran out of data before reaching a header
                 cur.pos = L.start_pos;
                 sd.incomplete = true;
                 break;
             }
-            // which segment job entered a header at the same sample?
+            // which segment job entered a header at the same sample?  (A probe that stopped behind its first FIND_SFD step, Job.tail_stop_sfd:
+            // which job's header-bearing attempt STARTED a FIND_SFD step in the state the probe stopped in - position and d_corr_fails, all
+            // that decoder_impl.cc:785-818 read: from that step on the two trajectories are one, header entry included.)
+            const bool at_sfd = L.status == kAttemptAtSfd;
+            const int64_t probe_sfd_pos = (at_sfd && L.n_sfd) ? L.sfd_pos[L.n_sfd - 1u] : -1;
+            const uint32_t probe_sfd_fails = (at_sfd && L.n_sfd) ? L.sfd_fails[L.n_sfd - 1u] : 0u;
             int match = -1;
             size_t mk = 0;
             for (size_t k = f + 1; k <= pb.target && match < 0; k++) {
@@ -504,7 +511,13 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
                 const uint32_t nall = std::min(R1.res[k].n_attempts, R1.cap);
                 for (uint32_t a = 0; a < nall; a++) {
                     const AttemptRec &r = R1.rec(k, a);
-                    if (r.hdr_pos != L.hdr_pos || (r.status != kAttemptFrame && r.status != kAttemptOutOfData)) continue;
+                    if (r.hdr_pos < 0 || (r.status != kAttemptFrame && r.status != kAttemptOutOfData)) continue;
+                    if (!at_sfd) { if (r.hdr_pos != L.hdr_pos) continue; }
+                    else {
+                        bool shared = false;
+                        for (uint32_t q = 0; q < r.n_sfd && q < (uint32_t)kMaxSfdRec; q++) shared = shared || (r.sfd_pos[q] == probe_sfd_pos && r.sfd_fails[q] == probe_sfd_fails);
+                        if (!shared) continue;
+                    }
                     { // the header FEC branch follows the carried-in d_phdr.cr (:655): the job's speculative decode only stands
                       // if its branch is the true one, or the two Hamming branches agree on this header - and class 0
                       // (no switch case upstream: the header reads as zeros) never agrees with either
@@ -517,8 +530,8 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
             }
             if (match < 0) {
                 if (dbg) {
-                    fprintf(stderr, "[lora_hip] probe for segment %zu [%lld, %lld): start %lld cr %u -> trig %lld hdr %lld\n", pb.target, (long long)segs[pb.target].b0, (long long)segs[pb.target].b1,
-                            (long long)pb.start.pos, pb.start.cr, (long long)L.trig_pos, (long long)L.hdr_pos);
+                    fprintf(stderr, "[lora_hip] probe for segment %zu [%lld, %lld): start %lld cr %u -> trig %lld hdr %lld (stopped %s, FIND_SFD state %lld / %u)\n", pb.target, (long long)segs[pb.target].b0, (long long)segs[pb.target].b1,
+                            (long long)pb.start.pos, pb.start.cr, (long long)L.trig_pos, (long long)L.hdr_pos, at_sfd ? "behind its first FIND_SFD step" : "at the header", (long long)probe_sfd_pos, probe_sfd_fails);
                     for (size_t k = pb.target ? pb.target - 1 : 0; k <= pb.target; k++)
                         for (uint32_t a = 0; a < std::min(R1.res[k].n_attempts, R1.cap); a++) {
                             const AttemptRec &r = R1.rec(k, a);
@@ -527,7 +540,7 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
                         }
                 }
                 cur = Cursor{L.start_pos, L.cr_prev};
-                s = serial_to(b1, "no segment job entered the same header");
+                s = serial_to(b1, at_sfd ? "no segment job passed through the probe's FIND_SFD state" : "no segment job entered the same header");
                 if (s != 0) return s;
                 continue;
             }

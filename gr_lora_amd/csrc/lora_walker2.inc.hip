@@ -64,6 +64,7 @@ struct alignas(16) W2State {
     uint32_t n_words, n_cw, n_sym;
     uint32_t n_att, npush, n_steps, frame_ok;
     uint32_t att_cr_prev, att_ambig;
+    uint32_t n_sfd;       // FIND_SFD steps of the open attempt whose entry state is in its record (walker3)
     float    energy_threshold;
     float    push_tail[4];
     uint8_t  phdr[4];
@@ -164,7 +165,9 @@ __device__ __forceinline__ void w2_end_step(W2State &S, const Job &job, const La
             r.npush = S.npush;
             for (int i = 0; i < 4; i++) r.push_tail[i] = S.push_tail[i];
             r.cr_prev = S.att_cr_prev; r.hdr_ambig = S.att_ambig; r.n_symbols = S.n_sym;
+            r.n_sfd = S.n_sfd < (uint32_t)kMaxSfdRec ? S.n_sfd : (uint32_t)kMaxSfdRec;
         }
+        S.n_sfd = 0;
         S.n_att++;
         S.in_attempt = 0;
         S.frame_ok = 0;
@@ -1025,7 +1028,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             r.start_pos = S.att_start; r.trig_pos = S.att_trig; r.hdr_pos = S.att_hdr; r.end_pos = S.pos;
             r.npush = S.npush;
             for (int i = 0; i < 4; i++) r.push_tail[i] = S.push_tail[i];
-            r.cr_prev = S.att_cr_prev; r.hdr_ambig = S.att_ambig; r.n_symbols = S.n_sym; r.frame_len = 0;
+            r.cr_prev = S.att_cr_prev; r.hdr_ambig = S.att_ambig; r.n_symbols = S.n_sym; r.frame_len = 0; r.n_sfd = 0;
         }
         JobResult &jr = C.results[jid];
         const int64_t e_pos = in_attempt ? S.att_start : S.pos;

@@ -1378,6 +1378,7 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
         }
     };
 
+    bool stop_sfd = false; // phase 1 with Job.tail_stop_sfd: the probe stops behind its first FIND_SFD step
     for (int phase = 0; phase < 2; phase++) {
     if (t0) {
         S = W2State{};
@@ -1453,7 +1454,7 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                         St.corr_fails = 0u;
                         St.state = kSync;
                         St.in_attempt = 1;
-                        St.att_trig = St.pos; St.att_hdr = -1; St.att_cr_prev = St.cr; St.att_ambig = 0; St.n_sym = 0;
+                        St.att_trig = St.pos; St.att_hdr = -1; St.att_cr_prev = St.cr; St.att_ambig = 0; St.n_sym = 0; St.n_sfd = 0;
                     } else {
                         consumed = (int32_t)sps;
                     }
@@ -1490,6 +1491,15 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                 W2State St = S;
                 for (int g = 0; g < NQ; g++) {
                     if (g > 0 && (St.state != kFindSfd || !w2_pre_step(St, job, rec_cap, sps))) break;
+                    // a tail probe with Job.tail_stop_sfd has seen enough once it stands at the start of its SECOND FIND_SFD step: the first
+                    // one's fine_sync(-1, 4 D) (:801-803) has pulled it onto the chirp boundary its successor's own attempt passes through,
+                    // and (position, d_corr_fails) is all that :785-818 read - the stitch matches it against that attempt's record
+                    if (stop_sfd && St.n_sfd >= 1u) { St.stop_reason = 4; St.done = 1; break; }
+                    if (St.n_att < rec_cap && St.n_sfd < (uint32_t)kMaxSfdRec) { // the state this step starts in, for such a match
+                        recs[St.n_att].sfd_pos[St.n_sfd] = St.pos;
+                        recs[St.n_att].sfd_fails[St.n_sfd] = (uint8_t)St.corr_fails;
+                    }
+                    St.n_sfd++;
                     float c = fo.c[0];
                     int32_t fs = fo.fine[0];
 #pragma unroll
@@ -1671,11 +1681,15 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
         const bool in_attempt = S.in_attempt != 0;
         if (in_attempt && S.n_att < rec_cap) {
             AttemptRec &r = recs[S.n_att];
-            r.status = (S.stop_reason == 3) ? kAttemptAtHeader : kAttemptOutOfData;
+            r.status = (S.stop_reason == 3) ? kAttemptAtHeader : (S.stop_reason == 4) ? kAttemptAtSfd : kAttemptOutOfData;
             r.start_pos = S.att_start; r.trig_pos = S.att_trig; r.hdr_pos = S.att_hdr; r.end_pos = S.pos;
             r.npush = S.npush;
             for (int i = 0; i < 4; i++) r.push_tail[i] = S.push_tail[i];
             r.cr_prev = S.att_cr_prev; r.hdr_ambig = S.att_ambig; r.n_symbols = S.n_sym; r.frame_len = 0;
+            uint32_t ns = S.n_sfd < (uint32_t)kMaxSfdRec ? S.n_sfd : (uint32_t)kMaxSfdRec;
+            if (S.stop_reason == 4 && ns < (uint32_t)kMaxSfdRec) { r.sfd_pos[ns] = S.pos; r.sfd_fails[ns] = (uint8_t)S.corr_fails; ns++; } // the state the probe stopped in
+            r.n_sfd = ns;
+            if (S.stop_reason == 4) S.stop_reason = 3; // (reported like any other probe stop)
         }
         JobResult &jr = C.results[jid];
         const int64_t e_pos = in_attempt ? S.att_start : S.pos;
@@ -1719,6 +1733,7 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
         job.start = (int64_t)(((uint64_t)hi << 32) | lo);
         job.cr_prev = __builtin_amdgcn_readfirstlane(ws.ph_cr);
         job.scan_limit = job.probe_limit; job.stop_at_header = 1; job.max_attempts = 0;
+        stop_sfd = job.tail_stop_sfd != 0u;
         recs += natt;
         rec_cap = C.recs_per_job - natt;
     }

@@ -113,14 +113,17 @@ void     lora_oracle_demod_at(lora_oracle_t *o, const float *iq, const int64_t *
 
 /* ---- job-level entry, used by tests/host_sim to exercise the product's speculation scheduler on the CPU ----
  * Runs the state machine like one walker job: start in DETECT at `start` with d_phdr.cr = cr_prev, begin no new
- * DETECT step at pos >= scan_limit, stop after max_attempts (0 = no limit) or, with stop_at_header, on entering
- * DECODE_HEADER.  Attempts are reported in the same terms as the device's AttemptRec / JobResult.                */
+ * DETECT step at pos >= scan_limit, stop after max_attempts (0 = no limit) or, with stop_at_header & 1, on entering
+ * DECODE_HEADER; stop_at_header & 2: also at the start of an attempt's second FIND_SFD step (Job.tail_stop_sfd).  Attempts are reported in the same terms as the device's AttemptRec / JobResult.                */
 typedef struct {
     int64_t  start_pos, trig_pos, hdr_pos, end_pos;
-    uint32_t status;        /* 1 frame, 2 lost sync, 3 out of data, 4 stopped at header */
+    uint32_t status;        /* 1 frame, 2 lost sync, 3 out of data, 4 stopped at header, 5 stopped behind the first FIND_SFD step */
     uint32_t npush;
     float    push_tail[4];
     uint32_t cr_prev, hdr_ambig, frame_len, n_symbols;
+    int64_t  sfd_pos[12];   /* the state at the start of every FIND_SFD step of the attempt (position, d_corr_fails): what a tail probe   */
+    uint32_t n_sfd;         /* that stopped behind its first FIND_SFD step (status 5; stop_at_header bit 1) is matched against             */
+    uint8_t  sfd_fails[12];
     uint8_t  frame[264];
 } oracle_attempt_t;
 typedef struct {

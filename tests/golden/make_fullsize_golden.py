@@ -29,7 +29,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # (tag, sf, cr, packets, payload, streams, seed) - the same calls tests/test_gpu_fullsize.py makes
 CASES = [("config2-1stream", 7, 4, 1024, 32, 1, 2), ("config2-8streams", 7, 4, 1024, 32, 8, 2)]
 for _sf in (7, 8, 9, 10, 11, 12):
-    for _cr in (1, 4):
+    for _cr in (1, 2, 3, 4):   # BASELINE config 3: CR 4/5 - 4/8
         CASES.append(("config3-sf%d-cr%d" % (_sf, _cr), _sf, _cr, 256, 32, 8, 100 * _sf + _cr))
 
 

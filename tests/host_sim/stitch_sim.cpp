@@ -18,12 +18,14 @@ struct SimEnv {
     size_t n_items;
     uint32_t sps_, ctor_cr_, seg_symbols, slots;
     std::vector<SimFrame> frames;
-    uint32_t n_jobs = 0, n_probes = 0, n_slow = 0, n_tails = 0;
+    uint32_t n_jobs = 0, n_probes = 0, n_slow = 0, n_tails = 0, n_early = 0;
     RunOut outs[2];
     RunOut &run_out(int which) { return outs[which & 1]; }
     bool burst_plan = false;  // offer the scheduler the gaps between bursts (the device's envelope pre-pass)
     uint32_t planned = 0;
     bool tail_probes = true; // emulate Job.probe_limit (walker2); false: the generic kernels' behaviour (explicit probe jobs only)
+    bool early = false;      // emulate walker3: FIND_SFD entry states in the attempt records, tail probes stop behind their first FIND_SFD step
+    bool early_probe() const { return early; }
 
     uint32_t sps() const { return sps_; }
     uint32_t ctor_cr() const { return ctor_cr_; }
@@ -72,6 +74,7 @@ struct SimEnv {
                 d.start_pos = s.start_pos; d.trig_pos = s.trig_pos; d.hdr_pos = s.hdr_pos; d.end_pos = s.end_pos;
                 d.status = s.status; d.npush = s.npush; std::memcpy(d.push_tail, s.push_tail, sizeof d.push_tail);
                 d.cr_prev = s.cr_prev; d.hdr_ambig = s.hdr_ambig; d.frame_len = s.frame_len; d.n_symbols = s.n_symbols;
+                d.n_sfd = early ? s.n_sfd : 0u; std::memcpy(d.sfd_pos, s.sfd_pos, sizeof d.sfd_pos); std::memcpy(d.sfd_fails, s.sfd_fails, sizeof d.sfd_fails);
                 std::memcpy(d.frame, s.frame, s.frame_len);
             }
         };
@@ -89,8 +92,9 @@ struct SimEnv {
             if (tail_probes && jb.probe_limit > jb.scan_limit && r.stop_reason == 0u && !r.pad) {
                 oracle_job_result_t t{};
                 const uint32_t first = r.n_attempts, cap = rpj > first ? rpj - first : 0u;
-                lora_oracle_run_job(o, iq + 2 * jb.stream_off, (size_t)jb.stream_len, r.final_pos, jb.probe_limit, r.final_cr, 0, 1, cap,
+                lora_oracle_run_job(o, iq + 2 * jb.stream_off, (size_t)jb.stream_len, r.final_pos, jb.probe_limit, r.final_cr, 0, jb.tail_stop_sfd ? 3 : 1, cap,
                                     tmp.data(), &t);
+                n_early += (t.pad && t.n_attempts && t.n_attempts <= cap && tmp[t.n_attempts - 1].status == 5u) ? 1u : 0u;
                 jr.tail_valid = 1; jr.tail_first_rec = first; jr.tail_final_pos = t.final_pos; jr.tail_n_attempts = t.n_attempts;
                 jr.tail_final_cr = t.final_cr; jr.tail_npush = t.npush; std::memcpy(jr.tail_push_tail, t.push_tail, sizeof jr.tail_push_tail);
                 jr.tail_stop_reason = t.stop_reason; jr.tail_pad = t.pad;
@@ -126,6 +130,7 @@ extern "C" int stitch_sim_decode(const float *iq, size_t n_items, int sf, int ct
     SimEnv env{o, iq, n_items, lora_oracle_sps(o), (uint32_t)ctor_cr, segment_symbols, resident_slots};
     env.tail_probes = (tail_probes & 1) != 0;
     env.burst_plan = (tail_probes & 2) != 0;
+    env.early = (tail_probes & 4) != 0;
     std::vector<StreamDesc> sds(1);
     sds[0].off = 0; sds[0].len = n_items; sds[0].id = 0; sds[0].cr_in = (uint32_t)ctor_cr; sds[0].abs_base = 0;
     const int rc = decode_streams(env, sds);
@@ -138,7 +143,7 @@ extern "C" int stitch_sim_decode(const float *iq, size_t n_items, int sf, int ct
         std::memcpy(out + used, f.blob.data(), f.blob.size());
         lens[n] = (int)f.blob.size(); hdr_pos[n] = f.hdr_pos; used += f.blob.size(); n++;
     }
-    stats[0] = env.n_jobs; stats[1] = env.n_probes; stats[2] = env.n_slow; stats[3] = sds[0].incomplete ? 1u : 0u; stats[4] = env.n_tails; stats[5] = env.planned;
+    stats[0] = env.n_jobs; stats[1] = env.n_probes; stats[2] = env.n_slow; stats[3] = sds[0].incomplete ? 1u : 0u; stats[4] = env.n_tails; stats[5] = env.planned; stats[6] = env.n_early;
     return n;
 }
 

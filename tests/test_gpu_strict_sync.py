@@ -116,3 +116,29 @@ def test_generic_kernel_sync_decision(oracle_mod, sf, decim_bw):
         assert [i.header_pos for _, i in got] == o.frame_positions(), (sf, demod)
         assert_trace_parity(tr, o.trace(), True, (sf, demod))
         assert len(got) == 3
+
+
+@pytest.mark.parametrize("sf", [9, 10, 11])
+def test_early_stopping_tail_probes_on_the_device(oracle_mod, sf):
+    """walker3's tail probes stop behind their first FIND_SFD step (Job.tail_stop_sfd) and are matched against the FIND_SFD entry
+    states their successor recorded (tests/test_stitch_sim.py holds the protocol to the serial decoder on the CPU): on regular
+    traffic cut into segments every packet merges through such a probe - no explicit probe launch, no serial re-run - and the
+    frames and header positions are the serial oracle's"""
+    from gr_lora_amd import capi
+    cfg = synth.TxConfig(sf=sf, cr=4, reduced_rate=(sf > 10))
+    rng = np.random.default_rng(40 + sf)
+    n = {9: 14, 10: 10, 11: 6}[sf]
+    payloads = [bytes(rng.integers(0, 256, 12, dtype=np.uint8)) for _ in range(n)]
+    st = synth.build_stream(payloads, cfg, rng=rng, noise_sigma=synth.awgn_sigma_for_snr(45.0, cfg))
+    kw = dict(sf=sf, cr=4, reduced_rate=(sf > 10))
+    o = oracle_mod.Oracle(demod=2, **kw)
+    o.run(st.iq)
+    h = capi.Handle(demod=2, segment_symbols=70, **kw)      # (a packet is ~60 symbols + a gap of 2-6: about one packet per segment)
+    dev = _dev(st.iq)
+    h.decode_device(dev.data_ptr(), st.iq.size, [0], [st.iq.size], 0)
+    got = h.drain()
+    tm = h.timing()
+    h.close()
+    assert [g.hex() for g, _ in got] == [f.hex() for f in o.frames()] and len(got) == n
+    assert [i.header_pos for _, i in got] == o.frame_positions()
+    assert tm.jobs >= n // 2 and tm.probes == 0 and tm.slow_path_relaunches <= 1, (tm.jobs, tm.probes, tm.slow_path_relaunches)

@@ -28,20 +28,20 @@ def sim(oracle_mod):
     L.stitch_sim_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int,
                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
 
-    def run(iq, sf, ctor_cr=4, demod=2, reduced=False, seg=0, slots=512, tails=True, plan=False):
+    def run(iq, sf, ctor_cr=4, demod=2, reduced=False, seg=0, slots=512, tails=True, plan=False, early=False):
         a = np.ascontiguousarray(iq, dtype=np.complex64)
         out = np.zeros(1 << 20, dtype=np.uint8)
         lens = np.zeros(4096, dtype=np.int32)
         hp = np.zeros(4096, dtype=np.int64)
         st = np.zeros(8, dtype=np.uint32)
-        n = L.stitch_sim_decode(a.ctypes.data, a.size, sf, ctor_cr, 1, int(reduced), demod, seg, slots, int(tails) | (2 if plan else 0), out.ctypes.data, out.size,
+        n = L.stitch_sim_decode(a.ctypes.data, a.size, sf, ctor_cr, 1, int(reduced), demod, seg, slots, int(tails) | (2 if plan else 0) | (4 if early else 0), out.ctypes.data, out.size,
                                 lens.ctypes.data, hp.ctypes.data, 4096, st.ctypes.data)
         assert n >= 0, n
         frames, off = [], 0
         for i in range(n):
             frames.append(bytes(out[off:off + lens[i]]))
             off += int(lens[i])
-        return frames, hp[:n].tolist(), dict(jobs=int(st[0]), probes=int(st[1]), slow=int(st[2]), incomplete=int(st[3]), tails=int(st[4]), planned=int(st[5]))
+        return frames, hp[:n].tolist(), dict(jobs=int(st[0]), probes=int(st[1]), slow=int(st[2]), incomplete=int(st[3]), tails=int(st[4]), planned=int(st[5]), early=int(st[6]))
     return run
 
 
@@ -104,6 +104,9 @@ def test_fast_path_dominates_on_regular_traffic(sim, oracle_mod):
     got, gpos, stats = sim(st.iq, 7, seg=64)
     assert got == want and gpos == wpos
     assert stats["slow"] <= 2 and stats["jobs"] > 60
+    got, gpos, stats = sim(st.iq, 7, seg=0, slots=30, plan=True, early=True)      # burst-aware cuts + early-stopping tail probes (walker3's mode)
+    assert got == want and gpos == wpos
+    assert stats["slow"] == 0 and stats["early"] > 0 and stats["probes"] == 0, stats
 
 
 @pytest.mark.parametrize("sf,cr,noise_db", [(8, 1, -32), (7, 2, -30), (9, 3, None)])
@@ -208,3 +211,39 @@ def test_header_with_cr_zero_ahead_of_a_cut(sim, oracle_mod, seg):
         for tails in (True, False):
             got, gpos, stats = sim(iq, 7, ctor_cr=ctor_cr, seg=seg, slots=64, tails=tails)
             assert got == want and gpos == wpos, (seg, ctor_cr, tails)
+
+
+@pytest.mark.parametrize("seg", [16, 23, 40, 64, 150, 0])
+def test_early_stopping_tail_probes_equal_serial(sim, oracle_mod, seg):
+    """Job.tail_stop_sfd (walker3): tail probes stop behind their first FIND_SFD step and are matched against the FIND_SFD entry
+    states their successor recorded - the same ragged traffic as test_segmented_equals_serial (back-to-back packets, gaps of 0, 1,
+    half a symbol), noisy and clean: segmented == serial, and the probes really do stop early."""
+    cfg = synth.TxConfig(sf=7, cr=4)
+    rng = np.random.default_rng(900 + seg)
+    payloads = [bytes(rng.integers(0, 256, int(rng.integers(1, 48)), dtype=np.uint8)) for _ in range(30)]
+    gaps = [int(g) for g in rng.integers(0, 7 * cfg.sps, len(payloads))]
+    gaps[5] = 0; gaps[6] = 1; gaps[7] = cfg.sps // 2; gaps[8] = 2 * cfg.sps + 3
+    for sigma in (0.0, 10 ** (-30 / 20.0)):
+        st = synth.build_stream(payloads, cfg, gaps=gaps, rng=np.random.default_rng(seg), noise_sigma=sigma)
+        want, wpos = _serial(oracle_mod, st.iq, 7)
+        got, gpos, stats = sim(st.iq, 7, seg=seg, slots=40, early=True)
+        assert got == want and gpos == wpos, (seg, sigma)
+        assert stats["early"] > 0 and stats["early"] <= stats["tails"], stats
+        ref_stats = sim(st.iq, 7, seg=seg, slots=40)[2]
+        # (a probe that stopped early finds no partner when its successor triggered more than a symbol later - cuts in mid-preamble, which
+        # this adversarial grid produces and burst-aware cuts do not; the price is a serial fall-back, never a wrong frame)
+        assert stats["slow"] <= ref_stats["slow"] + 4, (stats, ref_stats)
+
+
+@pytest.mark.parametrize("sf,cr,noise_db", [(8, 1, -32), (7, 2, -30), (9, 3, None)])
+def test_early_stopping_probes_with_noise_and_stale_cr(sim, oracle_mod, sf, cr, noise_db):
+    cfg = synth.TxConfig(sf=sf, cr=cr)
+    rng = np.random.default_rng(77 + sf)
+    payloads = [bytes(rng.integers(0, 256, int(rng.integers(4, 30)), dtype=np.uint8)) for _ in range(12)]
+    st = synth.build_stream(payloads, cfg, rng=rng, noise_sigma=(10 ** (noise_db / 20.0) if noise_db else 0.0))
+    want, wpos = _serial(oracle_mod, st.iq, sf)
+    for seg in (20, 57):
+        got, gpos, stats = sim(st.iq, sf, seg=seg, early=True)
+        assert got == want and gpos == wpos
+    got, gpos, stats = sim(st.iq, sf, seg=0, slots=8, plan=True, early=True)
+    assert got == want and gpos == wpos
