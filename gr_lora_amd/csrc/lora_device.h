@@ -173,5 +173,7 @@ uint32_t wave_tables_floats(uint32_t sf);                                  // 0 
 void build_wave_tables(uint32_t sf, const float2 *down, float *out);
 uint32_t walker_lds_bytes(const DevParams &p);
 uint32_t walker_resident_slots(const DevParams &p);
+uint32_t walker_resident_slots_full(const DevParams &p);                  // second, smaller slot count where the kernel exists as half- and full-size workgroups (0: none)
+const char *walker_kernel_name_for(const DevParams &p, uint32_t n_jobs);   // ... and the variant a launch of n_jobs jobs runs
 
 } // namespace lora_hip

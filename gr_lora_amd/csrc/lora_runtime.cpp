@@ -182,7 +182,10 @@ struct lora_hip_decoder {
     uint32_t stream_cr = 0;
     PwrState stream_pwr;
     size_t batch_items = 0;
+    const char *last_kernel = nullptr; // name of the walker kernel the last pass's main launch ran
+    uint32_t last_kernel_jobs = 0;     // ... and its job count (reset when a pass begins)
     uint32_t resident_slots = 0;
+    uint32_t resident_slots_alt = ~0u; // slots of the full-size kernel where a half-size variant exists (walker3 SF9 / SF10), else 0
     uint32_t eager_recs = 4;
     uint32_t last_plan_burst = 0, last_plan_segments = 0;
 };
@@ -419,6 +422,7 @@ lora_hip_status run_jobs_begin(lora_hip_decoder *h, const float2 *d_iq, const st
     }
     c.balance = no_balance ? nullptr : h->d_balance.p;
     HIP_TRY(h, hipEventRecord(h->ev0, st));
+    if (nj >= h->last_kernel_jobs) { h->last_kernel = walker_kernel_name_for(h->P, nj); h->last_kernel_jobs = nj; } // (the pass's main launch: probe and fix-up launches are smaller)
     if (launch_walker(h->P, c, st) != 0) return fail(h, LORA_HIP_ERR_HIP, "walker launch failed: %s", hipGetErrorString(hipGetLastError()));
     HIP_TRY(h, hipEventRecord(h->ev1, st));
     if (!direct) {
@@ -670,6 +674,11 @@ struct DeviceEnv {
         if (h->resident_slots == 0) h->resident_slots = std::max<uint32_t>(walker_resident_slots(h->P), 64u);
         return h->resident_slots;
     }
+    uint32_t resident_slots_alt() const
+    {
+        if (h->resident_slots_alt == ~0u) h->resident_slots_alt = walker_resident_slots_full(h->P);
+        return h->resident_slots_alt;
+    }
     bool tracing() const { return (h->cfg.flags & LORA_HIP_FLAG_TRACE) != 0; }
     bool implicit() const { return h->P.implicit != 0; }
     // walker3 (SF9-12 at decimation 8) records the FIND_SFD entry states of every attempt; its tail probes stop behind their first
@@ -695,7 +704,7 @@ struct DeviceEnv {
     int run_jobs_end(RunOut &out) { return ::run_jobs_end(h, out) == LORA_HIP_OK ? 0 : -1; }
     void publish(const AttemptRec &r, StreamDesc &sd) { ::publish(h, r, sd); }
     void append_trace(const RunOut &out, uint32_t job, uint32_t cap, int64_t base) { ::append_trace(h, out, job, cap, base); }
-    void count_jobs(uint32_t n) { h->timing.jobs += n; }
+    void count_jobs(uint32_t n) { h->timing.jobs += n; h->last_kernel_jobs = 0; } // (called once per pass, ahead of its main launch)
     void count_probes(uint32_t n) { h->timing.probes += n; }
     void count_slow_path() { h->timing.slow_path_relaunches++; }
     void note_plan(bool burst_aware, size_t n_segs)
@@ -1769,7 +1778,8 @@ lora_hip_status lora_hip_last_plan(const lora_hip_decoder_t *h, uint32_t *burst_
     return LORA_HIP_OK;
 }
 
-const char *lora_hip_walker_kernel_name(const lora_hip_decoder_t *h) { return h ? walker_kernel_name(h->P) : ""; }
+// (the variant the last pass launched where the kernel exists in two workgroup sizes - walker3 SF9 / SF10: *_half with more jobs than CUs)
+const char *lora_hip_walker_kernel_name(const lora_hip_decoder_t *h) { return h ? (h->last_kernel ? h->last_kernel : walker_kernel_name(h->P)) : ""; }
 
 lora_hip_status lora_hip_last_timing(const lora_hip_decoder_t *h, lora_hip_timing_t *t)
 {

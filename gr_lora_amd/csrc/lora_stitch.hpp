@@ -11,6 +11,7 @@
 //   bool quiet_edges(const std::vector<StreamDesc> &, std::vector<std::vector<int64_t>> &);   (gap starts per stream, false = none)
 //   void publish(const AttemptRec &, StreamDesc &);   void append_trace(const RunOut &, uint32_t job, uint32_t cap, int64_t base);
 //   void count_jobs(uint32_t), count_probes(uint32_t), count_slow_path(), note_plan(bool burst_aware, size_t n_segments);   double walker_ms();
+//   uint32_t resident_slots_alt();   (a second, smaller slot count when the kernel exists in two workgroup sizes; 0: none)
 //   bool early_probe();   (the jobs record their FIND_SFD entry states and their tail probes may stop behind the first one: Job.tail_stop_sfd)
 #pragma once
 #include <algorithm>
@@ -264,9 +265,26 @@ int decode_begin(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
     static const bool no_plan = getenv("LORA_HIP_NO_BURST_PLAN") != nullptr;
     if (segmenting && env.segment_symbols() == 0 && !no_plan && total > 2ull * seg) {
         std::vector<std::vector<int64_t>> edges;
-        if (env.quiet_edges(streams, edges)) planned = plan_burst_segments(streams, edges, sps, slots, seg, cuts);
+        if (env.quiet_edges(streams, edges)) {
+            planned = plan_burst_segments(streams, edges, sps, slots, seg, cuts);
+            // fewer bursts than slots, but the kernel also exists with half as many, larger workgroups (walker3 SF9 / SF10 as one or two per CU):
+            // one wave of those
+            const uint32_t alt = env.resident_slots_alt();
+            if (!planned && alt && alt < slots) {
+                const uint64_t seg_alt = std::max<uint64_t>(64ull * sps, (total + alt - alt / 16u - 1) / (alt - alt / 16u));
+                planned = plan_burst_segments(streams, edges, sps, alt, seg_alt, cuts);
+            }
+        }
     }
 
+    // the fixed grid (no burst-aware plan) is sized for the LARGER workgroups where the kernel exists in two sizes: its jobs start inside packets, and
+    // each pays a scan to the next preamble, an acquisition and a tail probe - twice as many jobs cost more than two workgroups per CU give back
+    // (BASELINE config 4, 32 s per pass: 11.7 % of HBM peak with 244 jobs against 10.8 % with 484)
+    if (!planned && segmenting && env.segment_symbols() == 0 && env.resident_slots_alt() && env.resident_slots_alt() < slots) {
+        const uint32_t alt = env.resident_slots_alt();
+        const uint64_t wj = std::max<uint64_t>(alt - alt / 16u, (uint64_t)streams.size());
+        seg = std::max<uint64_t>(64ull * sps, (total + wj - 1) / wj);
+    }
     std::vector<Seg> &segs = ctx.segs;
     std::vector<size_t> &first_seg = ctx.first_seg;
     first_seg.assign(streams.size() + 1, 0);
@@ -396,6 +414,37 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
         if (chain && pending) add_probe(e - 1, (int64_t)sd.len); // header-less tail still has to be walked
     }
     first_probe[streams.size()] = probes.size();
+    // Tail probes that stopped behind their first FIND_SFD step (Job.tail_stop_sfd) in a state NO header-bearing attempt of their successors
+    // passed through - the successor triggered two or more chirps later, as happens when a cut falls inside a packet train: they are run to the
+    // header after all, as explicit probe jobs in the one launch below (a mismatch must cost a probe, not a serial walk of the segment).
+    for (size_t q = 0; q < probes.size(); q++) {
+        if (probes[q].job >= 0) continue;
+        const size_t tj = (size_t)probes[q].tail_of;
+        const JobResult &jr = R1.res[tj];
+        if (!jr.tail_pad || jr.tail_n_attempts == 0u) continue;
+        const uint32_t li = std::min(jr.tail_first_rec, R1.cap) + jr.tail_n_attempts - 1u;
+        if (li >= R1.cap) continue;
+        const AttemptRec &L = R1.rec(tj, li);
+        if (L.status != kAttemptAtSfd || L.n_sfd == 0u) continue;
+        const int64_t ppos = L.sfd_pos[L.n_sfd - 1u];
+        const uint32_t pfails = L.sfd_fails[L.n_sfd - 1u];
+        bool shared = false;
+        for (size_t k = first_seg[probes[q].stream] + 1; k <= probes[q].target && !shared; k++) {
+            const uint32_t nall = std::min(R1.res[k].n_attempts, R1.cap);
+            for (uint32_t a = 0; a < nall && !shared; a++) {
+                const AttemptRec &r = R1.rec(k, a);
+                if (r.hdr_pos < 0 || (r.status != kAttemptFrame && r.status != kAttemptOutOfData)) continue;
+                for (uint32_t z = 0; z < r.n_sfd && z < (uint32_t)kMaxSfdRec; z++) shared = shared || (r.sfd_pos[z] == ppos && r.sfd_fails[z] == pfails);
+            }
+        }
+        if (shared) continue;
+        const StreamDesc &sd = streams[probes[q].stream];
+        Job j{};
+        j.stream_off = sd.off; j.stream_len = sd.len; j.start = probes[q].start.pos; j.scan_limit = jobs[tj].probe_limit;
+        j.stream_id = sd.id; j.cr_prev = probes[q].start.cr; j.max_attempts = 0; j.stop_at_header = 1;
+        probes[q].job = (int)pjobs.size(); probes[q].tail_of = -1;
+        pjobs.push_back(j);
+    }
     RunOut &R2 = env.run_out(1);
     R2.res.clear(); R2.recs.clear();
     if (!pjobs.empty()) {

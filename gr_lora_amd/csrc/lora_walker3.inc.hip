@@ -84,11 +84,15 @@
 #define LORA_W3_STAGGER 0       // start-up stagger between workgroups, shader clocks per step (measured: no gain)
 #endif
 
-template <int SF> struct W3Geom {
+template <int SF, int HV = 0> struct W3Geom {
     static constexpr int N = 1 << SF, SPS = 8 * N;
     static constexpr bool T512 = (LORA_W3_T512_MASK >> (SF - 9)) & 1;
-    static constexpr int T = T512 ? 512 : 1024;         // threads per workgroup (16 or 8 wavefronts, one workgroup per CU)
-    static constexpr int NG = SF == 9 ? 4 : SF == 10 ? 2 : 1; // groups: windows evaluated per round
+    // HV = 1 (SF9 / SF10 only): HALF the workgroup - half the groups, half the threads, the same work per thread and the same geometry per group - so
+    // that TWO workgroups share a CU (79 / 78 KB of LDS each) and one's rounds fill the other's waits (+12 % at SF9, +4.5 % at SF10 when a
+    // launch holds at least two jobs per CU; with one job per CU it would walk its packet at half the width - the launcher picks by job count)
+    static_assert(HV == 0 || (HV == 1 && SF <= 10), "half-size workgroups exist for SF9 and SF10");
+    static constexpr int T = (T512 ? 512 : 1024) >> HV; // threads per workgroup (16 or 8 wavefronts, one workgroup per CU; HV: 4, two per CU)
+    static constexpr int NG = (SF == 9 ? 4 : SF == 10 ? 2 : 1) >> HV; // groups: windows evaluated per round
     static constexpr int TG = T / NG;                   // threads of one group = one symbol window
     static constexpr int VT = SF >= 11 ? 1024 : N / 2;  // "virtual threads" of a group: the units of passes 2 and 3 (what TG is at T = 1024)
     static constexpr int U = VT / TG;                   // units per thread in passes 2 and 3 (1; T512: 2)
@@ -98,7 +102,7 @@ template <int SF> struct W3Geom {
     static constexpr int AR = 16 / ROUNDS;              // rows resident in LDS per round
     static constexpr int M = N / 16, M2 = M / 16, LOGM2 = ilog2(M2);
     static constexpr int SA = 8 * M + 8;                // entries per row
-    static constexpr int NTW = N > 2048 ? N / 2 : N;    // W_N^t entries kept in LDS (SF12: half, the rest by sign)
+    static constexpr int NTW = (N > 2048 || (HV && SF == 10)) ? N / 2 : N; // W_N^t entries kept in LDS (SF12, and SF10's half-size workgroup - 82 080 -> 77 984 B -: half, the rest by sign)
     static constexpr int CH = SPS / 16;                 // samples between a thread's consecutive loads
     static constexpr int NWL = VT / (8 * AR), NB = 16 / NWL; // pass 3: butterflies per unit
     static constexpr int LEN = SPS / T;                 // SYNC: shifts per thread (all groups together)
@@ -125,32 +129,32 @@ struct alignas(16) W3Shared {
     Shared   sh;                   // integer chain (words / codewords / decoded bytes)
 };
 
-template <int SF> struct W3Lds {
+template <int SF, int HV = 0> struct W3Lds {
     v2f      *data;  // [NG][AR][SA]
     v2f      *tw;    // [NTW]  W_N^t
     W3Shared *ws;
 };
 
-template <int SF>
-__device__ __forceinline__ W3Lds<SF> w3_carve(unsigned char *smem)
+template <int SF, int HV = 0>
+__device__ __forceinline__ W3Lds<SF, HV> w3_carve(unsigned char *smem)
 {
-    using G = W3Geom<SF>;
-    W3Lds<SF> L;
+    using G = W3Geom<SF, HV>;
+    W3Lds<SF, HV> L;
     L.data = reinterpret_cast<v2f *>(smem);
     L.tw = L.data + (size_t)G::NG * G::data_entries;
     L.ws = reinterpret_cast<W3Shared *>(L.tw + G::NTW);
     return L;
 }
-template <int SF> constexpr uint32_t w3_lds_bytes()
+template <int SF, int HV = 0> constexpr uint32_t w3_lds_bytes()
 {
-    using G = W3Geom<SF>;
+    using G = W3Geom<SF, HV>;
     return (uint32_t)(((size_t)G::NG * G::data_entries + G::NTW) * sizeof(v2f) + ((sizeof(W3Shared) + 15) & ~(size_t)15));
 }
 
-template <int SF>
-__device__ __forceinline__ v2f w3_tw(const W3Lds<SF> &L, uint32_t idx)
+template <int SF, int HV = 0>
+__device__ __forceinline__ v2f w3_tw(const W3Lds<SF, HV> &L, uint32_t idx)
 {
-    using G = W3Geom<SF>;
+    using G = W3Geom<SF, HV>;
     if constexpr (G::NTW == G::N) return L.tw[idx];
     else {
         const v2f w = L.tw[idx & (uint32_t)(G::NTW - 1)];
@@ -220,10 +224,10 @@ __device__ __forceinline__ bool w3_ub(bool b) { return __builtin_amdgcn_readfirs
 
 // ---- group reductions: one barrier; slots alternate.  Every thread gets the totals of its OWN group (uniform); with `all`
 // (wave-uniform) the totals of EVERY group - what thread 0's replay consumes, so only its wavefront pays for them --------
-template <int SF, int K>
-__device__ __forceinline__ void w3_group_sums(float (&v)[K], W3Shared &ws, int &slot, int grp, int gwave, float (&out)[W3Geom<SF>::NG][K], bool all = true)
+template <int SF, int K, int HV = 0>
+__device__ __forceinline__ void w3_group_sums(float (&v)[K], W3Shared &ws, int &slot, int grp, int gwave, float (&out)[W3Geom<SF, HV>::NG][K], bool all = true)
 {
-    using G = W3Geom<SF>;
+    using G = W3Geom<SF, HV>;
     const int lane = threadIdx.x & 63;
     float (*red)[72] = ws.red[slot];
     slot ^= 1;
@@ -251,11 +255,11 @@ __device__ __forceinline__ void w3_group_sums(float (&v)[K], W3Shared &ws, int &
     }
 }
 
-template <int SF>
-__device__ __forceinline__ void w3_group_argmax_first(float v, int idx, W3Shared &ws, int &slot, int grp, int gwave, float (&bv_out)[W3Geom<SF>::NG],
-                                                      int (&bi_out)[W3Geom<SF>::NG], bool all = true)
+template <int SF, int HV = 0>
+__device__ __forceinline__ void w3_group_argmax_first(float v, int idx, W3Shared &ws, int &slot, int grp, int gwave, float (&bv_out)[W3Geom<SF, HV>::NG],
+                                                      int (&bi_out)[W3Geom<SF, HV>::NG], bool all = true)
 {
-    using G = W3Geom<SF>;
+    using G = W3Geom<SF, HV>;
     const int lane = threadIdx.x & 63;
     float (*red)[72] = ws.red[slot];
     slot ^= 1;
@@ -355,15 +359,15 @@ __device__ __forceinline__ void w3_ifreq16(const v2f (&a)[16], const v2f (&ap)[1
 struct W3DemodOut { uint32_t s[4]; int32_t fine[4]; float en[4]; int slot; };
 __device__ const v2f w3_no_pre[16] = {};
 struct W3DemodArgs { const float2 *down, *ctab; const float *up_ifreq_v; uint32_t enable_fine_sync, demod_mode; };
-template <int SF>
-__device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds<SF> &L, const float2 *__restrict__ x, bool valid, bool want_energy, int &slot,
-                                               uint32_t (&s_out)[W3Geom<SF>::NG], int32_t (&fine_out)[W3Geom<SF>::NG], float (&en_out)[W3Geom<SF>::NG],
+template <int SF, int HV = 0>
+__device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds<SF, HV> &L, const float2 *__restrict__ x, bool valid, bool want_energy, int &slot,
+                                               uint32_t (&s_out)[W3Geom<SF, HV>::NG], int32_t (&fine_out)[W3Geom<SF, HV>::NG], float (&en_out)[W3Geom<SF, HV>::NG],
                                                long long *stamps = nullptr /* tools/demod_bench.py --stamps: clock per phase */,
                                                bool use_pre = false, const v2f (&pre)[16] = w3_no_pre /* LORA_W3_PRELOAD: pair 0's samples, already requested (use_pre uniform) */)
 {
 #define LORA_W3STAMP(i) do { if (stamps) stamps[i] = clock64(); } while (0)
     LORA_W3STAMP(0);
-    using G = W3Geom<SF>;
+    using G = W3Geom<SF, HV>;
     constexpr int N = G::N, SPS = G::SPS, TG = G::TG, CH = G::CH, M2 = G::M2, AR = G::AR, SA = G::SA, PAIRS = G::PAIRS, ROUNDS = G::ROUNDS, NG = G::NG, VT = G::VT, U = G::U;
     int tt = threadIdx.x;
     asm volatile("" : "+v"(tt)); // keeps per-thread table addresses out of the caller's loop-invariant set
@@ -439,10 +443,10 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
             {
                 v2f w[8];
 #pragma unroll
-                for (int m = 1; m < 8; m++) w[m] = w3_tw<SF>(L, (uint32_t)(q0 * brev_bits(m, 4)));
+                for (int m = 1; m < 8; m++) w[m] = w3_tw<SF, HV>(L, (uint32_t)(q0 * brev_bits(m, 4)));
                 cmul_batch<7>(a + 1, w + 1);
 #pragma unroll
-                for (int m = 8; m < 16; m++) w[m - 8] = w3_tw<SF>(L, (uint32_t)(q0 * brev_bits(m, 4)));
+                for (int m = 8; m < 16; m++) w[m - 8] = w3_tw<SF, HV>(L, (uint32_t)(q0 * brev_bits(m, 4)));
                 cmul_batch<8>(a + 8, w);
             }
 #pragma unroll
@@ -517,10 +521,10 @@ if (p == 0 && use_pre) {
             {
                 v2f w[8];
 #pragma unroll
-                for (int m = 1; m < 8; m++) w[m] = w3_tw<SF>(L, (uint32_t)(q0 * brev_bits(m, 4)));
+                for (int m = 1; m < 8; m++) w[m] = w3_tw<SF, HV>(L, (uint32_t)(q0 * brev_bits(m, 4)));
                 cmul_batch<7>(a + 1, w + 1);
 #pragma unroll
-                for (int m = 8; m < 16; m++) w[m - 8] = w3_tw<SF>(L, (uint32_t)(q0 * brev_bits(m, 4)));
+                for (int m = 8; m < 16; m++) w[m - 8] = w3_tw<SF, HV>(L, (uint32_t)(q0 * brev_bits(m, 4)));
                 cmul_batch<8>(a + 8, w);
             }
 #pragma unroll
@@ -566,10 +570,10 @@ if (p == 0 && use_pre) {
             if (q1 != 0) { // W_{N/16}^{q1 a2} = W_N^{16 q1 a2}; q1 is the same in all lanes of a wavefront
                 v2f w[8];
 #pragma unroll
-                for (int m = 1; m < 8; m++) w[m] = w3_tw<SF>(L, (uint32_t)(16 * q1 * brev_bits(m, 4)));
+                for (int m = 1; m < 8; m++) w[m] = w3_tw<SF, HV>(L, (uint32_t)(16 * q1 * brev_bits(m, 4)));
                 cmul_batch<7>(a + 1, w + 1);
 #pragma unroll
-                for (int m = 8; m < 16; m++) w[m - 8] = w3_tw<SF>(L, (uint32_t)(16 * q1 * brev_bits(m, 4)));
+                for (int m = 8; m < 16; m++) w[m - 8] = w3_tw<SF, HV>(L, (uint32_t)(16 * q1 * brev_bits(m, 4)));
                 cmul_batch<8>(a + 8, w);
             }
 #pragma unroll
@@ -630,13 +634,13 @@ if (p == 0 && use_pre) {
     const bool all = grp == 0 && gwave == 0; // thread 0's wavefront: the replay needs every group's results
     float bvs[NG];
     int bis[NG];
-    w3_group_argmax_first<SF>(bv, bi, ws, slot, grp, gwave, bvs, bis, all);
+    w3_group_argmax_first<SF, HV>(bv, bi, ws, slot, grp, gwave, bvs, bis, all);
     LORA_W3STAMP(6);
 #pragma unroll
     for (int g = 0; g < NG; g++) { s_out[g] = (uint32_t)bis[g]; fine_out[g] = 0; en_out[g] = 0.0f; }
     if (want_energy) {
         float e1[1] = {en}, eo[NG][1];
-        w3_group_sums<SF, 1>(e1, ws, slot, grp, gwave, eo, all);
+        w3_group_sums<SF, 1, HV>(e1, ws, slot, grp, gwave, eo, all);
 #pragma unroll
         for (int g = 0; g < NG; g++) en_out[g] = eo[g][0];
     }
@@ -686,7 +690,7 @@ if (p == 0 && use_pre) {
     }
     LORA_W3STAMP(7);
     float co[NG][3];
-    w3_group_sums<SF, 3>(cs, ws, slot, grp, gwave, co, all);
+    w3_group_sums<SF, 3, HV>(cs, ws, slot, grp, gwave, co, all);
     LORA_W3STAMP(8);
 #undef LORA_W3STAMP
 #pragma unroll
@@ -707,11 +711,11 @@ if (p == 0 && use_pre) {
 // (volk_32f_accumulator_s32f / D, :475-476) is three DPP adds, its left neighbour one lane permute - across wavefront and
 // chunk boundaries through a small LDS array (one value per wavefront, chunk and pair) - and the largest drop above 0.1
 // (:479-488) a first-maximum reduction over the group.  s_out[g] is demodulate()'s bin_idx itself.
-template <int SF>
-__device__ __forceinline__ void w3_demod_round_grad(const W3DemodArgs &P, const W3Lds<SF> &L, const float2 *__restrict__ x, bool valid, bool want_energy, int &slot,
-                                                    uint32_t (&s_out)[W3Geom<SF>::NG], int32_t (&fine_out)[W3Geom<SF>::NG], float (&en_out)[W3Geom<SF>::NG])
+template <int SF, int HV = 0>
+__device__ __forceinline__ void w3_demod_round_grad(const W3DemodArgs &P, const W3Lds<SF, HV> &L, const float2 *__restrict__ x, bool valid, bool want_energy, int &slot,
+                                                    uint32_t (&s_out)[W3Geom<SF, HV>::NG], int32_t (&fine_out)[W3Geom<SF, HV>::NG], float (&en_out)[W3Geom<SF, HV>::NG])
 {
-    using G = W3Geom<SF>;
+    using G = W3Geom<SF, HV>;
     constexpr int N = G::N, SPS = G::SPS, TG = G::TG, CH = G::CH, PAIRS = G::PAIRS, NG = G::NG, GW = G::GW;
     int tt = threadIdx.x;
     asm volatile("" : "+v"(tt));
@@ -796,7 +800,7 @@ __device__ __forceinline__ void w3_demod_round_grad(const W3DemodArgs &P, const 
     const bool all = grp == 0 && gwave == 0;
     float bvs[NG];
     int bis[NG];
-    w3_group_argmax_first<SF>(bv, bi, ws, slot, grp, gwave, bvs, bis, all);
+    w3_group_argmax_first<SF, HV>(bv, bi, ws, slot, grp, gwave, bvs, bis, all);
 #pragma unroll
     for (int g = 0; g < NG; g++) {
         const uint32_t max_index = (bis[g] == 0x7fffffff) ? 0u : (uint32_t)bis[g] + 1u; // :486
@@ -805,7 +809,7 @@ __device__ __forceinline__ void w3_demod_round_grad(const W3DemodArgs &P, const 
     }
     if (want_energy) {
         float e1[1] = {en}, eo[NG][1];
-        w3_group_sums<SF, 1>(e1, ws, slot, grp, gwave, eo, all);
+        w3_group_sums<SF, 1, HV>(e1, ws, slot, grp, gwave, eo, all);
 #pragma unroll
         for (int g = 0; g < NG; g++) en_out[g] = eo[g][0];
     }
@@ -827,7 +831,7 @@ __device__ __forceinline__ void w3_demod_round_grad(const W3DemodArgs &P, const 
         }
     }
     float co[NG][3];
-    w3_group_sums<SF, 3>(cs, ws, slot, grp, gwave, co, all);
+    w3_group_sums<SF, 3, HV>(cs, ws, slot, grp, gwave, co, all);
 #pragma unroll
     for (int g = 0; g < NG; g++) {
         float mx = 0.0f;
@@ -840,10 +844,10 @@ __device__ __forceinline__ void w3_demod_round_grad(const W3DemodArgs &P, const 
 }
 
 // copies W_N^t into LDS; all threads; the caller synchronises
-template <int SF>
-__device__ __forceinline__ void w3_tables_to_lds(const DevParams &P, const W3Lds<SF> &L)
+template <int SF, int HV = 0>
+__device__ __forceinline__ void w3_tables_to_lds(const DevParams &P, const W3Lds<SF, HV> &L)
 {
-    using G = W3Geom<SF>;
+    using G = W3Geom<SF, HV>;
     const v2f *__restrict__ src = reinterpret_cast<const v2f *>(P.w3_tw);
     for (int i = threadIdx.x; i < G::NTW; i += G::T) L.tw[i] = src[i];
 }
@@ -862,9 +866,9 @@ __device__ __forceinline__ void w3_tables_to_lds(const DevParams &P, const W3Lds
 #ifndef LORA_W3_SFD_K
 #define LORA_W3_SFD_K 0x1111   // FIND_SFD windows per group and round
 #endif
-template <int SF> struct W3Acq {
+template <int SF, int HV = 0> struct W3Acq {
     static constexpr int KD = (LORA_W3_DET_K >> (4 * (SF - 9))) & 15, KS = (LORA_W3_SFD_K >> (4 * (SF - 9))) & 15;
-    static constexpr int NQD = KD * W3Geom<SF>::NG, NQS = KS * W3Geom<SF>::NG; // windows per round
+    static constexpr int NQD = KD * W3Geom<SF, HV>::NG, NQS = KS * W3Geom<SF, HV>::NG; // windows per round
     static_assert(KD >= 1 && KS >= 1 && NQD <= 8 && NQS <= 8, "results are kept for at most 8 windows per round");
 };
 struct alignas(16) W3AcqScratch { // in the demodulator's LDS data array
@@ -877,11 +881,11 @@ struct alignas(16) W3AcqScratch { // in the demodulator's LDS data array
 // ---- DETECT (:340-366): sums of c1 conj(c2), |c1|^2, |c2|^2 over the symbol pairs of the windows q = grp KD + k at x0 + q sps.
 // A group's KD windows are consecutive: its KD + 1 symbols are read once, the energy of a symbol serves the two windows it
 // belongs to (summed in the same order either way).  out[q] = {re, im, e1, e2}, uniform.
-template <int SF>
-__device__ __forceinline__ void w3_detect_round(const float2 *__restrict__ x0, int n_valid, W3AcqScratch *sc, float (&out)[W3Acq<SF>::NQD][4])
+template <int SF, int HV = 0>
+__device__ __forceinline__ void w3_detect_round(const float2 *__restrict__ x0, int n_valid, W3AcqScratch *sc, float (&out)[W3Acq<SF, HV>::NQD][4])
 {
-    using G = W3Geom<SF>;
-    constexpr int KD = W3Acq<SF>::KD, NQ = W3Acq<SF>::NQD, GW = G::GW;
+    using G = W3Geom<SF, HV>;
+    constexpr int KD = W3Acq<SF, HV>::KD, NQ = W3Acq<SF, HV>::NQD, GW = G::GW;
     int tt = threadIdx.x;
     asm volatile("" : "+v"(tt)); // keeps per-thread offsets out of the caller's loop-invariant set (they would be parked in scratch)
     const int grp = __builtin_amdgcn_readfirstlane(tt / G::TG), t = tt % G::TG, gwave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
@@ -958,11 +962,11 @@ __device__ __forceinline__ void w3_sync_ifreq16(const __attribute__((address_spa
         f[j] = fp.x; f[j + 1] = fp.y;
     }
 }
-template <int SF>
+template <int SF, int HV = 0>
 __device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double sync_b, const float2 *__restrict__ x, W3Shared *wsp, int slot,
                                                        const float *__restrict__ strict_u /* d_upchirp_ifreq, or nullptr: closed form only */, float *strict_buf)
 {
-    using G = W3Geom<SF>;
+    using G = W3Geom<SF, HV>;
     constexpr int SPS = G::SPS, LEN = G::LEN, WAVES = G::T / 64;
     constexpr int n = SPS - 1;
     W3Shared &ws = *wsp;
@@ -1111,11 +1115,11 @@ __device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double syn
 // fine_sync(-1, 4 D) over the 63 lags in closed form (see w2_sfd_window for the derivation).  c[q] and fine[q] come back uniform.
 struct W3SfdOut { float c[8]; int32_t fine[8]; };
 struct W3SfdArgs { const float *down_ifreq, *up_ifreq_v; float down_ifreq_avg, down_ifreq_sd, down_ifreq_dsum; double sync_a, sync_b; };
-template <int SF>
+template <int SF, int HV = 0>
 __device__ LORA_W3_SFD_INLINE W3SfdOut w3_sfd_round(W3SfdArgs P, const float2 *__restrict__ x0, int n_valid, W3AcqScratch *sc)
 {
-    using G = W3Geom<SF>;
-    constexpr int SPS = G::SPS, TG = G::TG, CH = G::CH, PAIRS = G::PAIRS, GW = G::GW, NG = G::NG, KS = W3Acq<SF>::KS, NQ = W3Acq<SF>::NQS;
+    using G = W3Geom<SF, HV>;
+    constexpr int SPS = G::SPS, TG = G::TG, CH = G::CH, PAIRS = G::PAIRS, GW = G::GW, NG = G::NG, KS = W3Acq<SF, HV>::KS, NQ = W3Acq<SF, HV>::NQS;
     const w3_buf_t ddb = w3_buf(P.down_ifreq);
     int tt = threadIdx.x;
     asm volatile("" : "+v"(tt));
@@ -1307,10 +1311,10 @@ __device__ __forceinline__ bool w3_post_symbol(const DevParams &P, W2State &S, S
 // is never used).  A round reads its NG windows in one burst at its very start - every CU at about the same time, so the burst
 // runs at the HBM limit (~11 B/clk/CU) while the rest of the round moves nothing; touched a round ahead, the lines come from L2 /
 // MALL instead.  The value must stay live until the data has landed (the caller consumes it at the top of the next round).
-template <int SF>
+template <int SF, int HV = 0>
 __device__ __forceinline__ void w3_touch(const float2 *X, int64_t first_item, int64_t fallback_item, int64_t n_items, float (&v)[4])
 {
-    using G = W3Geom<SF>;
+    using G = W3Geom<SF, HV>;
     // (always a load - past the end of the stream it re-reads the current window - and nothing done to the value: any use,
     // even a select against 0, makes the compiler wait for it right here)
     const int64_t fi = first_item + (int64_t)G::SPS <= n_items ? first_item : fallback_item; // uniform per group
@@ -1328,14 +1332,14 @@ __device__ __forceinline__ void w3_touch(const float2 *X, int64_t first_item, in
 // outcome that invalidates the later windows (a trigger, a state change, d_fine_sync != 0, a loop-top check, the end of
 // the data); it then writes the state back and the next plan.  The accepted sequence is exactly the serial one.  Keeping
 // the state out of the other wavefronts' registers is what lets the demodulator run without spills.
-template <int SF, bool GRAD>
+template <int SF, bool GRAD, int HV = 0>
 __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg &C)
 {
-    using G = W3Geom<SF>;
+    using G = W3Geom<SF, HV>;
     constexpr uint32_t sps = G::SPS;
     constexpr int T = G::T, NG = G::NG;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const W3Lds<SF> L = w3_carve<SF>(smem);
+    const W3Lds<SF, HV> L = w3_carve<SF, HV>(smem);
     W3Shared &ws = *L.ws;
     Shared &sh = ws.sh;
     W2State &S = ws.st;
@@ -1354,7 +1358,7 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
     int slot = 0;
     const W3DemodArgs DA{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode};
 
-    w3_tables_to_lds<SF>(P, L);
+    w3_tables_to_lds<SF, HV>(P, L);
     walker_stagger(LORA_W3_STAGGER);
 
     // plan for the next round from the TRUE state (thread 0 only)
@@ -1429,9 +1433,9 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
         W3AcqScratch *acq = reinterpret_cast<W3AcqScratch *>(L.data);
 
         if (plan_mode == kPlanDetect) { // :752-768, detect_preamble_autocorr :340-366
-            constexpr int NQ = W3Acq<SF>::NQD;
+            constexpr int NQ = W3Acq<SF, HV>::NQD;
             float a[NQ][4];
-            w3_detect_round<SF>(X + pos, n_in_data < NQ ? n_in_data : NQ, acq, a);
+            w3_detect_round<SF, HV>(X + pos, n_in_data < NQ ? n_in_data : NQ, acq, a);
             if (t0) {
                 W2State St = S;
                 for (int g = 0; g < NQ; g++) {
@@ -1469,7 +1473,7 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
         }
 
         if (plan_mode == kPlanSync) { // :770-783
-            const W3SyncOut so = w3_sync<SF>(P.sync_a, P.sync_b, X + pos, &ws, slot, P.strict_sync ? P.up_ifreq : nullptr, reinterpret_cast<float *>(L.data));
+            const W3SyncOut so = w3_sync<SF, HV>(P.sync_a, P.sync_b, X + pos, &ws, slot, P.strict_sync ? P.up_ifreq : nullptr, reinterpret_cast<float *>(L.data));
             slot = __builtin_amdgcn_readfirstlane(so.slot);
             if (t0) {
                 W2State St = S;
@@ -1484,8 +1488,8 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
         }
 
         if (plan_mode == kPlanSfd) { // :785-818
-            constexpr int NQ = W3Acq<SF>::NQS;
-            const W3SfdOut fo = w3_sfd_round<SF>(W3SfdArgs{P.down_ifreq, P.up_ifreq_v, P.down_ifreq_avg, P.down_ifreq_sd, P.down_ifreq_dsum, P.sync_a, P.sync_b}, X + pos,
+            constexpr int NQ = W3Acq<SF, HV>::NQS;
+            const W3SfdOut fo = w3_sfd_round<SF, HV>(W3SfdArgs{P.down_ifreq, P.up_ifreq_v, P.down_ifreq_avg, P.down_ifreq_sd, P.down_ifreq_dsum, P.sync_a, P.sync_b}, X + pos,
                                                  n_in_data < NQ ? n_in_data : NQ, acq);
             if (t0) {
                 W2State St = S;
@@ -1575,9 +1579,9 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
             uint32_t sq[NG];
             int32_t fq[NG];
             float eq[NG];
-            if constexpr (GRAD) w3_demod_round_grad<SF>(DA, L, xg, dvalid, P.implicit != 0u, slot, sq, fq, eq); // sq = bin_idx itself
+            if constexpr (GRAD) w3_demod_round_grad<SF, HV>(DA, L, xg, dvalid, P.implicit != 0u, slot, sq, fq, eq); // sq = bin_idx itself
 #if LORA_W3_PRELOAD
-            else w3_demod_round<SF>(DA, L, xg, dvalid, P.implicit != 0u, slot, sq, fq, eq, nullptr, use_pre, pre);
+            else w3_demod_round<SF, HV>(DA, L, xg, dvalid, P.implicit != 0u, slot, sq, fq, eq, nullptr, use_pre, pre);
             { // the next round's window of this group, assuming no symbol moves the clock: requested now, used (or dropped) a round later
                 const int64_t nbase = pos + (int64_t)NG * sps, ngpos = nbase + (int64_t)grp * sps;
                 pre_ok = !GRAD && ((LORA_W3_PRELOAD >> (SF - 9)) & 1) && ngpos + 2 * (int64_t)sps <= n_items;
@@ -1592,10 +1596,10 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                 }
             }
 #else
-            else w3_demod_round<SF>(DA, L, xg, dvalid, P.implicit != 0u, slot, sq, fq, eq);
+            else w3_demod_round<SF, HV>(DA, L, xg, dvalid, P.implicit != 0u, slot, sq, fq, eq);
 #endif
 #if LORA_W3_PREFETCH & 1
-            w3_touch<SF>(X, gpos + (int64_t)NG * sps, gvalid ? gpos : pos, n_items, touched);
+            w3_touch<SF, HV>(X, gpos + (int64_t)NG * sps, gvalid ? gpos : pos, n_items, touched);
 #endif
             if (t0) {
 #if LORA_W3_REPLAY_STATS
@@ -1745,6 +1749,11 @@ __global__ __launch_bounds__(W3Geom<9>::T, W3Geom<9>::T512 ? 2 : 4) void walker3
 __global__ __launch_bounds__(W3Geom<10>::T, W3Geom<10>::T512 ? 2 : 4) void walker3_kernel_sf10(DevParams P, LaunchCfg C) { walker3_body<10, false>(P, C); }
 __global__ __launch_bounds__(W3Geom<11>::T, W3Geom<11>::T512 ? 2 : 4) void walker3_kernel_sf11(DevParams P, LaunchCfg C) { walker3_body<11, false>(P, C); }
 __global__ __launch_bounds__(W3Geom<12>::T, W3Geom<12>::T512 ? 2 : 4) void walker3_kernel_sf12(DevParams P, LaunchCfg C) { walker3_body<12, false>(P, C); }
+// half-size workgroups, two per CU (W3Geom HV = 1): launched when a pass holds more jobs than full-size workgroups fit at once
+__global__ __launch_bounds__((W3Geom<9, 1>::T), 2) void walker3_kernel_sf9_half(DevParams P, LaunchCfg C) { walker3_body<9, false, 1>(P, C); }
+__global__ __launch_bounds__((W3Geom<10, 1>::T), 2) void walker3_kernel_sf10_half(DevParams P, LaunchCfg C) { walker3_body<10, false, 1>(P, C); }
+__global__ __launch_bounds__((W3Geom<9, 1>::T), 2) void walker3_kernel_sf9_grad_half(DevParams P, LaunchCfg C) { walker3_body<9, true, 1>(P, C); }
+__global__ __launch_bounds__((W3Geom<10, 1>::T), 2) void walker3_kernel_sf10_grad_half(DevParams P, LaunchCfg C) { walker3_body<10, true, 1>(P, C); }
 // demod_mode 0: the gradient demodulator (the reference's shipped default, :499) in the decode rounds
 __global__ __launch_bounds__(W3Geom<9>::T, W3Geom<9>::T512 ? 2 : 4) void walker3_kernel_sf9_grad(DevParams P, LaunchCfg C) { walker3_body<9, true>(P, C); }
 __global__ __launch_bounds__(W3Geom<10>::T, W3Geom<10>::T512 ? 2 : 4) void walker3_kernel_sf10_grad(DevParams P, LaunchCfg C) { walker3_body<10, true>(P, C); }
@@ -1752,14 +1761,14 @@ __global__ __launch_bounds__(W3Geom<11>::T, W3Geom<11>::T512 ? 2 : 4) void walke
 __global__ __launch_bounds__(W3Geom<12>::T, W3Geom<12>::T512 ? 2 : 4) void walker3_kernel_sf12_grad(DevParams P, LaunchCfg C) { walker3_body<12, true>(P, C); }
 
 // ---- symbol-level kernel: one group per symbol, for lora_hip_demod_symbols_device ------------------------------
-template <int SF, bool GRAD>
-__global__ __launch_bounds__(W3Geom<SF>::T, W3Geom<SF>::T512 ? 2 : 4) void demod_symbols_w3_kernel(DevParams P, const float2 *iq, const int64_t *offsets, uint32_t n,
+template <int SF, bool GRAD, int HV = 0>
+__global__ __launch_bounds__((W3Geom<SF, HV>::T), (W3Geom<SF, HV>::T512 ? 2 : 4)) void demod_symbols_w3_kernel(DevParams P, const float2 *iq, const int64_t *offsets, uint32_t n,
                                                                     uint32_t *bins, int32_t *fine, long long *stamps_out)
 {
-    using G = W3Geom<SF>;
+    using G = W3Geom<SF, HV>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const W3Lds<SF> L = w3_carve<SF>(smem);
-    w3_tables_to_lds<SF>(P, L);
+    const W3Lds<SF, HV> L = w3_carve<SF, HV>(smem);
+    w3_tables_to_lds<SF, HV>(P, L);
     __syncthreads();
     int slot = 0;
     const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x / G::TG);
@@ -1769,8 +1778,8 @@ __global__ __launch_bounds__(W3Geom<SF>::T, W3Geom<SF>::T512 ? 2 : 4) void demod
         int32_t fs[G::NG];
         float en[G::NG];
         long long stamps[9];
-        if constexpr (GRAD) w3_demod_round_grad<SF>(W3DemodArgs{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode}, L, iq + offsets[valid ? s0 + grp : s0], valid, false, slot, b, fs, en);
-        else w3_demod_round<SF>(W3DemodArgs{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode}, L, iq + offsets[valid ? s0 + grp : s0], valid, false, slot, b, fs, en,
+        if constexpr (GRAD) w3_demod_round_grad<SF, HV>(W3DemodArgs{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode}, L, iq + offsets[valid ? s0 + grp : s0], valid, false, slot, b, fs, en);
+        else w3_demod_round<SF, HV>(W3DemodArgs{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode}, L, iq + offsets[valid ? s0 + grp : s0], valid, false, slot, b, fs, en,
                            stamps_out ? stamps : nullptr);
         if (stamps_out && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && s0 == blockIdx.x * G::NG + gridDim.x * G::NG) // (second round of block 0: every wavefront's stamps)
             for (int i = 0; i < 9; i++) stamps_out[(threadIdx.x >> 6) * 9 + i] = stamps[i];
@@ -1785,10 +1794,10 @@ __global__ __launch_bounds__(W3Geom<SF>::T, W3Geom<SF>::T512 ? 2 : 4) void demod
 // ---- host side: tables -----------------------------------------------------------------------------------------
 // w3_tw: W_N^t, t < NTW.  w3_ctab: the combine coefficient of value i of thread t3 in round g at [(g 16 + i) T + t3]:
 // W_sps^{k r} for the signed bin k of k1 = a + 16 a2 + 256 b2 (+ the fold at k1 = N/2, :450).
-template <int SF>
+template <int SF, int HV = 0>
 static void build_w3_tables_sf(float2 *tw, float2 *ctab)
 {
-    using G = W3Geom<SF>;
+    using G = W3Geom<SF, HV>;
     constexpr int N = G::N, SPS = G::SPS, T = G::VT;
     for (int t = 0; t < G::NTW; t++) {
         const double a = -2.0 * M_PI * (double)t / (double)N;
@@ -1827,6 +1836,8 @@ void build_w3_tables(uint32_t sf, float2 *tw, float2 *ctab /* sps entries */)
     else if (sf == 12u) build_w3_tables_sf<12>(tw, ctab);
 }
 
+static uint32_t walker3_threads_half(uint32_t sf) { return (uint32_t)(sf == 9u ? W3Geom<9, 1>::T : W3Geom<10, 1>::T); }
+static uint32_t walker3_lds_half(uint32_t sf) { return sf == 9u ? w3_lds_bytes<9, 1>() : w3_lds_bytes<10, 1>(); }
 static uint32_t walker3_threads(uint32_t sf) { return (uint32_t)(sf == 9u ? W3Geom<9>::T : sf == 10u ? W3Geom<10>::T : sf == 11u ? W3Geom<11>::T : W3Geom<12>::T); }
 static uint32_t walker3_groups(uint32_t sf) { return sf == 9u ? W3Geom<9>::NG : sf == 10u ? W3Geom<10>::NG : 1u; }
 static uint32_t walker3_lds(uint32_t sf) { return sf == 9u ? w3_lds_bytes<9>() : sf == 10u ? w3_lds_bytes<10>() : sf == 11u ? w3_lds_bytes<11>() : w3_lds_bytes<12>(); }

@@ -31,6 +31,7 @@ struct SimEnv {
     uint32_t ctor_cr() const { return ctor_cr_; }
     uint32_t segment_symbols() const { return seg_symbols; }
     uint32_t resident_slots() const { return slots; }
+    uint32_t resident_slots_alt() const { return 0; }
     bool tracing() const { return false; }
     bool implicit() const { return false; }
     bool quiet_edges(const std::vector<StreamDesc> &streams, std::vector<std::vector<int64_t>> &edges)

@@ -1,6 +1,6 @@
 """BASELINE.json's configurations at their FULL sizes against the CPU oracle (same demodulator): every frame, every header
 position.  config 2: 1024 packets x 32 B at SF7 as one stream and as 8 streams; config 3: 256 packets per SF, SF7-12,
-CR4/5 and CR4/8; config 4: 64 continuous SF9 channels.  The oracle runs one decoder per stream on a thread pool (the
+CR4/5 - CR4/8; config 4: 64 continuous SF9 channels.  The oracle runs one decoder per stream on a thread pool (the
 ctypes calls release the GIL).
 
 In the reference's shipped configuration (gradient demodulator, decoder_impl.cc:499) configs 2 and 3 are ALSO held to
@@ -95,7 +95,7 @@ def test_config2_full_size_grad_vs_reference_fixture(streams):
 
 
 @pytest.mark.parametrize("sf", [7, 8, 9, 10, 11, 12])
-@pytest.mark.parametrize("cr", [1, 4])
+@pytest.mark.parametrize("cr", [1, 2, 3, 4])
 def test_config3_full_size_grad_vs_reference_fixture(sf, cr):
     _against_reference_fixture("config3-sf%d-cr%d" % (sf, cr))
 
@@ -108,7 +108,7 @@ def test_sf8_profile_workload_grad_vs_reference_fixture():
 @pytest.mark.parametrize("sf", [7, 8, 9, 10, 11, 12])
 def test_config3_full_size(oracle_mod, sf):
     n = 256
-    for cr in (1, 4):
+    for cr in (1, 2, 3, 4):     # BASELINE config 3: CR 4/5 - 4/8
         cfg, iq, offs, lens, expect = bench.make_workload(sf, cr, n, 32, 8, seed=100 * sf + cr)
         kw = dict(sf=sf, cr=4, reduced_rate=(sf > 10))
         want = _oracle_streams(oracle_mod, iq, offs, lens, 2, **kw)

