@@ -17,9 +17,6 @@
 // being rewritten.
 
 constexpr int kW2DetectK = 4;   // DETECT windows per worker and round
-#ifndef LORA_W2_DOUBLE
-#define LORA_W2_DOUBLE 0 // 1-3: the worker beside the control wavefront takes two windows of a decode round (measured slower)
-#endif
 #ifndef LORA_W2_WAVES_SF7
 #define LORA_W2_WAVES_SF7 8
 #endif
@@ -31,9 +28,6 @@ constexpr int kW2DetectK = 4;   // DETECT windows per worker and round
 #endif
 #ifndef LORA_W2_SFD_UNROLL
 #define LORA_W2_SFD_UNROLL 1 // both evaluations inlined: the second window's loads are issued under the first one's arithmetic (+1 %)
-#endif
-#ifndef LORA_W2_STAGGER
-#define LORA_W2_STAGGER 0 // start-up stagger between workgroups, shader clocks per step (measured: no gain)
 #endif
 #ifndef LORA_W2_EU_SF8
 #define LORA_W2_EU_SF8 2 // wavefronts per SIMD the SF8 kernel's register budget is set for
@@ -522,10 +516,9 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
 {
     constexpr int N = 1 << SF, SPS = 8 * N;
     constexpr int kW2 = 64 * WAVES, kW2Workers = WAVES - 1; // the last wavefront is the control wavefront
-    // Decode rounds look at kW2Win windows: one per worker, plus one more taken by the worker that shares its SIMD with the
-    // control wavefront (LORA_W2_DOUBLE).  WAVES wavefronts land two per SIMD, so with every worker taking one window the SIMD
-    // of the (mostly waiting) control wavefront carries half the arithmetic of the others and the round lasts as long as theirs.
-    constexpr int kW2Win = kW2Workers + (LORA_W2_DOUBLE ? 1 : 0);
+    // Decode rounds look at kW2Win windows: one per worker.  (A second window for the worker that shares its SIMD with the mostly waiting control
+    // wavefront was built and measured 13 % slower - the SIMD time-slices its wavefronts evenly, DESIGN 5.2 - and is gone from the sources.)
+    constexpr int kW2Win = kW2Workers;
     static_assert(kW2Win <= kW2MaxWaves, "speci is sized for kW2MaxWaves windows");
     static_assert(WAVES <= kW2MaxWaves, "W2Shared is sized for kW2MaxWaves wavefronts");
     constexpr uint32_t sps = SPS;
@@ -561,20 +554,6 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     const bool is_ctl = wave == kW2Workers;                 // control wavefront
     const bool t0 = threadIdx.x == kW2Workers * 64;         // the control thread: sole owner of the decoder state S
     if (is_ctl) __builtin_amdgcn_s_setprio(2);              // its serial bookkeeping is on every round's critical path
-    // the worker that takes two windows in a decode round: the lowest one on the control wavefront's SIMD
-    int dbl_wave = kW2Workers & 3;
-#if LORA_W2_DOUBLE == 2
-    {
-        const uint32_t simd = (__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3u;
-        if (lane == 0) ((volatile uint32_t *)W.red)[wave] = simd;
-        __syncthreads();
-        const uint32_t cs = ((volatile uint32_t *)W.red)[kW2Workers];
-        dbl_wave = -1;
-        for (int w = kW2Workers - 1; w >= 0; w--) if (((volatile uint32_t *)W.red)[w] == cs) dbl_wave = w;
-        dbl_wave = __builtin_amdgcn_readfirstlane(dbl_wave);
-        __syncthreads();
-    }
-#endif
 
     const uint32_t dbg_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime(), dbg_c0 = (uint32_t)(clock64() >> 6);
     WaveTabs FT{};
@@ -584,7 +563,6 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     } else {
         FT = wave_tabs_to_lds<SF>(P, tab4, vl, kW2);
     }
-    walker_stagger(LORA_W2_STAGGER);
     for (uint32_t i = threadIdx.x; i < sps; i += kW2) ddl[i] = P.down_ifreq[i] - P.down_ifreq_avg;
 
     // plan for the next round from the TRUE state (control thread only)
@@ -934,14 +912,8 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             }
         }
         if (!is_ctl) {
-            // window `wave`, and for the doubled worker window kW2Workers after it (one copy of the demodulator: no unrolling)
-            const int n_mine = (kW2Win > kW2Workers && wave == dbl_wave) ? 2 : 1;
-#if LORA_W2_DOUBLE == 3
-            if (n_mine == 2) __builtin_amdgcn_s_setprio(2); // two windows in the time the others take for one (reset at the top of the round)
-#endif
-#pragma nounroll
-            for (int rep = 0; rep < n_mine; rep++) {
-                const int widx = rep == 0 ? wave : kW2Workers;
+            { // window `wave`
+                const int widx = wave;
                 const int64_t dwpos = dpos + (int64_t)widx * sps;
                 const bool dvalid = widx < dn && dwpos + 2 * (int64_t)sps <= n_items;
                 uint32_t ws = 0;

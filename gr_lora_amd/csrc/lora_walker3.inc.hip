@@ -38,9 +38,6 @@
 // as in walker2).
 
 // build-time options (defaults = what ships; the others are kept for same-box A/B runs, tools/build_variant.sh + tools/ab.sh)
-#ifndef LORA_W3_PREFETCH
-#define LORA_W3_PREFETCH 0      // 1: decode rounds, 2: DETECT / FIND_SFD rounds touch the next round's lines in L2 (measured: no gain)
-#endif
 #ifndef LORA_W3_LATE_F_MASK
 #define LORA_W3_LATE_F_MASK 0   // bit (SF - 9): that SF's walker computes fine_sync's ifreq from a second read of the window
 #endif
@@ -75,13 +72,6 @@
 #define LORA_W3_P1_PIPE 0       // bit (SF - 9), 512-thread geometry only: pass 1 requests a pair's predecessors and dechirp factors together with its
                                 // samples, and the NEXT pair's samples before it computes on this one (pass 1 is half of a round and was a chain of
                                 // dependent load -> use stages: 2 x (samples, 2 x predecessors, 2 x dechirp factors))
-#endif
-#ifndef LORA_W3_PRELOAD
-#define LORA_W3_PRELOAD 0       // bit (SF - 9): decode rounds: the first 16 samples per thread of the NEXT round's window (zero drift assumed) are requested right
-                                // behind this round's last reduction and stay in flight under thread 0's replay and the plan barrier (32 registers)
-#endif
-#ifndef LORA_W3_STAGGER
-#define LORA_W3_STAGGER 0       // start-up stagger between workgroups, shader clocks per step (measured: no gain)
 #endif
 
 template <int SF, int HV = 0> struct W3Geom {
@@ -357,13 +347,11 @@ __device__ __forceinline__ void w3_ifreq16(const v2f (&a)[16], const v2f (&ap)[1
 // fine_sync(bin_idx, 2) (:300-338, :501-502; 0 when drift correction is off); en[g] = determine_energy (:368-375) when
 // want_energy.  Called by all threads of the workgroup (barriers inside); the results of every group come back uniform.
 struct W3DemodOut { uint32_t s[4]; int32_t fine[4]; float en[4]; int slot; };
-__device__ const v2f w3_no_pre[16] = {};
 struct W3DemodArgs { const float2 *down, *ctab; const float *up_ifreq_v; uint32_t enable_fine_sync, demod_mode; };
 template <int SF, int HV = 0>
 __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds<SF, HV> &L, const float2 *__restrict__ x, bool valid, bool want_energy, int &slot,
                                                uint32_t (&s_out)[W3Geom<SF, HV>::NG], int32_t (&fine_out)[W3Geom<SF, HV>::NG], float (&en_out)[W3Geom<SF, HV>::NG],
-                                               long long *stamps = nullptr /* tools/demod_bench.py --stamps: clock per phase */,
-                                               bool use_pre = false, const v2f (&pre)[16] = w3_no_pre /* LORA_W3_PRELOAD: pair 0's samples, already requested (use_pre uniform) */)
+                                               long long *stamps = nullptr /* tools/demod_bench.py --stamps: clock per phase */)
 {
 #define LORA_W3STAMP(i) do { if (stamps) stamps[i] = clock64(); } while (0)
     LORA_W3STAMP(0);
@@ -388,13 +376,8 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
     if constexpr (P1_PIPE) {
     if (valid) {
         v2f nxt[16];
-        if (use_pre) {
 #pragma unroll
-            for (int c = 0; c < 16; c++) nxt[c] = pre[c];
-        } else {
-#pragma unroll
-            for (int c = 0; c < 16; c++) nxt[c] = w3_ld2(xb, 8u * tu, (uint32_t)(c * CH * 8));
-        }
+        for (int c = 0; c < 16; c++) nxt[c] = w3_ld2(xb, 8u * tu, (uint32_t)(c * CH * 8));
 #pragma unroll
         for (int p = 0; p < PAIRS; p++) {
             const int base = p * TG + t;
@@ -468,13 +451,8 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
 #pragma unroll
             for (int c = 0; c < 16; c++) a[c] = (v2f){(float)(t + c), (float)(t ^ c)};
 #else
-if (p == 0 && use_pre) {
 #pragma unroll
-                for (int c = 0; c < 16; c++) a[c] = pre[c];
-            } else {
-#pragma unroll
-                for (int c = 0; c < 16; c++) a[c] = w3_ld2(xb, ob, (uint32_t)(c * CH * 8));
-            }
+            for (int c = 0; c < 16; c++) a[c] = w3_ld2(xb, ob, (uint32_t)(c * CH * 8));
 #endif
             if (want_energy) {
 #pragma unroll
@@ -1359,7 +1337,6 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
     const W3DemodArgs DA{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode};
 
     w3_tables_to_lds<SF, HV>(P, L);
-    walker_stagger(LORA_W3_STAGGER);
 
     // plan for the next round from the TRUE state (thread 0 only)
     auto plan_from = [&](W2State &St, W2Plan &pl) {
@@ -1395,21 +1372,8 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
         plan_from(S, ws.plan[0]);
     }
 
-#if LORA_W3_PREFETCH
-    float touched[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#endif
-#if LORA_W3_PRELOAD
-    v2f pre[16];
-    bool pre_ok = false;
-    int64_t pre_base = -1;
-#pragma unroll
-    for (int c = 0; c < 16; c++) pre[c] = (v2f){0.0f, 0.0f};
-#endif
     for (uint32_t it = 0;; it++) {
         __syncthreads(); // plan[it & 1] and everything thread 0 wrote are visible; plan[(it + 1) & 1] is free
-#if LORA_W3_PREFETCH
-        asm volatile("" :: "v"(touched[0]), "v"(touched[1]), "v"(touched[2]), "v"(touched[3])); // the previous round's touch has landed by the time this round's loads are waited for
-#endif
         const W2Plan &pl_in = ws.plan[it & 1u];
         const uint64_t pl_pp = (uint64_t)pl_in.pos;
         const int64_t pos = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(pl_pp >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)pl_pp));
@@ -1573,34 +1537,11 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
         // ---- kPlanDecode: DECODE_HEADER / DECODE_PAYLOAD rounds (:826-886, demodulate :493-529) ----
         {
             const bool dvalid = gvalid && grp < plan_n_win;
-#if LORA_W3_PRELOAD
-            const bool use_pre = !GRAD && ((LORA_W3_PRELOAD >> (SF - 9)) & 1) && pre_ok && pre_base == pos && dvalid; // (uniform: pre_base and pos are scalars, validity is per group)
-#endif
             uint32_t sq[NG];
             int32_t fq[NG];
             float eq[NG];
             if constexpr (GRAD) w3_demod_round_grad<SF, HV>(DA, L, xg, dvalid, P.implicit != 0u, slot, sq, fq, eq); // sq = bin_idx itself
-#if LORA_W3_PRELOAD
-            else w3_demod_round<SF, HV>(DA, L, xg, dvalid, P.implicit != 0u, slot, sq, fq, eq, nullptr, use_pre, pre);
-            { // the next round's window of this group, assuming no symbol moves the clock: requested now, used (or dropped) a round later
-                const int64_t nbase = pos + (int64_t)NG * sps, ngpos = nbase + (int64_t)grp * sps;
-                pre_ok = !GRAD && ((LORA_W3_PRELOAD >> (SF - 9)) & 1) && ngpos + 2 * (int64_t)sps <= n_items;
-                pre_base = nbase;
-                if (pre_ok) {
-                    int tq = threadIdx.x;
-                    asm volatile("" : "+v"(tq));
-                    const w3_buf_t nb = w3_buf(w3_uniform_ptr(X + ngpos));
-                    const uint32_t ob = 8u * (uint32_t)(tq % G::TG);
-#pragma unroll
-                    for (int c = 0; c < 16; c++) pre[c] = w3_ld2(nb, ob, (uint32_t)(c * G::CH * 8));
-                }
-            }
-#else
             else w3_demod_round<SF, HV>(DA, L, xg, dvalid, P.implicit != 0u, slot, sq, fq, eq);
-#endif
-#if LORA_W3_PREFETCH & 1
-            w3_touch<SF, HV>(X, gpos + (int64_t)NG * sps, gvalid ? gpos : pos, n_items, touched);
-#endif
             if (t0) {
 #if LORA_W3_REPLAY_STATS
                 const long long tr0 = clock64(); // (LORA_HIP_DEBUG accounting: ctl[0] = the demodulation, ctl[1] = thread 0's replay, of the decode rounds)
