@@ -40,7 +40,10 @@ EXPORTS_CHANNELIZER = [
 class ChannelizerConfig(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("samp_rate", C.c_float), ("center_freq", C.c_float), ("channel_list", C.POINTER(C.c_float)),
                 ("n_channels", C.c_uint32), ("bandwidth", C.c_uint32), ("decimation", C.c_uint32), ("device", C.c_int32),
-                ("cutoff_hz", C.c_float), ("transition_hz", C.c_float)]
+                ("cutoff_hz", C.c_float), ("transition_hz", C.c_float), ("flags", C.c_uint32)]
+
+
+CHANNELIZER_FLAG_UINT32_OFFSET = 1  # d_freq_offset in upstream's uint32_t arithmetic (a negative offset wraps), include/lora_hip_channelizer.h
 
 
 class Config(C.Structure):
@@ -489,13 +492,13 @@ class Mux:
 class Channelizer:
     """lora_hip_channelizer_* (include/lora_hip_channelizer.h): the frequency-translating FIR in front of the decoder."""
 
-    def __init__(self, samp_rate, center_freq, channel_list, bandwidth, decimation=1, device=0, cutoff_hz=0.0, transition_hz=0.0):
+    def __init__(self, samp_rate, center_freq, channel_list, bandwidth, decimation=1, device=0, cutoff_hz=0.0, transition_hz=0.0, flags=0):
         self.L = load()
         self.n_channels = len(channel_list)
         self._chan = (C.c_float * self.n_channels)(*[float(c) for c in channel_list])
         cfg = ChannelizerConfig(struct_size=C.sizeof(ChannelizerConfig), samp_rate=float(samp_rate), center_freq=float(center_freq),
                                 channel_list=self._chan, n_channels=self.n_channels, bandwidth=int(bandwidth), decimation=int(decimation), device=int(device),
-                                cutoff_hz=float(cutoff_hz), transition_hz=float(transition_hz))
+                                cutoff_hz=float(cutoff_hz), transition_hz=float(transition_hz), flags=int(flags))
         self.h = C.c_void_p()
         st = self.L.lora_hip_channelizer_create(C.byref(cfg), C.byref(self.h))
         if st != 0:

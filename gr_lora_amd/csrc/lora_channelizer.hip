@@ -182,6 +182,7 @@ struct lora_hip_channelizer {
     int tile_in = 0;               // input items per workgroup
     std::vector<ChanParams> chan;
     float cfo = 0.0f;          // d_cfo is a float upstream (channelizer_impl.h:37)
+    bool cfo_applied = false;  // apply_cfo has run: the frequency is d_freq_offset + d_cfo in float from then on (:70)
     int device = 0;
     long long n_abs = 0;       // input items consumed so far
     float *d_taps = nullptr;
@@ -222,7 +223,11 @@ lora_hip_status upload_channels(lora_hip_channelizer *h, bool first)
     for (size_t c = 0; c < h->channels.size(); c++) {
         // d_freq_offset = channel_list[0] - center_freq: a float subtraction stored in a uint32_t (:47, channelizer_impl.h:39),
         // i.e. truncated to whole Hz; a negative offset keeps its sign here (upstream it wraps: unsigned field, UB conversion)
-        const double f = std::trunc((double)(float)(h->channels[c] - h->cfg.center_freq)) + (double)h->cfo; // + d_cfo (:70)
+        double f = std::trunc((double)(float)(h->channels[c] - h->cfg.center_freq)) + (double)h->cfo; // + d_cfo (:70)
+        if (h->cfg.flags & LORA_HIP_CHANNELIZER_FLAG_UINT32_OFFSET) { // upstream's own arithmetic: the unsigned field (a negative offset wraps), the CFO added in float
+            const uint32_t u = (uint32_t)(int64_t)(float)(h->channels[c] - h->cfg.center_freq);
+            f = h->cfo_applied ? (double)((float)u + h->cfo) : (double)u;
+        }
         const double tps = f / (double)h->cfg.samp_rate;
         if (!first) { // keep the oscillator phase continuous across the change
             ChanParams &cp = h->chan[c];
@@ -406,6 +411,7 @@ lora_hip_status lora_hip_channelizer_apply_cfo(lora_hip_channelizer_t *h, float 
     if (!h) return LORA_HIP_ERR_ARG;
     CH_TRY(h, hipSetDevice(h->device));
     h->cfo += cfo; // :69
+    h->cfo_applied = true;
     return upload_channels(h, false);
 }
 

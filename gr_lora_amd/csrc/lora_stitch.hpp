@@ -316,6 +316,7 @@ int decode_begin(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
         Job &j = jobs[k];
         j.stream_off = sd.off; j.stream_len = sd.len; j.start = segs[k].b0; j.scan_limit = segs[k].b1;
         j.stream_id = sd.id; j.cr_prev = (k == first_seg[segs[k].stream]) ? sd.cr_in : env.ctor_cr();
+        j.cr_is_guess = (k == first_seg[segs[k].stream]) ? 0u : 1u; // (a later segment's d_phdr.cr is its predecessor's last header's: unknown here)
         j.max_attempts = 0; j.stop_at_header = 0;
         // tail probe: past its own limit the job continues as the next segment's probe (same limit an explicit probe gets)
         const bool has_next = k + 1 < segs.size() && segs[k + 1].stream == segs[k].stream;

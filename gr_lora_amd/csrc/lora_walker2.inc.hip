@@ -59,6 +59,7 @@ struct alignas(16) W2State {
     uint32_t n_att, npush, n_steps, frame_ok;
     uint32_t att_cr_prev, att_ambig;
     uint32_t n_sfd;       // FIND_SFD steps of the open attempt whose entry state is in its record (walker3)
+    uint32_t cr_guess;    // Job.cr_is_guess until the first header is parsed
     float    energy_threshold;
     float    push_tail[4];
     uint8_t  phdr[4];
@@ -215,8 +216,14 @@ __device__ __forceinline__ bool w2_post_symbol(const DevParams &P, W2State &S, S
             decode_header_bytes(sh, S.n_cw, 2, hA);
             decode_header_bytes(sh, S.n_cw, 1, hB);
             const uint8_t *use = (S.cr >= 3u) ? hA : (S.cr >= 1u ? hB : h0);
-            S.phdr[0] = use[0]; S.phdr[1] = use[1]; S.phdr[2] = use[2];
             S.att_ambig = (uint32_t)((hA[0] != hB[0]) || (hA[1] != hB[1]) || (hA[2] != hB[2]));
+            if (S.cr_guess && S.att_ambig) { // Job.cr_is_guess: the branch whose own header names a coding rate of its class (the stitch checks the choice)
+                const uint32_t ca = hA[1] >> 5, cb = hB[1] >> 5;
+                const bool okA = ca >= 3u, okB = cb == 1u || cb == 2u;
+                if (okA != okB) { use = okA ? hA : hB; S.cr = okA ? 4u : 1u; S.att_cr_prev = S.cr; }
+            }
+            S.cr_guess = 0;
+            S.phdr[0] = use[0]; S.phdr[1] = use[1]; S.phdr[2] = use[2];
             const uint32_t rem = S.n_cw > 5u ? S.n_cw - 5u : 0u; // erase the 5 header codewords (:632)
             for (uint32_t i = 0; i < rem; i++) sh.cw[i] = sh.cw[i + 5u];
             S.n_cw = rem;
@@ -616,6 +623,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         S.state = kDetect; S.pos = job.start; S.cr = job.cr_prev; S.has_crc = P.ctor_crc;
         S.phdr[1] = (uint8_t)((P.ctor_cr << 5) | (P.ctor_crc << 4));
         S.att_start = job.start; S.att_trig = -1; S.att_hdr = -1; S.att_cr_prev = job.cr_prev;
+        S.cr_guess = (phase == 0) ? job.cr_is_guess : 0u; // (the tail probe starts from the job's own end state: no guess)
         if (job.start_at_header && phase == 0) { S.state = kDecodeHeader; S.in_attempt = 1; S.att_trig = job.start; S.att_hdr = job.start; } // (acquired elsewhere)
         if (phase == 0) W.stats = W2Stats{};
         W.stats.prev_state = -1;

@@ -37,7 +37,14 @@ typedef struct lora_hip_channelizer_config {
      * the receiver (python/qa_testsuite.py:233); apps/qa_testsuite.py builds that one through these fields.           */
     float    cutoff_hz;
     float    transition_hz;
+    uint32_t flags;          /* LORA_HIP_CHANNELIZER_FLAG_* (callers built against the older, shorter struct: 0) */
 } lora_hip_channelizer_config_t;
+
+/* Upstream keeps d_freq_offset = channel_list[0] - center_freq in a uint32_t (lib/channelizer_impl.h:39, channelizer_impl.cc:47): whole Hz,
+ * and a NEGATIVE offset wraps - the x86-64 conversion of -100032.0f yields 4294867264, the filter translates by that many Hz (an alias:
+ * +867264 Hz at 1 Msps, not -100032) and apply_cfo adds the CFO to it in float (:70).  By default this library keeps the sign, which is
+ * what the block is meant to do; with this flag it reproduces upstream's arithmetic bit for bit (for A/B runs against an upstream flowgraph). */
+#define LORA_HIP_CHANNELIZER_FLAG_UINT32_OFFSET 1u
 
 typedef struct lora_hip_channelizer lora_hip_channelizer_t;
 

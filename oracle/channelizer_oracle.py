@@ -37,7 +37,7 @@ def firdes_low_pass(gain: float, fs: float, cutoff: float, transition: float) ->
 class Channelizer:
     """Streaming restatement; one instance per channel (the reference translates channel_list[0] only)."""
 
-    def __init__(self, samp_rate, center_freq, channel_freq, bandwidth, decimation=1):
+    def __init__(self, samp_rate, center_freq, channel_freq, bandwidth, decimation=1, uint32_offset=False):
         self.fs = float(samp_rate)
         self.decimation = int(decimation)
         self.taps = firdes_low_pass(1.0, samp_rate, float(int(bandwidth) // 2) + 15000.0, 10000.0)
@@ -46,6 +46,11 @@ class Channelizer:
         # unsigned field; the float -> unsigned conversion of a negative value is undefined behaviour); here and in the
         # device library it keeps its sign, which is what the block is meant to do.
         self.freq = float(np.trunc(np.float32(channel_freq) - np.float32(center_freq)))
+        # uint32_offset: upstream's arithmetic as it stands - the value lands in a uint32_t (a negative one wraps: the x86-64 conversion goes
+        # through int64), and apply_cfo adds d_cfo to it in float (LORA_HIP_CHANNELIZER_FLAG_UINT32_OFFSET)
+        self.uint32_offset = bool(uint32_offset)
+        if self.uint32_offset:
+            self.freq = float(int(np.trunc(np.float32(channel_freq) - np.float32(center_freq))) % (1 << 32))
         self.cfo = 0.0
         self._hist = np.zeros(len(self.taps) - 1, dtype=np.complex128)   # raw input history (filter delay line)
         self._n = 0            # absolute index of the next input item
@@ -55,12 +60,15 @@ class Channelizer:
         # d_cfo += cfo; set_center_freq(d_freq_offset + d_cfo) (:68-71): freq_xlating rebuilds its band-pass taps for
         # the new frequency (they apply to the delay line as it stands) and its rotator keeps its phase
         self.cfo += float(np.float32(cfo))
+        if self.uint32_offset:   # d_freq_offset + d_cfo: uint32_t + float -> float
+            self.cfo = float(np.float32(self.cfo))
+            self._f_override = float(np.float32(np.float32(self.freq) + np.float32(self.cfo)))
 
     def work(self, x) -> np.ndarray:
         x = np.asarray(x, dtype=np.complex64).astype(np.complex128)
         if x.size == 0:
             return np.zeros(0, dtype=np.complex128)
-        tps = (self.freq + self.cfo) / self.fs
+        tps = (getattr(self, "_f_override", None) if getattr(self, "_f_override", None) is not None else (self.freq + self.cfo)) / self.fs
         k = np.arange(len(self.taps), dtype=np.float64)
         bp = self.taps.astype(np.float64) * np.exp(2j * np.pi * tps * k)          # band-pass taps h[k] e^{+j theta k}
         buf = np.concatenate([self._hist, x])

@@ -157,3 +157,31 @@ def test_wideband_four_channels_device_resident(torch_cuda, oracle_mod):
         assert got.get(c, []) == want
     ch.close()
     h.close()
+
+
+def test_uint32_offset_compat_mode(torch_cuda):
+    """LORA_HIP_CHANNELIZER_FLAG_UINT32_OFFSET: upstream keeps d_freq_offset in a uint32_t (lib/channelizer_impl.h:39) - a channel BELOW the
+    tuned frequency wraps (868.0 MHz tuned, 867.9 MHz wanted: -100032 -> 4294867264 Hz, an alias at 1 Msps) and apply_cfo adds in float
+    (:70).  With the flag the device reproduces that arithmetic (same tolerance against the float64 restatement as everything else in
+    this file); without it the offset keeps its sign.  No reference-held vector exists for this block: parity stays UNPINNED at sample
+    level - the oracle is a restatement of GNU Radio's published algorithm, not of its output."""
+    from gr_lora_amd import capi
+    from oracle import channelizer_oracle as co
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal(60000) + 1j * rng.standard_normal(60000)).astype(np.complex64)
+    for flags, compat in ((capi.CHANNELIZER_FLAG_UINT32_OFFSET, True), (0, False)):
+        ch = capi.Channelizer(1e6, 868.0e6, [867.9e6], 125000, 2, flags=flags)
+        ref = co.Channelizer(1e6, 868.0e6, 867.9e6, 125000, 2, uint32_offset=compat)
+        y0, r0 = ch.work(x[:30000])[0], ref.work(x[:30000])
+        ch.apply_cfo(137.5); ref.apply_cfo(137.5)
+        y1, r1 = ch.work(x[30000:])[0], ref.work(x[30000:])
+        y, r = np.concatenate([y0, y1]), np.concatenate([r0, r1])
+        assert y.size == r.size
+        assert np.abs(y - r).max() <= 2e-5 * np.abs(r).max(), (compat, float(np.abs(y - r).max() / np.abs(r).max()))
+        ch.close()
+    # the two modes really differ on a negative offset
+    a = capi.Channelizer(1e6, 868.0e6, [867.9e6], 125000, 2, flags=capi.CHANNELIZER_FLAG_UINT32_OFFSET)
+    b = capi.Channelizer(1e6, 868.0e6, [867.9e6], 125000, 2)
+    ya, yb = a.work(x[:8192])[0], b.work(x[:8192])[0]
+    assert np.abs(ya - yb).max() > 0.05 * np.abs(yb).max()
+    a.close(); b.close()

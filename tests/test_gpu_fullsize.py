@@ -79,14 +79,23 @@ def _against_reference_fixture(tag):
     cfg, iq, offs, lens, expect = bench.make_workload(fx["sf"], fx["cr"], fx["packets"], fx["payload"], fx["streams"], seed=fx["seed"])
     assert int(iq.size) == fx["n_items"]
     got = _gpu_streams(iq, offs, lens, 0, **fx["decoder_kw"])
+    stale_reads = 0
     for s, ((gf, gp), want) in enumerate(zip(got, fx["per_stream"])):
         assert len(gf) == want["frames"], (tag, s, len(gf), want["frames"])
         # every spreading factor: the reference's bytes and the reference's header positions.  (Until round 3 SF11 / SF12 carried a
         # latitude here - positions within one sample, up to 10 % differing frames at CR 4/5: SYNC's closed form landed on the other
         # side of detect_upchirp's float tie in every packet.  The tie is now decided with the reference's own arithmetic.)
         assert gp == want["header_pos"], (tag, s, sum(a != b for a, b in zip(gp, want["header_pos"])))
-        assert [hashlib.sha256(f).hexdigest()[:10] for f in gf] == want["frame_sha"], (tag, s)
-        assert _digest(gf) == want["sha256"], (tag, s)
+        # One thing the reference does cannot be reproduced: a header that decodes to CR 0 (bit errors; "no switch case", decoder_impl.cc:655-675)
+        # leaves d_decoded EMPTY, and the reference then reads its header (memcpy(&d_phdr, &d_decoded[0], 3), :833) and publishes its payload
+        # (:603) out of the vector's stale storage - whatever earlier packets left on the heap.  Oracle and device pin those reads to zeros
+        # (oracle/lora_oracle.h); from the first frame of a stream whose published PHY header carries CR 0 on, d_phdr.cr stays 0 and every
+        # later frame of that stream is such a read: those frames are compared by count and position only.  (SF11 / SF12 at CR 4/7: 11 of 256.)
+        cut = next((i for i, f in enumerate(gf) if (f[16] >> 5) == 0), len(gf))
+        assert [hashlib.sha256(f).hexdigest()[:10] for f in gf[:cut]] == want["frame_sha"][:cut], (tag, s)
+        assert cut == len(gf) and _digest(gf) == want["sha256"] or cut < len(gf), (tag, s)
+        stale_reads += len(gf) - cut
+    assert stale_reads <= fx["packets"] // 16, (tag, stale_reads)
 
 
 @pytest.mark.parametrize("streams", [1, 8])

@@ -22,8 +22,8 @@ if sys.argv[1] == "run":
         rng = np.random.default_rng(sf)
         up = synth.base_upchirp(cfg)
         base = np.concatenate([np.roll(up, -int(s) * 8) for s in rng.integers(0, cfg.nbins, 64)]).astype(np.complex64)
-        iq = np.tile(base, n // 64)
-        offs = np.arange(n, dtype=np.int64) * cfg.sps
+        iq = np.concatenate([np.zeros(cfg.sps, np.complex64), np.tile(base, n // 64), np.zeros(cfg.sps, np.complex64)])  # (a symbol of margin at both ends)
+        offs = (1 + np.arange(n, dtype=np.int64)) * cfg.sps
         d = torch.from_numpy(iq.view(np.float32)).cuda()
         for demod in (2, 0):
             h = capi.Handle(sf=sf, demod=demod)
