@@ -83,11 +83,6 @@ struct Job {
     uint32_t tail_stop_sfd; // 1: the tail probe (probe_limit) stops behind its FIRST FIND_SFD step instead of at the header (kAttemptAtSfd): two
                            // trajectories that start a FIND_SFD step at the same sample with the same d_corr_fails are one from there on
                            // (:785-818 read nothing else), and the successor's attempt records hold every such state it went through
-    uint32_t cr_is_guess;  // 1: cr_prev is a guess (a speculative segment job: the true d_phdr.cr is its predecessor's last header's).  When the two
-                           // header FEC branches (:655) then disagree on the job's first header, the job takes the branch whose own header
-                           // names a coding rate of its class - traffic rarely changes CR from one packet to the next - and reports that
-                           // class in AttemptRec.cr_prev; the stitch accepts it only if the true d_phdr.cr is of that class, as before
-    uint32_t rsv1;
 };
 
 struct AttemptRec {

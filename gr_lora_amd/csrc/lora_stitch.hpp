@@ -316,7 +316,6 @@ int decode_begin(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
         Job &j = jobs[k];
         j.stream_off = sd.off; j.stream_len = sd.len; j.start = segs[k].b0; j.scan_limit = segs[k].b1;
         j.stream_id = sd.id; j.cr_prev = (k == first_seg[segs[k].stream]) ? sd.cr_in : env.ctor_cr();
-        j.cr_is_guess = (k == first_seg[segs[k].stream]) ? 0u : 1u; // (a later segment's d_phdr.cr is its predecessor's last header's: unknown here)
         j.max_attempts = 0; j.stop_at_header = 0;
         // tail probe: past its own limit the job continues as the next segment's probe (same limit an explicit probe gets)
         const bool has_next = k + 1 < segs.size() && segs[k + 1].stream == segs[k].stream;
@@ -380,6 +379,62 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
         return false;
     };
     auto job_ok = [&](size_t k) { return !R1.res[k].pad && R1.res[k].stop_reason != 2u; };
+    // ---- round 1b: segment jobs that guessed the wrong header FEC branch.  A later segment's job runs with the constructor's d_phdr.cr; the true
+    // one is its predecessor's last header's (:655).  Where the two are of different Hamming classes AND the two decodes of the job's first header
+    // disagree (bit errors: hdr_ambig), its frames are not the true decoder's - at CR 4/5 / 4/6 under noise that is most packets - and used to cost
+    // one serial launch per segment (32 ms for 16 of SF12's 256 packets).  The predecessor's tail probe has already reported the true value
+    // (cr_prev of its pending record): all such jobs are run again, together, with it, and take their originals' place before anything is
+    // stitched.  (The choice is checked like any other speculation: the stitch compares branch classes again.)
+    if (segmenting) {
+        std::vector<Job> rjobs;
+        std::vector<size_t> rk;
+        for (size_t i = 0; i < streams.size(); i++) {
+            for (size_t k = first_seg[i] + 1; k < first_seg[i + 1]; k++) {
+                const JobResult &pj = R1.res[k - 1];
+                if (!pj.tail_valid || !pj.tail_pad || pj.tail_n_attempts == 0u) continue;
+                const uint32_t li = std::min(pj.tail_first_rec, R1.cap) + pj.tail_n_attempts - 1u;
+                if (li >= R1.cap) continue;
+                const AttemptRec &L = R1.rec(k - 1, li);
+                if (L.status != kAttemptAtHeader && L.status != kAttemptAtSfd) continue;
+                const bool at_sfd = L.status == kAttemptAtSfd;
+                if (at_sfd && L.n_sfd == 0u) continue;
+                bool wrong = false, right = false;
+                const uint32_t nall = std::min(R1.res[k].n_attempts, R1.cap);
+                for (uint32_t a = 0; a < nall; a++) {
+                    const AttemptRec &r = R1.rec(k, a);
+                    if (r.hdr_pos < 0 || (r.status != kAttemptFrame && r.status != kAttemptOutOfData)) continue;
+                    bool same = !at_sfd && r.hdr_pos == L.hdr_pos;
+                    if (at_sfd)
+                        for (uint32_t z = 0; z < r.n_sfd && z < (uint32_t)kMaxSfdRec; z++)
+                            same = same || (r.sfd_pos[z] == L.sfd_pos[L.n_sfd - 1u] && r.sfd_fails[z] == L.sfd_fails[L.n_sfd - 1u]);
+                    if (!same) continue;
+                    const int cj = cr_class(r.cr_prev), cl = cr_class(L.cr_prev);
+                    if (cj != cl && (r.hdr_ambig || cj == 0 || cl == 0)) wrong = true; else right = true;
+                    break;
+                }
+                if (!wrong || right) continue;
+                Job j = jobs[k];
+                j.cr_prev = L.cr_prev;
+                rjobs.push_back(j);
+                rk.push_back(k);
+            }
+        }
+        if (!rjobs.empty()) {
+            RunOut &R3 = env.run_out(1);
+            R3.res.clear(); R3.recs.clear();
+            env.count_slow_path();
+            s = env.run_jobs(rjobs, rpj1, 0, R3);
+            if (s != 0) return s;
+            for (size_t q = 0; q < rk.size(); q++) {
+                const JobResult &nr = R3.res[q];
+                const uint32_t n = nr.n_attempts + (nr.tail_valid ? nr.tail_n_attempts : 0u);
+                if (n > R1.rpj || n > R3.cap) continue; // (does not fit the original's row: the original stands, the stitch falls back)
+                R1.res[rk[q]] = nr;
+                for (uint32_t a = 0; a < n; a++) R1.recs[rk[q] * R1.rpj + a] = R3.rec(q, a);
+            }
+            if (dbg_t) fprintf(stderr, "[lora_hip] %zu segment job(s) run again with the header FEC branch their predecessor's tail probe reported\n", rjobs.size());
+        }
+    }
     struct Probe { uint32_t stream; size_t target; Cursor start; int job; int tail_of; }; // job: index into pjobs, or -1 with tail_of = the job whose tail it is
     std::vector<Probe> probes;
     std::vector<size_t> first_probe(streams.size() + 1, 0);

@@ -58,8 +58,6 @@ struct alignas(16) W2State {
     uint32_t n_words, n_cw, n_sym;
     uint32_t n_att, npush, n_steps, frame_ok;
     uint32_t att_cr_prev, att_ambig;
-    uint32_t n_sfd;       // FIND_SFD steps of the open attempt whose entry state is in its record (walker3)
-    uint32_t cr_guess;    // Job.cr_is_guess until the first header is parsed
     float    energy_threshold;
     float    push_tail[4];
     uint8_t  phdr[4];
@@ -140,7 +138,9 @@ __device__ __forceinline__ bool w2_pre_step(W2State &S, const Job &job, uint32_t
     return true;
 }
 
-// `lead`: this lane performs the global stores (the decode rounds run this on the whole control wavefront, uniformly)
+// `lead`: this lane performs the global stores (the decode rounds run this on the whole control wavefront, uniformly).
+// KEEP_SFD: the caller (walker3) maintains AttemptRec.n_sfd itself; otherwise a finished attempt reports none.
+template <bool KEEP_SFD = false>
 __device__ __forceinline__ void w2_end_step(W2State &S, const Job &job, const LaunchCfg &C, AttemptRec *recs, StepRec *trace, int32_t st_in,
                             int32_t consumed, int32_t step_bin, int32_t fine, float step_val, long long t_start, bool lead = true)
 {
@@ -160,9 +160,8 @@ __device__ __forceinline__ void w2_end_step(W2State &S, const Job &job, const La
             r.npush = S.npush;
             for (int i = 0; i < 4; i++) r.push_tail[i] = S.push_tail[i];
             r.cr_prev = S.att_cr_prev; r.hdr_ambig = S.att_ambig; r.n_symbols = S.n_sym;
-            r.n_sfd = S.n_sfd < (uint32_t)kMaxSfdRec ? S.n_sfd : (uint32_t)kMaxSfdRec;
+            if constexpr (!KEEP_SFD) r.n_sfd = 0;
         }
-        S.n_sfd = 0;
         S.n_att++;
         S.in_attempt = 0;
         S.frame_ok = 0;
@@ -217,12 +216,6 @@ __device__ __forceinline__ bool w2_post_symbol(const DevParams &P, W2State &S, S
             decode_header_bytes(sh, S.n_cw, 1, hB);
             const uint8_t *use = (S.cr >= 3u) ? hA : (S.cr >= 1u ? hB : h0);
             S.att_ambig = (uint32_t)((hA[0] != hB[0]) || (hA[1] != hB[1]) || (hA[2] != hB[2]));
-            if (S.cr_guess && S.att_ambig) { // Job.cr_is_guess: the branch whose own header names a coding rate of its class (the stitch checks the choice)
-                const uint32_t ca = hA[1] >> 5, cb = hB[1] >> 5;
-                const bool okA = ca >= 3u, okB = cb == 1u || cb == 2u;
-                if (okA != okB) { use = okA ? hA : hB; S.cr = okA ? 4u : 1u; S.att_cr_prev = S.cr; }
-            }
-            S.cr_guess = 0;
             S.phdr[0] = use[0]; S.phdr[1] = use[1]; S.phdr[2] = use[2];
             const uint32_t rem = S.n_cw > 5u ? S.n_cw - 5u : 0u; // erase the 5 header codewords (:632)
             for (uint32_t i = 0; i < rem; i++) sh.cw[i] = sh.cw[i + 5u];
@@ -623,7 +616,6 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         S.state = kDetect; S.pos = job.start; S.cr = job.cr_prev; S.has_crc = P.ctor_crc;
         S.phdr[1] = (uint8_t)((P.ctor_cr << 5) | (P.ctor_crc << 4));
         S.att_start = job.start; S.att_trig = -1; S.att_hdr = -1; S.att_cr_prev = job.cr_prev;
-        S.cr_guess = (phase == 0) ? job.cr_is_guess : 0u; // (the tail probe starts from the job's own end state: no guess)
         if (job.start_at_header && phase == 0) { S.state = kDecodeHeader; S.in_attempt = 1; S.att_trig = job.start; S.att_hdr = job.start; } // (acquired elsewhere)
         if (phase == 0) W.stats = W2Stats{};
         W.stats.prev_state = -1;

@@ -1256,12 +1256,6 @@ __device__ __forceinline__ bool w3_post_symbol(const DevParams &P, W2State &S, S
                 decode_header_bytes(sh, S.n_cw, 1, hB);
                 const uint8_t *use = (S.cr >= 3u) ? hA : (S.cr >= 1u ? hB : h0);
                 S.att_ambig = (uint32_t)((hA[0] != hB[0]) || (hA[1] != hB[1]) || (hA[2] != hB[2]));
-                if (S.cr_guess && S.att_ambig) { // Job.cr_is_guess: the branch whose own header names a coding rate of its class (the stitch checks the choice)
-                    const uint32_t ca = hA[1] >> 5, cb = hB[1] >> 5;
-                    const bool okA = ca >= 3u, okB = cb == 1u || cb == 2u;
-                    if (okA != okB) { use = okA ? hA : hB; S.cr = okA ? 4u : 1u; S.att_cr_prev = S.cr; }
-                }
-                S.cr_guess = 0;
                 S.phdr[0] = use[0]; S.phdr[1] = use[1]; S.phdr[2] = use[2];
                 const uint32_t rem = S.n_cw > 5u ? S.n_cw - 5u : 0u; // erase the 5 header codewords (:632)
                 for (uint32_t i = 0; i < rem; i++) sh.cw[i] = sh.cw[i + 5u];
@@ -1375,7 +1369,8 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
         S.state = kDetect; S.pos = job.start; S.cr = job.cr_prev; S.has_crc = P.ctor_crc;
         S.phdr[1] = (uint8_t)((P.ctor_cr << 5) | (P.ctor_crc << 4));
         S.att_start = job.start; S.att_trig = -1; S.att_hdr = -1; S.att_cr_prev = job.cr_prev;
-        S.cr_guess = (phase == 0) ? job.cr_is_guess : 0u; // (the tail probe starts from the job's own end state: no guess)
+        sh.n_sfd = 0u;
+        if (job.start_at_header && phase == 0 && rec_cap > 0u) recs[0].n_sfd = 0u;
         if (job.start_at_header && phase == 0) { S.state = kDecodeHeader; S.in_attempt = 1; S.att_trig = job.start; S.att_hdr = job.start; } // (acquired elsewhere)
         if (phase == 0) ws.stats = W2Stats{};
         ws.stats.prev_state = -1;
@@ -1432,11 +1427,13 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                         St.corr_fails = 0u;
                         St.state = kSync;
                         St.in_attempt = 1;
-                        St.att_trig = St.pos; St.att_hdr = -1; St.att_cr_prev = St.cr; St.att_ambig = 0; St.n_sym = 0; St.n_sfd = 0;
+                        St.att_trig = St.pos; St.att_hdr = -1; St.att_cr_prev = St.cr; St.att_ambig = 0; St.n_sym = 0;
+                        sh.n_sfd = 0u;
+                        if (St.n_att < rec_cap) recs[St.n_att].n_sfd = 0u;
                     } else {
                         consumed = (int32_t)sps;
                     }
-                    w2_end_step(St, job, C, recs, trace, kDetect, consumed, -1, 0, autocorr, t_start);
+                    w2_end_step<true>(St, job, C, recs, trace, kDetect, consumed, -1, 0, autocorr, t_start);
                     if (St.done) break;
                 }
                 W2Plan np;
@@ -1453,7 +1450,7 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                 W2State St = S;
                 const int32_t consumed = (so.bi == 0x7fffffff) ? 0 : so.bi; // `int i = 0` stays when nothing exceeds 0 (:771)
                 St.state = kFindSfd;
-                w2_end_step(St, job, C, recs, trace, kSync, consumed, -1, 0, so.bv, t_start);
+                w2_end_step<true>(St, job, C, recs, trace, kSync, consumed, -1, 0, so.bv, t_start);
                 W2Plan np;
                 plan_from(St, np);
                 next = np; S = St;
@@ -1472,12 +1469,14 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                     // a tail probe with Job.tail_stop_sfd has seen enough once it stands at the start of its SECOND FIND_SFD step: the first
                     // one's fine_sync(-1, 4 D) (:801-803) has pulled it onto the chirp boundary its successor's own attempt passes through,
                     // and (position, d_corr_fails) is all that :785-818 read - the stitch matches it against that attempt's record
-                    if (stop_sfd && St.n_sfd >= 1u) { St.stop_reason = 4; St.done = 1; break; }
-                    if (St.n_att < rec_cap && St.n_sfd < (uint32_t)kMaxSfdRec) { // the state this step starts in, for such a match
-                        recs[St.n_att].sfd_pos[St.n_sfd] = St.pos;
-                        recs[St.n_att].sfd_fails[St.n_sfd] = (uint8_t)St.corr_fails;
+                    const uint32_t nsf = sh.n_sfd; // (thread 0's own counter, in LDS: not part of the register-resident state)
+                    if (stop_sfd && nsf >= 1u) { St.stop_reason = 4; St.done = 1; break; }
+                    if (St.n_att < rec_cap && nsf < (uint32_t)kMaxSfdRec) { // the state this step starts in, for such a match
+                        recs[St.n_att].sfd_pos[nsf] = St.pos;
+                        recs[St.n_att].sfd_fails[nsf] = (uint8_t)St.corr_fails;
+                        recs[St.n_att].n_sfd = nsf + 1u;
                     }
-                    St.n_sfd++;
+                    sh.n_sfd = nsf + 1u;
                     float c = fo.c[0];
                     int32_t fs = fo.fine[0];
 #pragma unroll
@@ -1490,7 +1489,7 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                         else St.corr_fails++;
                         if (St.corr_fails > 4u) St.state = kDetect; // :808-809
                     }
-                    w2_end_step(St, job, C, recs, trace, kFindSfd, (int32_t)sps + fine, -1, fine, c, t_start); // :816
+                    w2_end_step<true>(St, job, C, recs, trace, kFindSfd, (int32_t)sps + fine, -1, fine, c, t_start); // :816
                     if (St.done || fine != 0) break; // (fine != 0: the later windows started at the wrong sample)
                 }
                 // PAUSE (:820-824) looks at no sample: the step is taken here, behind its own loop-top checks, instead of in a
@@ -1499,7 +1498,7 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                     St.state = kDecodeHeader;
                     const int32_t consumed = (int32_t)(sps + P.delay_after_sync);
                     St.att_hdr = St.pos + consumed;
-                    w2_end_step(St, job, C, recs, trace, kPause, consumed, -1, 0, 0.0f, t_start);
+                    w2_end_step<true>(St, job, C, recs, trace, kPause, consumed, -1, 0, 0.0f, t_start);
                 }
                 W2Plan np;
                 plan_from(St, np);
@@ -1514,7 +1513,7 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                 St.state = kDecodeHeader;
                 const int32_t consumed = (int32_t)(sps + P.delay_after_sync);
                 St.att_hdr = St.pos + consumed;
-                w2_end_step(St, job, C, recs, trace, kPause, consumed, -1, 0, 0.0f, t_start);
+                w2_end_step<true>(St, job, C, recs, trace, kPause, consumed, -1, 0, 0.0f, t_start);
                 W2Plan np;
                 plan_from(St, np);
                 next = np; S = St;
@@ -1536,7 +1535,7 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                 St.state = kDetect;
                 St.n_words = 0; St.n_cw = 0;
                 St.fin_pending = 0;
-                w2_end_step(St, job, C, recs, trace, St.fin_st, St.fin_consumed, St.fin_bin, St.fin_fine, 0.0f, t_start);
+                w2_end_step<true>(St, job, C, recs, trace, St.fin_st, St.fin_consumed, St.fin_bin, St.fin_fine, 0.0f, t_start);
                 W2Plan np;
                 plan_from(St, np);
                 next = np; S = St;
@@ -1613,7 +1612,7 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                         St.fin_pending = 1; St.fin_st = st_w; St.fin_consumed = (int32_t)sps + fine; St.fin_bin = step_bin; St.fin_fine = fine;
                         break;
                     }
-                    w2_end_step(St, job, C, recs, trace, st_w, (int32_t)sps + fine, step_bin, fine, 0.0f, t_start); // :856,:883
+                    w2_end_step<true>(St, job, C, recs, trace, st_w, (int32_t)sps + fine, step_bin, fine, 0.0f, t_start); // :856,:883
                     if (St.done || fine != 0) break; // (fine != 0: the later windows started at the wrong sample)
                 }
 #if LORA_W3_REPLAY_STATS > 1
@@ -1641,7 +1640,7 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
             r.npush = S.npush;
             for (int i = 0; i < 4; i++) r.push_tail[i] = S.push_tail[i];
             r.cr_prev = S.att_cr_prev; r.hdr_ambig = S.att_ambig; r.n_symbols = S.n_sym; r.frame_len = 0;
-            uint32_t ns = S.n_sfd < (uint32_t)kMaxSfdRec ? S.n_sfd : (uint32_t)kMaxSfdRec;
+            uint32_t ns = sh.n_sfd < (uint32_t)kMaxSfdRec ? sh.n_sfd : (uint32_t)kMaxSfdRec;
             if (S.stop_reason == 4 && ns < (uint32_t)kMaxSfdRec) { r.sfd_pos[ns] = S.pos; r.sfd_fails[ns] = (uint8_t)S.corr_fails; ns++; } // the state the probe stopped in
             r.n_sfd = ns;
             if (S.stop_reason == 4) S.stop_reason = 3; // (reported like any other probe stop)

@@ -247,3 +247,20 @@ def test_early_stopping_probes_with_noise_and_stale_cr(sim, oracle_mod, sf, cr, 
         assert got == want and gpos == wpos
     got, gpos, stats = sim(st.iq, sf, seg=0, slots=8, plan=True, early=True)
     assert got == want and gpos == wpos
+
+
+def test_wrong_header_branch_jobs_are_rerun_in_one_batch(sim, oracle_mod):
+    """CR 4/5 traffic under noise into a decoder constructed with CR 4: every later segment's job guesses Hamming class 2 for its first header
+    where the true d_phdr.cr (the predecessor's header's) is of class 1, and with bit errors in the header the two decodes disagree.  Those jobs
+    are run again TOGETHER with the value their predecessor's tail probe reported (decode_end, round 1b) instead of one serial launch each:
+    segmented == serial, and the serial fall-backs stay a handful."""
+    cfg = synth.TxConfig(sf=8, cr=1)
+    rng = np.random.default_rng(321)
+    payloads = [bytes(rng.integers(0, 256, int(rng.integers(6, 24)), dtype=np.uint8)) for _ in range(40)]
+    st = synth.build_stream(payloads, cfg, rng=rng, noise_sigma=10 ** (-27 / 20.0))
+    want, wpos = _serial(oracle_mod, st.iq, 8, ctor_cr=4, demod=0)
+    for early in (False, True):
+        got, gpos, stats = sim(st.iq, 8, ctor_cr=4, demod=0, seg=0, slots=20, plan=True, early=early)
+        assert got == want and gpos == wpos, early
+        assert stats["planned"] == 1 and stats["slow"] <= 6, stats
+    assert len(want) >= 30
