@@ -1181,7 +1181,9 @@ struct lora_hip_mux {
     size_t batch = 0, tailcap = 0, region = 0;
     DevBuf<float2> dbuf[2];
     int cur = 0;
-    struct Chan { size_t fill = 0, tail_len = 0; uint32_t cr = 0; PwrState pwr; int64_t host_base = 0; std::vector<float2> ahead; size_t fl_off = 0, fl_len = 0; bool in_pass = false; };
+    struct Chan { size_t fill = 0, tail_len = 0; uint32_t cr = 0; PwrState pwr; int64_t host_base = 0; std::vector<float2> ahead; size_t fl_off = 0, fl_len = 0; bool in_pass = false;
+                  size_t ahead_off = 0; // items of `ahead` already uploaded (a read offset: the front is erased only once it is more than half of the vector)
+                  size_t ahead_left() const { return ahead.size() - ahead_off; } };
     std::vector<Chan> ch;
     hipStream_t copy_st = nullptr, comp_st = nullptr;
     hipEvent_t up_ev = nullptr, tail_ev = nullptr;
@@ -1343,14 +1345,29 @@ static lora_hip_status mux_rotate(lora_hip_mux *m, bool by_latency)
                                                hipMemcpyDeviceToDevice, m->copy_st));
             C.tail_len = len; C.fill = 0;
         } else { C.fill = 0; C.tail_len = 0; }
-        if (!C.ahead.empty()) { // what the channel delivered beyond its chunk
-            const size_t k = std::min(C.ahead.size(), m->batch);
-            s = mux_upload(m, c, C.ahead.data(), k);
-            if (s != LORA_HIP_OK) return s;
-            MUX_TRY(m, hipStreamSynchronize(m->copy_st)); // (the vector is about to change)
-            C.ahead.erase(C.ahead.begin(), C.ahead.begin() + (ptrdiff_t)k);
-            if (!m->have_first) { m->have_first = true; m->t_first = std::chrono::steady_clock::now(); }
-        }
+    }
+    // what the channels delivered beyond their chunks: every upload is queued first, the copy stream is waited for ONCE, and only then do the
+    // host vectors change (one synchronisation and one front erase per channel and rotation used to serialise n_channels waits and ~32 MB memmoves)
+    std::vector<size_t> took(m->n, 0);
+    bool any_up = false;
+    for (uint32_t c = 0; c < m->n; c++) {
+        lora_hip_mux::Chan &C = m->ch[c];
+        if (C.ahead_left() == 0) continue;
+        took[c] = std::min(C.ahead_left(), m->batch);
+        s = mux_upload(m, c, C.ahead.data() + C.ahead_off, took[c]);
+        if (s != LORA_HIP_OK) return s;
+        any_up = true;
+    }
+    if (any_up) {
+        MUX_TRY(m, hipStreamSynchronize(m->copy_st)); // (the vectors are about to change)
+        for (uint32_t c = 0; c < m->n; c++)
+            if (took[c]) {
+                lora_hip_mux::Chan &C = m->ch[c];
+                C.ahead_off += took[c];
+                if (C.ahead_off == C.ahead.size()) { C.ahead.clear(); C.ahead_off = 0; }
+                else if (C.ahead_off > C.ahead.size() / 2) { C.ahead.erase(C.ahead.begin(), C.ahead.begin() + (ptrdiff_t)C.ahead_off); C.ahead_off = 0; }
+            }
+        if (!m->have_first) { m->have_first = true; m->t_first = std::chrono::steady_clock::now(); }
     }
     return LORA_HIP_OK;
 }
@@ -1370,7 +1387,7 @@ lora_hip_status lora_hip_mux_work(lora_hip_mux_t *m, uint32_t channel, const flo
     lora_hip_mux::Chan &C = m->ch[channel];
     const float2 *src = reinterpret_cast<const float2 *>(iq);
     size_t left = n_items;
-    if (left && C.ahead.empty()) {
+    if (left && C.ahead_left() == 0) {
         const size_t k = std::min(left, m->batch - C.fill);
         if (k) {
             s = mux_upload(m, channel, src, k);
@@ -1385,7 +1402,7 @@ lora_hip_status lora_hip_mux_work(lora_hip_mux_t *m, uint32_t channel, const flo
                // has reached max_ahead (a silent or stalled neighbour must not let it grow without bound when the latency bound is off:
                // the others then go into the pass with what they hold)
         bool all_full = true, far_ahead = false;
-        for (const auto &c : m->ch) { all_full = all_full && c.fill == m->batch; far_ahead = far_ahead || (c.fill == m->batch && c.ahead.size() >= m->max_ahead); }
+        for (const auto &c : m->ch) { all_full = all_full && c.fill == m->batch; far_ahead = far_ahead || (c.fill == m->batch && c.ahead_left() >= m->max_ahead); }
         if (!all_full && !far_ahead) break;
         const uint64_t before = m->passes;
         s = mux_rotate(m, false);
@@ -1411,7 +1428,7 @@ lora_hip_status lora_hip_mux_flush(lora_hip_mux_t *m)
         s = mux_rotate(m, false);
         if (s != LORA_HIP_OK) return s;
         bool more = false;
-        for (const auto &c : m->ch) more = more || !c.ahead.empty();
+        for (const auto &c : m->ch) more = more || c.ahead_left() != 0;
         if (!more && m->passes == before) break; // nothing launched and nothing left to upload: what remains is shorter than a work() call (:91)
         if (!more) { // the last uploads are in: one more pass takes them
             bool any = false;

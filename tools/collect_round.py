@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Collects what tools/r03_final.sh left under gpurun_out/ into profiles/r03_* (after tools/profile_summary.py <tag> r03 for every tag) and prints the table."""
+"""Collects what tools/r04_final.sh (profile_all.sh) left under gpurun_out/ into profiles/<round>_* (after tools/profile_summary.py <tag> <round> for every
+tag) and prints the table.  usage: tools/collect_round.py r04"""
 import json, os, shutil, sys
+RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 out={"command":"tools/pmc_walker.sh sq_sf7 ; tools/pmc_walker.sh sq_sf9 --config 3 --sf 9 ; tools/pmc_walker.sh sq_sf12 --config 3 --sf 12 (six rocprofv3 --kernel-trace --pmc passes each, bench.py --steps 3 --warmup 1 --no-cpu-baseline; tools/pmc_summary.py), part of tools/profile_all.sh on the round's final sources",
@@ -18,14 +20,14 @@ for tag in ("sq_sf7","sq_sf9","sq_sf12"):
             "valu_wave_instructions_per_pass": c["SQ_INSTS_VALU"],
             "lds_bank_conflict_fraction (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE)": round(c["SQ_LDS_BANK_CONFLICT"]/max(c["SQ_LDS_IDX_ACTIVE"],1),4),
             "mfma_ops": c.get("SQ_INSTS_VALU_MFMA_MOPS_F32",0)}}
-json.dump(out,open("profiles/r03_sq_counters.json","w"),indent=1)
-for a,b in (("default_line","r03_default_bench_line"),("default_grad_line","r03_default_grad_bench_line"),("work_line","r03_work_bench_line"),("cfg4_line","r03_cfg4_bench_line"),("cfg4_8s_line","r03_cfg4_8s_bench_line"),("cfg4_2s_line","r03_cfg4_2s_bench_line"),("torchrun1_line","r03_torchrun_world1_bench_line"),("streams1_line","r03_streams1_bench_line"),("mux_cfg4_2s_line","r03_mux_cfg4_2s_bench_line"),("split1_line","r03_split_world1_bench_line")):
-    shutil.copy("gpurun_out/%s.json"%a,"profiles/%s.json"%b)
-for tag in ["sf7","sf8","sf9","sf10","sf11","sf12","sf7_grad","sf9_grad","sf12_grad"]:
-    line=json.load(open("profiles/r03_%s_bench_line.json"%tag)); pmc=json.load(open("profiles/r03_%s_pmc_traffic.json"%tag))
+json.dump(out,open("profiles/%s_sq_counters.json" % RND,"w"),indent=1)
+for a,b in (("default_line","default_bench_line"),("default_grad_line","default_grad_bench_line"),("work_line","work_bench_line"),("cfg4_line","cfg4_bench_line"),("cfg4_8s_line","cfg4_8s_bench_line"),("cfg4_2s_line","cfg4_2s_bench_line"),("torchrun1_line","torchrun_world1_bench_line"),("streams1_line","streams1_bench_line"),("mux_cfg4_2s_line","mux_cfg4_2s_bench_line"),("split1_line","split_world1_bench_line"),("default_fast_sync_line","default_fast_sync_bench_line")):
+    shutil.copy("gpurun_out/%s.json"%a,"profiles/%s_%s.json"%(RND,b))
+for tag in ["sf7","sf8","sf9","sf10","sf11","sf12","sf9_1024","sf7_grad","sf9_grad","sf12_grad"]:
+    line=json.load(open("profiles/%s_%s_bench_line.json"%(RND,tag))); pmc=json.load(open("profiles/%s_%s_pmc_traffic.json"%(RND,tag)))
     assert pmc["source_hash"]==bench.source_hash(), tag
     r=line["roofline"]; n=line["config"]["items_per_gpu"]; rp=pmc["rocprof_walker_avg_ms_per_pass"]
     print("%-10s %-26s value %7.1f Gs/s  kernel %.4f ms frac %.4f | rocprof %.4f ms frac %.4f | traffic %.2fx write %.3f GB | cpu %.1f (ref %.1f) | grad2 %s"%(tag, r["kernel"], line["value"]/1e3, r["kernel_ms_per_pass"], r["frac"], rp, 8*n/(rp*1e-3)/1e9/8000, pmc["traffic_over_algorithmic"], pmc["write_bytes_per_pass_raw"]/1e9, line["cpu_baseline"]["value"], (line["cpu_baseline"].get("reference_build") or {}).get("value",0), (line.get("reference_default_demodulator") or {}).get("frac")))
-for f in ["default_line","default_grad_line","work_line","cfg4_line","cfg4_8s_line","cfg4_2s_line","torchrun1_line","streams1_line","mux_cfg4_2s_line","split1_line"]:
+for f in ["default_line","default_fast_sync_line","default_grad_line","work_line","cfg4_line","cfg4_8s_line","cfg4_2s_line","torchrun1_line","streams1_line","mux_cfg4_2s_line","split1_line"]:
     d=json.load(open("gpurun_out/%s.json"%f)); print(f, d["value"], d.get("roofline",{}).get("frac"), d.get("roofline",{}).get("frac_rocprof"), d["config"].get("bit_exact_vs_expected"), d["config"].get("process_group"), (d.get("reference_default_demodulator") or {}).get("frac"), (d.get("one_handle_per_channel") or {}).get("value"))
 for k,v in out["kernels"].items(): print(k, list(v["derived"].values())[:4])

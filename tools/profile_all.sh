@@ -11,11 +11,13 @@ PROFILE_STEPS=8 tools/profile_round.sh sf9 --config 3 --sf 9
 PROFILE_STEPS=8 tools/profile_round.sh sf10 --config 3 --sf 10
 PROFILE_STEPS=6 tools/profile_round.sh sf11 --config 3 --sf 11
 PROFILE_STEPS=4 tools/profile_round.sh sf12 --config 3 --sf 12
+PROFILE_STEPS=6 tools/profile_round.sh sf9_1024 --config 3 --sf 9 --packets 1024   # more jobs than CUs: the half-size workgroups (walker3_kernel_sf9_half)
 # the reference's shipped demodulator (gradient, decoder_impl.cc:499) on the same workloads: its own kernels
 tools/profile_round.sh sf7_grad --demod 0
 PROFILE_STEPS=8 tools/profile_round.sh sf9_grad --config 3 --sf 9 --demod 0
 PROFILE_STEPS=4 tools/profile_round.sh sf12_grad --config 3 --sf 12 --demod 0
 python bench.py 2>/dev/null | tail -1 > gpurun_out/default_line.json
+LORA_HIP_STRICT_SYNC=0 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/default_fast_sync_line.json   # the closed-form SYNC alone (LORA_HIP_FLAG_FAST_SYNC): what the exact re-evaluation costs
 python bench.py --path work 2>/dev/null | tail -1 > gpurun_out/work_line.json
 python bench.py --config 4 --steps 30 --warmup 5 2>/dev/null | tail -1 > gpurun_out/cfg4_line.json
 python bench.py --config 4 --seconds 8 --steps 30 --warmup 5 2>/dev/null | tail -1 > gpurun_out/cfg4_8s_line.json
@@ -28,7 +30,6 @@ tools/pmc_walker.sh sq_sf9 --config 3 --sf 9
 tools/pmc_walker.sh sq_sf12 --config 3 --sf 12
 for t in sq_sf7 sq_sf9 sq_sf12; do python tools/pmc_summary.py gpurun_out/$t > gpurun_out/$t.json; rm -rf gpurun_out/$t; done
 python bench.py --path mux --config 4 --seconds 2 --steps 5 2>/dev/null | tail -1 > gpurun_out/mux_cfg4_2s_line.json
-python bench.py --config 3 --sf 9 --packets 1024 --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/sf9_1024_line.json
 python bench.py --split --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/split1_line.json
 } > gpurun_out/profile_all.log 2>&1
 # keep what travels back small: the per-dispatch traces are not needed once summarised... (kernel_stats + counter_collection csv only)
