@@ -18,12 +18,13 @@ DEMOD_GRAD, DEMOD_FFT, DEMOD_FFT_COMPAT = 0, 1, 2
 FLAG_TRACE = 1
 FLAG_PIN_HOST = 2
 FLAG_FAST_SYNC = 4  # keep SYNC's closed-form maximum (no exact re-evaluation of near-tied shifts)
+FLAG_NO_DECOUPLED = 8  # never run a pass decoupled (header-only jobs + the symbol-parallel payload pass)
 
 EXPORTS = [
     "lora_hip_abi_version", "lora_hip_strerror", "lora_hip_last_error", "lora_hip_create", "lora_hip_destroy",
     "lora_hip_get_geometry", "lora_hip_set_sf", "lora_hip_set_samp_rate", "lora_hip_work", "lora_hip_flush",
     "lora_hip_decode_device", "lora_hip_frames_available", "lora_hip_poll_frame", "lora_hip_drain_frames", "lora_hip_drain_slots", "lora_hip_demod_symbols_device", "lora_hip_demod_symbols_ex_device",
-    "lora_hip_last_timing", "lora_hip_last_plan", "lora_hip_gap_starts_device", "lora_hip_decode_device_begin", "lora_hip_decode_device_end", "lora_hip_decode_device_prepass", "lora_hip_trace", "lora_hip_trace_clear", "lora_hip_check_frame", "lora_hip_estimate_cfo_device", "lora_hip_ref_ifreq_device",
+    "lora_hip_last_timing", "lora_hip_last_plan", "lora_hip_last_payload_pass", "lora_hip_gap_starts_device", "lora_hip_decode_device_begin", "lora_hip_decode_device_end", "lora_hip_decode_device_prepass", "lora_hip_trace", "lora_hip_trace_clear", "lora_hip_check_frame", "lora_hip_estimate_cfo_device", "lora_hip_ref_ifreq_device",
     "lora_hip_set_stream_latency", "lora_hip_stream_info", "lora_hip_walker_kernel_name", "lora_hip_window_stats_device", "lora_hip_detect_preambles_device", "lora_hip_decode_at_headers_device",
     "lora_hip_mux_create", "lora_hip_mux_destroy", "lora_hip_mux_work", "lora_hip_mux_flush", "lora_hip_mux_set_latency", "lora_hip_mux_set_max_ahead", "lora_hip_mux_frames_available",
     "lora_hip_mux_poll_frame", "lora_hip_mux_passes", "lora_hip_mux_last_error",
@@ -139,6 +140,7 @@ def load():
     L.lora_hip_demod_symbols_ex_device.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int, vp, vp, vp]
     L.lora_hip_last_timing.argtypes = [vp, C.POINTER(Timing)]
     L.lora_hip_last_plan.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.lora_hip_last_payload_pass.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
     L.lora_hip_decode_device_begin.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_uint32, vp, C.c_uint32]
     L.lora_hip_decode_device_end.argtypes = [vp]
     L.lora_hip_decode_device_prepass.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_uint32, vp, C.c_uint32]
@@ -424,6 +426,12 @@ class Handle:
         b, n = C.c_uint32(0), C.c_uint32(0)
         self._check(self.L.lora_hip_last_plan(self.h, C.byref(b), C.byref(n)))
         return bool(b.value), int(n.value)
+
+    def payload_pass(self):
+        """dict(packets, rerun, symbols, ms) of the last pass's payload pass (all zero unless it ran decoupled): lora_hip_last_payload_pass."""
+        a, b, c, m = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_float(0)
+        self._check(self.L.lora_hip_last_payload_pass(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(m)))
+        return dict(packets=int(a.value), rerun=int(b.value), symbols=int(c.value), ms=float(m.value))
 
     def trace(self):
         p = C.POINTER(Step)()

@@ -30,7 +30,16 @@ enum AttemptStatus : uint32_t {
     kAttemptLostSync = 2,    // d_corr_fails > 4 -> back to DETECT (decoder_impl.cc:808-813)
     kAttemptOutOfData = 3,   // fewer than 2*sps items left mid-attempt (scheduler stops calling work())
     kAttemptAtHeader = 4,    // probe mode: stopped on entering DECODE_HEADER
-    kAttemptAtSfd = 5        // tail probe with Job.tail_stop_sfd: stopped behind its first FIND_SFD step; sfd_pos / sfd_fails[n_sfd - 1] = the state it stopped in
+    kAttemptAtSfd = 5,       // tail probe with Job.tail_stop_sfd: stopped behind its first FIND_SFD step; sfd_pos / sfd_fails[n_sfd - 1] = the state it stopped in
+    kAttemptHeaderOnly = 6   // LaunchCfg.skip_payload: header decoded, the payload symbols left to the symbol-parallel pass (SkippedPayload in frame[]); end_pos assumes
+                             // that none of them moves the symbol clock
+};
+// what a walker launched with LaunchCfg.skip_payload leaves in AttemptRec.frame (frame_len = sizeof) instead of a frame
+struct SkippedPayload {
+    uint8_t  phdr[3];          // d_phdr as parsed (:831-835)
+    uint8_t  n_left;           // codewords of the header block behind the five header ones (:632): sf - 7
+    uint8_t  left[8];
+    int32_t  payload_symbols;  // :842-847
 };
 constexpr int kMaxSfdRec = 12; // FIND_SFD steps of an attempt whose entry state is recorded (a preamble of 8 + sync word + SFD: at most 11)
 
@@ -146,6 +155,8 @@ struct LaunchCfg {
     uint32_t trace_cap;
     uint32_t n_jobs;
     uint32_t *balance;       // kBalanceWords words, zero-initialised once (walker2: progress exchange between the workgroups of a CU), or nullptr
+    uint32_t skip_payload;   // 1: the launch runs the kernels' header-only variant (walker3): a packet's attempt ends behind its header (kAttemptHeaderOnly) and the
+                             // job goes on in DETECT where the payload would end if no symbol moved the clock; the payload pass (launch_payload_pass) does the rest
 };
 constexpr uint32_t kBalanceCus = 2048;                 // (XCC_ID, SE, SH, CU) flattened
 constexpr uint32_t kBalanceWords = 3u * kBalanceCus;   // per CU: remaining work of its two workgroups, claim counter
@@ -162,8 +173,27 @@ int launch_envelope(const float2 *iq, const EnvStream *streams /* host table; fi
 int launch_walker(const DevParams &p, const LaunchCfg &c, void *stream);
 const char *walker_kernel_name(const DevParams &p);                        // the kernel launch_walker picks for this configuration
 int launch_demod_symbols(const DevParams &p, const float2 *iq, const int64_t *d_offsets, uint32_t n,
-                         int demod, uint32_t *d_bins, int32_t *d_fine, float *scratch, void *stream);
+                         int demod, uint32_t *d_bins, int32_t *d_fine, float *scratch, void *stream,
+                         const uint32_t *d_out_idx = nullptr /* walker3 kernels only: result s goes to bins / fine [d_out_idx[s]] */);
 int launch_detect_windows(const DevParams &p, const float2 *iq, const int64_t *d_offsets, uint32_t n, void *d_out /* 24 B per window */, void *stream); // N4: lora_detect.inc.hip
+// The payload pass of a launch with LaunchCfg.skip_payload: every payload symbol of every packet demodulated on its own (launch_demod_symbols over
+// the zero-drift positions), then one workgroup per packet takes the symbols through demodulate()'s integer chain (:506-529, :866-881).
+struct PayloadDesc {         // one packet (host-written)
+    uint32_t first;          // index of its first symbol in bins / fine
+    uint32_t n_walk;         // symbols DECODE_PAYLOAD demodulates: payload_symbols, or 1 when that is <= 0 (:866-870 run behind the first symbol)
+    uint32_t n_fixed;        // symbols [0, n_fixed) were read at their true positions in an earlier round of the pass: their d_fine_sync is already accounted for
+    uint32_t pad;
+    SkippedPayload sk;
+};
+struct PayloadOut {          // (device-written)
+    uint32_t first_moved;    // first symbol k >= n_fixed with d_fine_sync != 0 behind it (the symbols after it were read `moved_by` samples off), n_walk: none
+    int32_t  moved_by;
+    uint32_t frame_len;      // the frame as the bins stand: the serial decoder's once first_moved >= n_walk - 1
+    uint32_t pad;
+    uint8_t  frame[kMaxFrame + 4];
+};
+int launch_payload_chain(const DevParams &p, const uint32_t *d_bins, const int32_t *d_fine, const PayloadDesc *descs, PayloadOut *outs, uint32_t n_packets, void *stream);
+bool walker_has_skip_variant(const DevParams &p);                           // LaunchCfg.skip_payload is honoured (walker3, explicit header)
 int launch_ref_ifreq(const float2 *x, uint32_t n, float *d_arg, float *d_ifreq, void *stream); // diagnostics: the strict SYNC path's atan2f / ifreq
 int launch_cfo(const DevParams &p, const float2 *iq, const int64_t *d_offsets, uint32_t n, int mode, float *d_out, void *stream); // N4: explicit CFO estimate
 bool walker3_covers(uint32_t sf);                                          // SF9-12: lora_walker3.inc.hip
@@ -174,6 +204,6 @@ void build_wave_tables(uint32_t sf, const float2 *down, float *out);
 uint32_t walker_lds_bytes(const DevParams &p);
 uint32_t walker_resident_slots(const DevParams &p);
 uint32_t walker_resident_slots_full(const DevParams &p);                  // second, smaller slot count where the kernel exists as half- and full-size workgroups (0: none)
-const char *walker_kernel_name_for(const DevParams &p, uint32_t n_jobs);   // ... and the variant a launch of n_jobs jobs runs
+const char *walker_kernel_name_for(const DevParams &p, uint32_t n_jobs, bool skip = false); // ... and the variant a launch of n_jobs jobs runs (skip: LaunchCfg.skip_payload)
 
 } // namespace lora_hip

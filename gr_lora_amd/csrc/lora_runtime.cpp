@@ -188,6 +188,16 @@ struct lora_hip_decoder {
     uint32_t resident_slots_alt = ~0u; // slots of the full-size kernel where a half-size variant exists (walker3 SF9 / SF10), else 0
     uint32_t eager_recs = 4;
     uint32_t last_plan_burst = 0, last_plan_segments = 0;
+    // decoupled passes (lora_stitch.hpp payload_round): header-only segment jobs + the payload pass
+    int decoupled_policy = -1;         // -1 auto (few jobs for the device, few re-runs lately), 0 never, 1 whenever the kernels allow it
+    bool launch_skip = false;          // the next launches run the header-only kernel variant (LaunchCfg.skip_payload)
+    uint32_t dec_backoff = 0;          // auto: passes to sit out after one whose packets mostly had to be run again
+    uint32_t last_payload_packets = 0, last_payload_rerun = 0, last_payload_symbols = 0;
+    float last_payload_ms = 0.0f;
+    PinnedBuf<int64_t> p_pay_off;
+    PinnedBuf<PayloadDesc> p_pay_desc;
+    PinnedBuf<PayloadOut> p_pay_out;
+    DevBuf<int32_t> d_fine;
 };
 
 namespace {
@@ -327,6 +337,8 @@ lora_hip_status build_tables(lora_hip_decoder *h)
         // near-tied SYNC shifts decided by the reference's own float sums (lora_strict_sync.inc.hip): on unless the caller opts out
         P.strict_sync = (c.flags & LORA_HIP_FLAG_FAST_SYNC) ? 0u : 1u;
         if (const char *e = getenv("LORA_HIP_STRICT_SYNC")) P.strict_sync = (e[0] != '0') ? 1u : 0u; // (A/B runs)
+        h->decoupled_policy = (c.flags & LORA_HIP_FLAG_NO_DECOUPLED) ? 0 : -1;
+        if (const char *e = getenv("LORA_HIP_DECOUPLED")) h->decoupled_policy = e[0] == '0' ? 0 : e[0] == '1' ? 1 : -1; // 0 never, 1 always, anything else: auto
     }
     for (uint32_t t = 0; t < N / 2u; t++) {
         const double a = -2.0 * M_PI * (double)t / (double)N;
@@ -421,8 +433,9 @@ lora_hip_status run_jobs_begin(lora_hip_decoder *h, const float2 *d_iq, const st
         HIP_TRY(h, hipMemsetAsync(h->d_balance.p, 0, kBalanceWords * sizeof(uint32_t), st));
     }
     c.balance = no_balance ? nullptr : h->d_balance.p;
+    c.skip_payload = h->launch_skip ? 1u : 0u;
     HIP_TRY(h, hipEventRecord(h->ev0, st));
-    if (nj >= h->last_kernel_jobs) { h->last_kernel = walker_kernel_name_for(h->P, nj); h->last_kernel_jobs = nj; } // (the pass's main launch: probe and fix-up launches are smaller)
+    if (nj >= h->last_kernel_jobs) { h->last_kernel = walker_kernel_name_for(h->P, nj, h->launch_skip); h->last_kernel_jobs = nj; } // (the pass's main launch: probe and fix-up launches are smaller)
     if (launch_walker(h->P, c, st) != 0) return fail(h, LORA_HIP_ERR_HIP, "walker launch failed: %s", hipGetErrorString(hipGetLastError()));
     HIP_TRY(h, hipEventRecord(h->ev1, st));
     if (!direct) {
@@ -661,6 +674,62 @@ lora_hip_status quiet_edges(lora_hip_decoder *h, const float2 *d_iq, const std::
     return quiet_edges_collect(h, edges);
 }
 
+// The payload pass of a decoupled pass (lora_stitch.hpp payload_round): every payload symbol of every header-only packet demodulated at its
+// zero-drift position by the symbol-level kernels - all symbols of all packets in one launch, whatever CU is free - then one small workgroup per
+// packet for the integer chain (payload_chain_kernel).  Offsets go up in one copy; descriptors are read from and results written to page-locked
+// host memory directly, as the walkers' jobs and records are: one event wait, no copy-back.
+lora_hip_status run_payload_pass(lora_hip_decoder *h, const float2 *d_iq, std::vector<PayloadReq> &reqs, hipStream_t st)
+{
+    const int64_t sps = (int64_t)h->P.sps;
+    size_t n_sym = 0, n_pk = 0;
+    for (const PayloadReq &q : reqs) {
+        const bool fits = q.start >= 0 && q.start + ((int64_t)q.n_walk + 1) * sps <= (int64_t)q.stream_len; // every symbol passes the loop-top check (:91)
+        if (fits) { n_sym += q.n_walk; n_pk++; }
+    }
+    h->last_payload_symbols += (uint32_t)n_sym;
+    for (PayloadReq &q : reqs) { q.clean = 0; q.frame_len = 0; }
+    if (n_pk == 0) return LORA_HIP_OK;
+    HIP_TRY(h, h->p_pay_off.reserve(n_sym));
+    HIP_TRY(h, h->p_pay_desc.reserve(n_pk));
+    HIP_TRY(h, h->p_pay_out.reserve(n_pk));
+    HIP_TRY(h, h->d_offsets.reserve(n_sym));
+    HIP_TRY(h, h->d_bins.reserve(n_sym));
+    HIP_TRY(h, h->d_fine.reserve(n_sym));
+    size_t at = 0, pk = 0;
+    for (const PayloadReq &q : reqs) {
+        if (!(q.start >= 0 && q.start + ((int64_t)q.n_walk + 1) * sps <= (int64_t)q.stream_len)) continue;
+        PayloadDesc &d = h->p_pay_desc.p[pk];
+        d.first = (uint32_t)at; d.n_walk = q.n_walk; d.sk = q.sk;
+        for (uint32_t k = 0; k < q.n_walk; k++) h->p_pay_off.p[at++] = (int64_t)q.stream_off + q.start + (int64_t)k * sps;
+        h->p_pay_out.p[pk].clean = 0; h->p_pay_out.p[pk].frame_len = 0;
+        pk++;
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->d_offsets.p, h->p_pay_off.p, n_sym * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipEventRecord(h->ev0, st));
+    if (launch_demod_symbols(h->P, d_iq, h->d_offsets.p, (uint32_t)n_sym, (int)h->P.demod_mode, h->d_bins.p, h->d_fine.p, nullptr, st) != 0)
+        return fail(h, LORA_HIP_ERR_HIP, "payload pass: symbol launch failed: %s", hipGetErrorString(hipGetLastError()));
+    if (launch_payload_chain(h->P, h->d_bins.p, h->d_fine.p, h->p_pay_desc.p, h->p_pay_out.p, (uint32_t)n_pk, st) != 0)
+        return fail(h, LORA_HIP_ERR_HIP, "payload pass: chain launch failed: %s", hipGetErrorString(hipGetLastError()));
+    HIP_TRY(h, hipEventRecord(h->ev1, st));
+    HIP_TRY(h, hipEventRecord(h->ev_done, st));
+    HIP_TRY(h, hipEventSynchronize(h->ev_done));
+    pk = 0;
+    for (PayloadReq &q : reqs) {
+        if (!(q.start >= 0 && q.start + ((int64_t)q.n_walk + 1) * sps <= (int64_t)q.stream_len)) continue;
+        const PayloadOut &o = h->p_pay_out.p[pk++];
+        q.clean = (o.clean && o.frame_len >= 3u && o.frame_len <= (uint32_t)sizeof q.frame) ? 1u : 0u;
+        q.frame_len = q.clean ? o.frame_len : 0u;
+        if (q.clean) std::memcpy(q.frame, o.frame, o.frame_len);
+    }
+    float ms = 0.0f;
+    HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->last_payload_ms += ms;
+    h->timing.walker_ms += ms;       // (the pass's device time: the header-only walkers and the payload pass's two kernels)
+    h->timing.total_device_ms += ms;
+    h->timing.walker_launches += 2;
+    return LORA_HIP_OK;
+}
+
 // The device environment of the scheduler (lora_stitch.hpp): jobs are run by the walker kernels.
 struct DeviceEnv {
     lora_hip_decoder *h;
@@ -687,6 +756,28 @@ struct DeviceEnv {
     {
         static const bool off = getenv("LORA_HIP_NO_EARLY_PROBE") != nullptr;
         return !off && h->P.use_fast && h->P.decim == 8u && walker3_covers(h->P.sf);
+    }
+    // Decoupled pass: worth it when the launch leaves most of the device idle (a packet's symbols are a serial chain on one CU: the pass lasts as long
+    // as its longest packet, however few there are) and the traffic does not keep moving the symbol clock (such packets are run again whole).
+    bool decoupled(size_t n_jobs)
+    {
+        h->last_payload_packets = 0; h->last_payload_rerun = 0; h->last_payload_symbols = 0; h->last_payload_ms = 0.0f;
+        if (h->decoupled_policy == 0 || !walker_has_skip_variant(h->P) || tracing()) return false;
+        if (h->decoupled_policy == 1) return true;
+        if (h->dec_backoff) { h->dec_backoff--; return false; }
+        const uint32_t full = resident_slots_alt() ? resident_slots_alt() : resident_slots();
+        return 2u * (uint32_t)n_jobs <= full;
+    }
+    void set_skip_payload(bool on) { h->launch_skip = on; }
+    int run_payload(std::vector<PayloadReq> &reqs) { return ::run_payload_pass(h, d_iq, reqs, st) == LORA_HIP_OK ? 0 : -1; }
+    void count_payload(uint32_t packets, uint32_t rerun)
+    {
+        h->last_payload_packets += packets; h->last_payload_rerun += rerun;
+        if (rerun) h->timing.slow_path_relaunches++;
+        if (h->decoupled_policy < 0 && packets >= 4u && 4u * rerun > packets) h->dec_backoff = 32; // more than a quarter run again: the complete kernels for a while
+        static const bool dbg = getenv("LORA_HIP_DEBUG") != nullptr;
+        if (dbg) fprintf(stderr, "[lora_hip] payload pass: %u packets, %u symbols, %.3f ms; %u packet(s) moved the symbol clock or ran out of data: their jobs run again by the complete kernels\n",
+                         packets, h->last_payload_symbols, h->last_payload_ms, rerun);
     }
     RunOut &run_out(int which) { return h->run_out[which & 1]; }
     bool quiet_edges(const std::vector<StreamDesc> &streams, std::vector<std::vector<int64_t>> &edges)
@@ -796,6 +887,7 @@ void lora_hip_destroy(lora_hip_decoder_t *h)
     if (h->d_up_ifreq) (void)hipFree(h->d_up_ifreq);
     if (h->d_down_ifreq) (void)hipFree(h->d_down_ifreq);
     if (h->d_up_ifreq_v) (void)hipFree(h->d_up_ifreq_v);
+    h->p_pay_off.release(); h->p_pay_desc.release(); h->p_pay_out.release(); h->d_fine.release();
     h->d_jobs.release(); h->d_results.release(); h->d_recs.release(); h->d_scratch.release();
     h->d_trace.release(); h->d_staging.release(); h->d_offsets.release(); h->d_bins.release();
     stream_pipe_release(h);
@@ -1796,6 +1888,16 @@ lora_hip_status lora_hip_last_plan(const lora_hip_decoder_t *h, uint32_t *burst_
 }
 
 // (the variant the last pass launched where the kernel exists in two workgroup sizes - walker3 SF9 / SF10: *_half with more jobs than CUs)
+lora_hip_status lora_hip_last_payload_pass(const lora_hip_decoder_t *h, uint32_t *packets, uint32_t *rerun, uint32_t *symbols, float *ms)
+{
+    if (!h) return LORA_HIP_ERR_ARG;
+    if (packets) *packets = h->last_payload_packets;
+    if (rerun) *rerun = h->last_payload_rerun;
+    if (symbols) *symbols = h->last_payload_symbols;
+    if (ms) *ms = h->last_payload_ms;
+    return LORA_HIP_OK;
+}
+
 const char *lora_hip_walker_kernel_name(const lora_hip_decoder_t *h) { return h ? (h->last_kernel ? h->last_kernel : walker_kernel_name(h->P)) : ""; }
 
 lora_hip_status lora_hip_last_timing(const lora_hip_decoder_t *h, lora_hip_timing_t *t)

@@ -13,12 +13,16 @@
 //   void count_jobs(uint32_t), count_probes(uint32_t), count_slow_path(), note_plan(bool burst_aware, size_t n_segments);   double walker_ms();
 //   uint32_t resident_slots_alt();   (a second, smaller slot count when the kernel exists in two workgroup sizes; 0: none)
 //   bool early_probe();   (the jobs record their FIND_SFD entry states and their tail probes may stop behind the first one: Job.tail_stop_sfd)
+//   bool decoupled(size_t n_jobs);   (run this pass's segment jobs header-only and the payloads in the symbol-parallel payload pass)
+//   void set_skip_payload(bool);     (the launches that follow run the kernels' header-only variant, LaunchCfg.skip_payload)
+//   int  run_payload(std::vector<PayloadReq> &);   (0 = ok: clean / frame of every request filled in)   void count_payload(uint32_t packets, uint32_t moved, uint32_t rerun);
 #pragma once
 #include <algorithm>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <memory>
 #include <vector>
 
@@ -97,6 +101,40 @@ struct RunOut {
         return n < cap ? n : cap;
     }
 };
+
+// One packet of the payload pass: a kAttemptHeaderOnly record of a header-only job, and what the pass made of it.
+enum PayloadStatus : uint32_t {
+    kPayloadDecoded = 0,   // frame[] is the serial decoder's; its symbols moved the symbol clock by end_shift samples in all (0: the job's scan behind it stands)
+    kPayloadOutOfData = 1, // the data ends inside the payload (:91): the packet is pending
+    kPayloadUnresolved = 2 // the pass gave up (too many moves of the symbol clock): the complete kernels decode it again from its header
+};
+struct PayloadReq {
+    uint64_t stream_off, stream_len;
+    int64_t  start;          // first payload symbol, relative to the stream (symbol k is read at start + k sps while nothing moves the symbol clock)
+    int64_t  hdr_pos;        // (for an environment that decodes the packet from its header instead)
+    uint32_t n_walk;         // symbols DECODE_PAYLOAD demodulates
+    uint32_t cr_prev;
+    SkippedPayload sk;
+    // results
+    uint32_t status;         // PayloadStatus
+    int32_t  end_shift;
+    uint32_t frame_len;
+    uint8_t  frame[kMaxFrame + 4];
+};
+
+// records of `out` re-laid with a larger stride (rows grow when a re-run job's attempts are spliced into a row)
+inline void restride(RunOut &out, uint32_t new_rpj)
+{
+    if (new_rpj <= out.rpj) return;
+    const size_t nj = out.res.size();
+    RecStore n;
+    n.resize_uninit(nj * (size_t)new_rpj);
+    for (size_t j = 0; j < nj; j++)
+        for (uint32_t a = 0; a < out.rpj; a++) n[j * new_rpj + a] = out.recs[j * out.rpj + a];
+    out.recs.p.swap(n.p); std::swap(out.recs.n, n.n); std::swap(out.recs.cap, n.cap);
+    out.rpj = new_rpj;
+    if (out.cap < new_rpj) out.cap = new_rpj;
+}
 
 // A completed attempt of the TRUE trajectory: replay its DETECT pushes, take the
 // SNR at the trigger (:756), publish the frame if there is one.
@@ -237,6 +275,7 @@ struct PassCtx {
     std::vector<Job> jobs;
     uint32_t rpj1 = 0, rpj2 = 8, trace_cap = 0;
     bool segmenting = false, tracing = false, launched = false;
+    bool decoupled = false;  // the segment jobs run header-only (LaunchCfg.skip_payload), payload_round() decodes the payloads
     std::chrono::steady_clock::time_point tp_in, tp0;
 };
 
@@ -327,10 +366,186 @@ int decode_begin(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
     ctx.rpj1 = recs_for(max_span, sps) + (segmenting ? ctx.rpj2 : 0u);
     ctx.trace_cap = tracing ? (uint32_t)std::min<uint64_t>(2ull * (max_span / sps) + 64ull, 1ull << 22) : 0u;
     env.count_jobs((uint32_t)jobs.size());
+    // Few jobs for the device (a gateway's short pass: a handful of packets per channel): a packet's symbols are a serial chain on ONE CU while
+    // most CUs idle.  Decoupled pass: the jobs stop behind every header and skip the payload, whose symbols the payload pass demodulates all at once.
+    ctx.decoupled = segmenting && env.decoupled(jobs.size());
+    env.set_skip_payload(ctx.decoupled);
     ctx.tp0 = std::chrono::steady_clock::now();
     const int s = env.run_jobs_begin(jobs, ctx.rpj1, ctx.trace_cap, env.run_out(0)); // (result holders are kept by the environment between calls)
     if (s != 0) return s;
     ctx.launched = true;
+    return 0;
+}
+
+// The payload round of a decoupled pass.  Every kAttemptHeaderOnly record of the segment jobs goes through the payload pass (env.run_payload), which
+// returns the packet's frame and by how many samples its symbols moved the symbol clock in all.
+//  * Not at all: the record becomes the frame (kAttemptFrame); the job's scan behind it - started where the payload ends under that very assumption -
+//    stands.
+//  * By some samples: the frame stands, the scan behind it started beside the true position.  That is the situation at every segment boundary, and it
+//    is handled the same way: the job is split there into two - the second half's records are a speculation like any later segment's, and a probe from
+//    the TRUE end of the packet decides whether the true trajectory enters one of its headers (it does when SYNC / FIND_SFD pull both onto the next
+//    preamble, as they do for a few samples' difference).
+//  * The data ends inside the payload: the packet is pending, the job ends there.
+//  * Unresolved: the rest of the job is run again from that packet's header by the complete kernels (Job.start_at_header, same limits, same tail
+//    probe), all such jobs in one launch, and spliced in.
+// What the stitch then sees are ordinary records, jobs and segments.
+template <class Env>
+int payload_round(Env &env, const std::vector<StreamDesc> &streams, PassCtx &ctx, RunOut &R1)
+{
+    const uint32_t sps = env.sps();
+    struct Ref { size_t k; uint32_t a; };
+    std::vector<Ref> refs;
+    std::vector<PayloadReq> reqs;
+    for (size_t k = 0; k < ctx.jobs.size(); k++) {
+        const uint32_t nall = std::min(std::min(R1.res[k].n_attempts, R1.cap), R1.rpj);
+        const StreamDesc &sd = streams[ctx.segs[k].stream];
+        for (uint32_t a = 0; a < nall; a++) {
+            const AttemptRec &r = R1.rec(k, a);
+            if (r.status != kAttemptHeaderOnly) continue;
+            PayloadReq q{};
+            std::memcpy(&q.sk, r.frame, sizeof q.sk);
+            q.n_walk = (uint32_t)(q.sk.payload_symbols > 0 ? q.sk.payload_symbols : 1);
+            q.stream_off = sd.off; q.stream_len = sd.len;
+            q.start = r.end_pos - (int64_t)q.n_walk * (int64_t)sps;
+            q.hdr_pos = r.hdr_pos; q.cr_prev = r.cr_prev;
+            refs.push_back(Ref{k, a});
+            reqs.push_back(q);
+        }
+    }
+    if (reqs.empty()) return 0;
+    int s = env.run_payload(reqs);
+    if (s != 0) return s;
+
+    // in place: frames and true end positions; per job, where it is split and where it ends early
+    struct Plan { std::vector<uint32_t> split; int term = -1; uint32_t term_kind = 0; }; // split: behind these attempts; term: the job ends with this attempt (1 pending, 2 run again)
+    std::vector<Plan> plan(ctx.jobs.size());
+    uint32_t n_moved = 0, n_rerun = 0, n_pending = 0;
+    for (size_t i = 0; i < reqs.size(); i++) {
+        const size_t k = refs[i].k;
+        Plan &pl = plan[k];
+        if (pl.term >= 0) continue; // behind the attempt this job ends with
+        AttemptRec &r = R1.recs[k * R1.rpj + refs[i].a];
+        const PayloadReq &q = reqs[i];
+        if (q.status == kPayloadDecoded) {
+            r.status = kAttemptFrame;
+            r.frame_len = q.frame_len;
+            std::memcpy(r.frame, q.frame, std::min<size_t>(q.frame_len, sizeof r.frame));
+            r.n_symbols += q.n_walk;
+            r.end_pos += q.end_shift;
+            if (q.end_shift != 0) { pl.split.push_back(refs[i].a); n_moved++; }
+        } else {
+            pl.term = (int)refs[i].a; pl.term_kind = q.status == kPayloadOutOfData ? 1u : 2u;
+            if (pl.term_kind == 1u) n_pending++; else n_rerun++;
+        }
+    }
+    env.count_payload((uint32_t)reqs.size(), n_moved, n_rerun);
+    if (n_moved == 0 && n_rerun == 0 && n_pending == 0) return 0;
+
+    // jobs to run again (complete kernels), one launch
+    std::vector<Job> rjobs;
+    std::vector<size_t> rk;
+    for (size_t k = 0; k < plan.size(); k++) {
+        if (plan[k].term < 0 || plan[k].term_kind != 2u) continue;
+        const AttemptRec &r = R1.rec(k, (uint32_t)plan[k].term);
+        Job j = ctx.jobs[k];
+        j.start = r.hdr_pos; j.start_at_header = 1; j.cr_prev = r.cr_prev;
+        rjobs.push_back(j);
+        rk.push_back(k);
+    }
+    RunOut &R3 = env.run_out(1);
+    R3.res.clear(); R3.recs.clear();
+    if (!rjobs.empty()) {
+        env.set_skip_payload(false);
+        s = env.run_jobs(rjobs, ctx.rpj1, 0, R3);
+        if (s != 0) return s;
+    }
+
+    // the pass re-laid: every job cut into its pieces
+    struct Row { JobResult res; std::vector<AttemptRec> recs; };
+    std::vector<Seg> nsegs;
+    std::vector<Job> njobs;
+    std::vector<Row> nrows;
+    std::vector<size_t> nfirst(streams.size() + 1, 0);
+    size_t rq = 0;
+    for (size_t i = 0; i < streams.size(); i++) {
+        nfirst[i] = nsegs.size();
+        for (size_t k = ctx.first_seg[i]; k < ctx.first_seg[i + 1]; k++) {
+            const Plan &pl = plan[k];
+            const JobResult &jr = R1.res[k];
+            const uint32_t n_rows = std::min(std::min(jr.n_attempts + (jr.tail_valid ? jr.tail_n_attempts : 0u), R1.cap), R1.rpj);
+            uint32_t lo = 0;
+            int64_t b0 = ctx.segs[k].b0;
+            std::vector<uint32_t> cuts;
+            for (uint32_t a : pl.split) if (pl.term < 0 || (int)a < pl.term) cuts.push_back(a);
+            for (size_t c = 0; c <= cuts.size(); c++) {
+                const bool last = c == cuts.size();
+                Row row;
+                Job j = ctx.jobs[k];
+                Seg sg = ctx.segs[k];
+                j.start = b0; sg.b0 = b0;
+                if (!last) { // [lo, cuts[c]]: ends with a packet that moved the symbol clock; the scan behind it becomes the next piece
+                    const uint32_t hi = cuts[c];
+                    const AttemptRec &e = R1.rec(k, hi);
+                    int32_t shift = 0;
+                    for (size_t t = 0; t < reqs.size(); t++) if (refs[t].k == k && refs[t].a == hi) shift = reqs[t].end_shift;
+                    const int64_t assumed_end = e.end_pos - shift;
+                    for (uint32_t a = lo; a <= hi; a++) row.recs.push_back(R1.rec(k, a));
+                    row.res = JobResult{};
+                    row.res.final_pos = e.end_pos; row.res.n_attempts = hi - lo + 1u; row.res.final_cr = (uint32_t)e.frame[1] >> 5;
+                    row.res.stop_reason = 0; row.res.pad = 0; row.res.npush = 0; row.res.tail_valid = 0;
+                    j.scan_limit = assumed_end; j.probe_limit = 0; j.tail_stop_sfd = 0;
+                    sg.b1 = assumed_end;
+                    b0 = assumed_end; lo = hi + 1u;
+                } else if (pl.term >= 0 && pl.term_kind == 1u) { // ends with a pending packet
+                    const uint32_t hi = (uint32_t)pl.term;
+                    for (uint32_t a = lo; a <= hi; a++) row.recs.push_back(R1.rec(k, a));
+                    AttemptRec &e = row.recs.back();
+                    e.status = kAttemptOutOfData; e.frame_len = 0;
+                    row.res = JobResult{};
+                    row.res.final_pos = e.start_pos; row.res.n_attempts = hi - lo + 1u; row.res.final_cr = (uint32_t)e.frame[1] >> 5;
+                    row.res.stop_reason = 1; row.res.pad = 1; row.res.npush = 0; row.res.tail_valid = 0;
+                } else if (pl.term >= 0) { // ends with the re-run: the packet (its scan and acquisition are the original attempt's) and whatever the complete kernels found behind it
+                    const uint32_t hi = (uint32_t)pl.term;
+                    for (uint32_t a = lo; a < hi; a++) row.recs.push_back(R1.rec(k, a));
+                    JobResult nr = R3.res[rq];
+                    const uint32_t n_new = std::min(nr.n_attempts + (nr.tail_valid ? nr.tail_n_attempts : 0u), R3.rpj);
+                    const AttemptRec &old = R1.rec(k, hi);
+                    for (uint32_t t = 0; t < n_new; t++) row.recs.push_back(R3.rec(rq, t));
+                    if (nr.n_attempts >= 1u && n_new >= 1u) {
+                        AttemptRec &m = row.recs[hi - lo];
+                        m.start_pos = old.start_pos; m.trig_pos = old.trig_pos; m.npush = old.npush;
+                        for (int t = 0; t < 4; t++) m.push_tail[t] = old.push_tail[t];
+                        m.n_sfd = old.n_sfd;
+                        for (int t = 0; t < kMaxSfdRec; t++) { m.sfd_pos[t] = old.sfd_pos[t]; m.sfd_fails[t] = old.sfd_fails[t]; }
+                        if (nr.pad && nr.n_attempts == 1u) nr.final_pos = old.start_pos; // pending: the stream resumes at the start of this attempt's scan
+                    }
+                    nr.n_attempts += hi - lo;
+                    nr.tail_first_rec += hi - lo;
+                    row.res = nr;
+                    rq++;
+                } else { // the rest of the job as it ran
+                    for (uint32_t a = lo; a < n_rows; a++) row.recs.push_back(R1.rec(k, a));
+                    row.res = jr;
+                    row.res.n_attempts = jr.n_attempts >= lo ? jr.n_attempts - lo : 0u;
+                    row.res.tail_first_rec = jr.tail_first_rec >= lo ? jr.tail_first_rec - lo : 0u;
+                }
+                nsegs.push_back(sg);
+                njobs.push_back(j);
+                nrows.push_back(std::move(row));
+            }
+        }
+    }
+    nfirst[streams.size()] = nsegs.size();
+    uint32_t stride = 1;
+    for (const Row &r : nrows) stride = std::max<uint32_t>(stride, (uint32_t)r.recs.size());
+    R1.res.resize(nrows.size());
+    R1.recs.resize_uninit(nrows.size() * (size_t)stride);
+    R1.rpj = stride; R1.cap = std::max(R1.cap, stride);
+    for (size_t k = 0; k < nrows.size(); k++) {
+        R1.res[k] = nrows[k].res;
+        for (size_t a = 0; a < nrows[k].recs.size(); a++) R1.recs[k * stride + a] = nrows[k].recs[a];
+    }
+    ctx.segs.swap(nsegs); ctx.jobs.swap(njobs); ctx.first_seg.swap(nfirst);
     return 0;
 }
 
@@ -402,7 +617,7 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
                 const uint32_t nall = std::min(R1.res[k].n_attempts, R1.cap);
                 for (uint32_t a = 0; a < nall; a++) {
                     const AttemptRec &r = R1.rec(k, a);
-                    if (r.hdr_pos < 0 || (r.status != kAttemptFrame && r.status != kAttemptOutOfData)) continue;
+                    if (r.hdr_pos < 0 || (r.status != kAttemptFrame && r.status != kAttemptOutOfData && r.status != kAttemptHeaderOnly)) continue;
                     bool same = !at_sfd && r.hdr_pos == L.hdr_pos;
                     if (at_sfd)
                         for (uint32_t z = 0; z < r.n_sfd && z < (uint32_t)kMaxSfdRec; z++)
@@ -423,6 +638,7 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
             RunOut &R3 = env.run_out(1);
             R3.res.clear(); R3.recs.clear();
             env.count_slow_path();
+            env.set_skip_payload(ctx.decoupled);
             s = env.run_jobs(rjobs, rpj1, 0, R3);
             if (s != 0) return s;
             for (size_t q = 0; q < rk.size(); q++) {
@@ -435,6 +651,11 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
             if (dbg_t) fprintf(stderr, "[lora_hip] %zu segment job(s) run again with the header FEC branch their predecessor's tail probe reported\n", rjobs.size());
         }
     }
+    if (ctx.decoupled) { // the payloads of the header-only jobs; from here on the records are ordinary ones
+        s = payload_round(env, streams, ctx, R1);
+        if (s != 0) return s;
+    }
+    env.set_skip_payload(false);
     struct Probe { uint32_t stream; size_t target; Cursor start; int job; int tail_of; }; // job: index into pjobs, or -1 with tail_of = the job whose tail it is
     std::vector<Probe> probes;
     std::vector<size_t> first_probe(streams.size() + 1, 0);

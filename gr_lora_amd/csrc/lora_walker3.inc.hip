@@ -1313,7 +1313,10 @@ __device__ __forceinline__ void w3_touch(const float2 *X, int64_t first_item, in
 // outcome that invalidates the later windows (a trigger, a state change, d_fine_sync != 0, a loop-top check, the end of
 // the data); it then writes the state back and the next plan.  The accepted sequence is exactly the serial one.  Keeping
 // the state out of the other wavefronts' registers is what lets the demodulator run without spills.
-template <int SF, bool GRAD, int HV = 0>
+// SKIP (LaunchCfg.skip_payload): the header-only variant.  A packet's attempt ends behind its header: the record (kAttemptHeaderOnly) carries d_phdr, the
+// header block's spare codewords and d_payload_symbols, and the job goes on in DETECT where DECODE_PAYLOAD would end if no symbol moved the symbol
+// clock.  The payload symbols are demodulated by the payload pass - all of them at once, over the whole device - and the host checks the assumption.
+template <int SF, bool GRAD, int HV = 0, bool SKIP = false>
 __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg &C)
 {
     using G = W3Geom<SF, HV>;
@@ -1613,6 +1616,22 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                         break;
                     }
                     w2_end_step<true>(St, job, C, recs, trace, st_w, (int32_t)sps + fine, step_bin, fine, 0.0f, t_start); // :856,:883
+                    if constexpr (SKIP) {
+                        if (is_first && St.state == kDecodePayload && !St.done) { // header parsed (:831-847): the payload is the payload pass's
+                            AttemptRec &r = recs[St.n_att];
+                            SkippedPayload sk;
+                            sk.phdr[0] = St.phdr[0]; sk.phdr[1] = St.phdr[1]; sk.phdr[2] = St.phdr[2];
+                            sk.n_left = (uint8_t)(St.n_cw < 8u ? St.n_cw : 8u);
+                            for (uint32_t i = 0; i < 8u; i++) sk.left[i] = i < St.n_cw ? sh.cw[i] : (uint8_t)0;
+                            sk.payload_symbols = St.payload_symbols;
+                            *reinterpret_cast<SkippedPayload *>(r.frame) = sk;
+                            const int32_t n_walk = St.payload_symbols > 0 ? St.payload_symbols : 1; // (:866-870 are reached behind the first symbol at the earliest)
+                            St.state = kDetect; St.frame_ok = 0; St.n_words = 0; St.n_cw = 0;
+                            w2_end_step<true>(St, job, C, recs, nullptr, kDecodePayload, n_walk * (int32_t)sps, -1, 0, 0.0f, t_start); // (the attempt is closed: status, positions, pushes)
+                            r.status = kAttemptHeaderOnly; r.frame_len = (uint32_t)sizeof(SkippedPayload);
+                            break;
+                        }
+                    }
                     if (St.done || fine != 0) break; // (fine != 0: the later windows started at the wrong sample)
                 }
 #if LORA_W3_REPLAY_STATS > 1
@@ -1704,6 +1723,15 @@ __global__ __launch_bounds__((W3Geom<9, 1>::T), 2) void walker3_kernel_sf9_half(
 __global__ __launch_bounds__((W3Geom<10, 1>::T), 2) void walker3_kernel_sf10_half(DevParams P, LaunchCfg C) { walker3_body<10, false, 1>(P, C); }
 __global__ __launch_bounds__((W3Geom<9, 1>::T), 2) void walker3_kernel_sf9_grad_half(DevParams P, LaunchCfg C) { walker3_body<9, true, 1>(P, C); }
 __global__ __launch_bounds__((W3Geom<10, 1>::T), 2) void walker3_kernel_sf10_grad_half(DevParams P, LaunchCfg C) { walker3_body<10, true, 1>(P, C); }
+// header-only variants (LaunchCfg.skip_payload), full-size workgroups: the launches of a decoupled pass hold fewer jobs than the device has CUs
+__global__ __launch_bounds__(W3Geom<9>::T, W3Geom<9>::T512 ? 2 : 4) void walker3_kernel_sf9_skip(DevParams P, LaunchCfg C) { walker3_body<9, false, 0, true>(P, C); }
+__global__ __launch_bounds__(W3Geom<10>::T, W3Geom<10>::T512 ? 2 : 4) void walker3_kernel_sf10_skip(DevParams P, LaunchCfg C) { walker3_body<10, false, 0, true>(P, C); }
+__global__ __launch_bounds__(W3Geom<11>::T, W3Geom<11>::T512 ? 2 : 4) void walker3_kernel_sf11_skip(DevParams P, LaunchCfg C) { walker3_body<11, false, 0, true>(P, C); }
+__global__ __launch_bounds__(W3Geom<12>::T, W3Geom<12>::T512 ? 2 : 4) void walker3_kernel_sf12_skip(DevParams P, LaunchCfg C) { walker3_body<12, false, 0, true>(P, C); }
+__global__ __launch_bounds__(W3Geom<9>::T, W3Geom<9>::T512 ? 2 : 4) void walker3_kernel_sf9_grad_skip(DevParams P, LaunchCfg C) { walker3_body<9, true, 0, true>(P, C); }
+__global__ __launch_bounds__(W3Geom<10>::T, W3Geom<10>::T512 ? 2 : 4) void walker3_kernel_sf10_grad_skip(DevParams P, LaunchCfg C) { walker3_body<10, true, 0, true>(P, C); }
+__global__ __launch_bounds__(W3Geom<11>::T, W3Geom<11>::T512 ? 2 : 4) void walker3_kernel_sf11_grad_skip(DevParams P, LaunchCfg C) { walker3_body<11, true, 0, true>(P, C); }
+__global__ __launch_bounds__(W3Geom<12>::T, W3Geom<12>::T512 ? 2 : 4) void walker3_kernel_sf12_grad_skip(DevParams P, LaunchCfg C) { walker3_body<12, true, 0, true>(P, C); }
 // demod_mode 0: the gradient demodulator (the reference's shipped default, :499) in the decode rounds
 __global__ __launch_bounds__(W3Geom<9>::T, W3Geom<9>::T512 ? 2 : 4) void walker3_kernel_sf9_grad(DevParams P, LaunchCfg C) { walker3_body<9, true>(P, C); }
 __global__ __launch_bounds__(W3Geom<10>::T, W3Geom<10>::T512 ? 2 : 4) void walker3_kernel_sf10_grad(DevParams P, LaunchCfg C) { walker3_body<10, true>(P, C); }

@@ -51,6 +51,11 @@ typedef enum lora_hip_demod {
                                       :231-240, one sequential float sum per shift as volk_32f_x2_dot_prod_32f_generic adds) and the FIRST maximum of those
                                       sums wins, as in :399-407 - on a clean preamble two adjacent shifts tie to ~6 / sps^2 of the peak and the float
                                       arithmetic alone decides.  Costs 1.5-4 % of a pass; FFT demodulators publish the same bytes either way. */
+#define LORA_HIP_FLAG_NO_DECOUPLED 8u /* never run a pass decoupled.  A decoupled pass (chosen per pass when its jobs would leave most CUs idle - a gateway's short
+                                       * pass, a few packets per channel; SF9-12 at decimation 8, explicit header): the state-machine jobs stop behind every header
+                                       * and skip the payload, all payload symbols are demodulated at once at their zero-drift positions, and a packet whose symbols
+                                       * moved the symbol clock is decoded again by the complete kernels.  Same frames either way (decoder_impl.cc:838-886).
+                                       * LORA_HIP_DECOUPLED=0|1 in the environment overrides the per-pass choice (1: every pass the kernels allow). */
 #define LORA_HIP_FLAG_PIN_HOST 2u  /* lora_hip_work may page-lock (hipHostRegister) the caller's buffers to DMA straight from them;
                                       only for long-lived buffers the caller uses for nothing else.  Memory that is already
                                       page-locked (hipHostMalloc / registered by the caller) is always used directly. */
@@ -254,6 +259,10 @@ lora_hip_status lora_hip_last_timing(const lora_hip_decoder_t *h, lora_hip_timin
  * walker2_kernel_sf7/8[_grad] (wave per symbol), walker3_kernel_sf9..12[_grad] (workgroup per symbol), walker_kernel* (generic:
  * other decimations, LORA_HIP_NO_FAST).                                                                                        */
 const char     *lora_hip_walker_kernel_name(const lora_hip_decoder_t *h);
+/* The payload pass of the last pass when it ran decoupled (LORA_HIP_FLAG_NO_DECOUPLED above): packets whose payload it took, how many of them
+ * were decoded again by the complete kernels, payload symbols demodulated, device time of its two kernels (part of lora_hip_timing_t.walker_ms);
+ * all zero when the pass was not decoupled.                                                                                               */
+lora_hip_status lora_hip_last_payload_pass(const lora_hip_decoder_t *h, uint32_t *packets, uint32_t *rerun, uint32_t *symbols, float *ms);
 
 /* How the last pass cut its streams into speculation segments (diagnostics): *burst_aware = 1 when the cuts were placed
  * in the gaps between bursts found by the energy-envelope pre-pass, 0 for the fixed grid (configured segment length,

@@ -118,10 +118,13 @@ void     lora_oracle_demod_at(lora_oracle_t *o, const float *iq, const int64_t *
 /* ---- job-level entry, used by tests/host_sim to exercise the product's speculation scheduler on the CPU ----
  * Runs the state machine like one walker job: start in DETECT at `start` with d_phdr.cr = cr_prev, begin no new
  * DETECT step at pos >= scan_limit, stop after max_attempts (0 = no limit) or, with stop_at_header & 1, on entering
- * DECODE_HEADER; stop_at_header & 2: also at the start of an attempt's second FIND_SFD step (Job.tail_stop_sfd).  Attempts are reported in the same terms as the device's AttemptRec / JobResult.                */
+ * DECODE_HEADER; stop_at_header & 2: also at the start of an attempt's second FIND_SFD step (Job.tail_stop_sfd); & 4: an attempt ends behind its
+ * header (status 6: frame[] = d_phdr, the count and the values of the header block's spare codewords at [3], [4..12), d_payload_symbols at [12..16))
+ * and the job goes on in DETECT where the payload would end with d_fine_sync == 0 throughout (LaunchCfg.skip_payload); & 8: the job starts in
+ * DECODE_HEADER at `start` with an attempt open (Job.start_at_header).  Attempts are reported in the same terms as the device's AttemptRec / JobResult. */
 typedef struct {
     int64_t  start_pos, trig_pos, hdr_pos, end_pos;
-    uint32_t status;        /* 1 frame, 2 lost sync, 3 out of data, 4 stopped at header, 5 stopped behind the first FIND_SFD step */
+    uint32_t status;        /* 1 frame, 2 lost sync, 3 out of data, 4 stopped at header, 5 stopped behind the first FIND_SFD step, 6 header only */
     uint32_t npush;
     float    push_tail[4];
     uint32_t cr_prev, hdr_ambig, frame_len, n_symbols;

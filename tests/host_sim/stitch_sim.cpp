@@ -26,6 +26,37 @@ struct SimEnv {
     bool tail_probes = true; // emulate Job.probe_limit (walker2); false: the generic kernels' behaviour (explicit probe jobs only)
     bool early = false;      // emulate walker3: FIND_SFD entry states in the attempt records, tail probes stop behind their first FIND_SFD step
     bool early_probe() const { return early; }
+    int decoupled_mode = 0;  // 1: every pass decoupled (header-only segment jobs + payload pass)
+    bool skip = false;
+    uint32_t n_payload = 0, n_rerun = 0;
+    bool decoupled(size_t) const { return decoupled_mode != 0; }
+    void set_skip_payload(bool on) { skip = on; }
+    uint32_t n_moved = 0, n_pending = 0;
+    void count_payload(uint32_t p, uint32_t m, uint32_t r) { n_payload += p; n_moved += m; n_rerun += r; }
+    // the payload pass, by the oracle: the packet decoded from its header by the complete state machine - its frame, and how far from the zero-drift
+    // end it ended (the device finds the same two things by demodulating the symbols on their own and following their d_fine_sync)
+    int run_payload(std::vector<PayloadReq> &reqs)
+    {
+        std::vector<oracle_attempt_t> tmp(2);
+        for (PayloadReq &q : reqs) {
+            oracle_job_result_t r{};
+            lora_oracle_run_job(o, iq + 2 * q.stream_off, (size_t)q.stream_len, q.hdr_pos, q.hdr_pos + 1, q.cr_prev, 1, 8, 1, tmp.data(), &r);
+            const oracle_attempt_t &t = tmp[0];
+            q.frame_len = 0; q.end_shift = 0;
+            if (r.n_attempts == 1u && !r.pad && t.status == 1u) {
+                q.status = kPayloadDecoded;
+                q.end_shift = (int32_t)(t.end_pos - (q.start + (int64_t)q.n_walk * (int64_t)sps_));
+                q.frame_len = t.frame_len;
+                std::memcpy(q.frame, t.frame, t.frame_len);
+            } else {
+                q.status = kPayloadOutOfData;
+                n_pending++;
+            }
+            if (payload_force_rerun && ((n_forced++ % payload_force_rerun) == 0u)) q.status = kPayloadUnresolved;
+        }
+        return 0;
+    }
+    uint32_t payload_force_rerun = 0, n_forced = 0; // tests: every n-th packet is reported as not clean
 
     uint32_t sps() const { return sps_; }
     uint32_t ctor_cr() const { return ctor_cr_; }
@@ -76,14 +107,14 @@ struct SimEnv {
                 d.status = s.status; d.npush = s.npush; std::memcpy(d.push_tail, s.push_tail, sizeof d.push_tail);
                 d.cr_prev = s.cr_prev; d.hdr_ambig = s.hdr_ambig; d.frame_len = s.frame_len; d.n_symbols = s.n_symbols;
                 d.n_sfd = early ? s.n_sfd : 0u; std::memcpy(d.sfd_pos, s.sfd_pos, sizeof d.sfd_pos); std::memcpy(d.sfd_fails, s.sfd_fails, sizeof d.sfd_fails);
-                std::memcpy(d.frame, s.frame, s.frame_len);
+                std::memcpy(d.frame, s.frame, s.frame_len); // (status 6: the 16 bytes of SkippedPayload, same layout)
             }
         };
         for (size_t j = 0; j < jobs.size(); j++) {
             const Job &jb = jobs[j];
             oracle_job_result_t r{};
             lora_oracle_run_job(o, iq + 2 * jb.stream_off, (size_t)jb.stream_len, jb.start, jb.scan_limit, jb.cr_prev,
-                                jb.max_attempts, (int)jb.stop_at_header, rpj, tmp.data(), &r);
+                                jb.max_attempts, (int)jb.stop_at_header | (skip ? 4 : 0) | (jb.start_at_header ? 8 : 0), rpj, tmp.data(), &r);
             JobResult &jr = out.res[j];
             jr.final_pos = r.final_pos; jr.n_attempts = r.n_attempts; jr.final_cr = r.final_cr; jr.npush = r.npush;
             std::memcpy(jr.push_tail, r.push_tail, sizeof jr.push_tail);
@@ -132,6 +163,8 @@ extern "C" int stitch_sim_decode(const float *iq, size_t n_items, int sf, int ct
     env.tail_probes = (tail_probes & 1) != 0;
     env.burst_plan = (tail_probes & 2) != 0;
     env.early = (tail_probes & 4) != 0;
+    env.decoupled_mode = (tail_probes & 8) ? 1 : 0;
+    env.payload_force_rerun = (uint32_t)(tail_probes >> 8) & 0xffu;
     std::vector<StreamDesc> sds(1);
     sds[0].off = 0; sds[0].len = n_items; sds[0].id = 0; sds[0].cr_in = (uint32_t)ctor_cr; sds[0].abs_base = 0;
     const int rc = decode_streams(env, sds);
@@ -144,7 +177,7 @@ extern "C" int stitch_sim_decode(const float *iq, size_t n_items, int sf, int ct
         std::memcpy(out + used, f.blob.data(), f.blob.size());
         lens[n] = (int)f.blob.size(); hdr_pos[n] = f.hdr_pos; used += f.blob.size(); n++;
     }
-    stats[0] = env.n_jobs; stats[1] = env.n_probes; stats[2] = env.n_slow; stats[3] = sds[0].incomplete ? 1u : 0u; stats[4] = env.n_tails; stats[5] = env.planned; stats[6] = env.n_early;
+    stats[0] = env.n_jobs; stats[1] = env.n_probes; stats[2] = env.n_slow; stats[3] = sds[0].incomplete ? 1u : 0u; stats[4] = env.n_tails; stats[5] = env.planned; stats[6] = env.n_early; stats[7] = env.n_payload; stats[8] = env.n_rerun; stats[9] = env.n_moved; stats[10] = env.n_pending;
     return n;
 }
 

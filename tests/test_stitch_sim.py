@@ -28,20 +28,22 @@ def sim(oracle_mod):
     L.stitch_sim_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int,
                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
 
-    def run(iq, sf, ctor_cr=4, demod=2, reduced=False, seg=0, slots=512, tails=True, plan=False, early=False):
+    def run(iq, sf, ctor_cr=4, demod=2, reduced=False, seg=0, slots=512, tails=True, plan=False, early=False, decoupled=False, force_rerun=0):
         a = np.ascontiguousarray(iq, dtype=np.complex64)
         out = np.zeros(1 << 20, dtype=np.uint8)
         lens = np.zeros(4096, dtype=np.int32)
         hp = np.zeros(4096, dtype=np.int64)
-        st = np.zeros(8, dtype=np.uint32)
-        n = L.stitch_sim_decode(a.ctypes.data, a.size, sf, ctor_cr, 1, int(reduced), demod, seg, slots, int(tails) | (2 if plan else 0) | (4 if early else 0), out.ctypes.data, out.size,
+        st = np.zeros(12, dtype=np.uint32)
+        mode = int(tails) | (2 if plan else 0) | (4 if early else 0) | (8 if decoupled else 0) | ((force_rerun & 0xff) << 8)
+        n = L.stitch_sim_decode(a.ctypes.data, a.size, sf, ctor_cr, 1, int(reduced), demod, seg, slots, mode, out.ctypes.data, out.size,
                                 lens.ctypes.data, hp.ctypes.data, 4096, st.ctypes.data)
         assert n >= 0, n
         frames, off = [], 0
         for i in range(n):
             frames.append(bytes(out[off:off + lens[i]]))
             off += int(lens[i])
-        return frames, hp[:n].tolist(), dict(jobs=int(st[0]), probes=int(st[1]), slow=int(st[2]), incomplete=int(st[3]), tails=int(st[4]), planned=int(st[5]), early=int(st[6]))
+        return frames, hp[:n].tolist(), dict(jobs=int(st[0]), probes=int(st[1]), slow=int(st[2]), incomplete=int(st[3]), tails=int(st[4]), planned=int(st[5]), early=int(st[6]),
+                                           payload=int(st[7]), rerun=int(st[8]), moved=int(st[9]), pending=int(st[10]))
     return run
 
 
@@ -264,3 +266,58 @@ def test_wrong_header_branch_jobs_are_rerun_in_one_batch(sim, oracle_mod):
         assert got == want and gpos == wpos, early
         assert stats["planned"] == 1 and stats["slow"] <= 6, stats
     assert len(want) >= 30
+
+
+@pytest.mark.parametrize("early", [False, True])
+@pytest.mark.parametrize("seg", [16, 40, 150, 0])
+def test_decoupled_pass_equals_serial(sim, oracle_mod, seg, early):
+    """The decoupled pass (header-only segment jobs, LaunchCfg.skip_payload + the payload pass, lora_stitch.hpp payload_round) against the serial
+    decoder: clean traffic (no packet is run again), noisy traffic with a drifting symbol clock (packets that move the clock ARE run again, and the
+    rest of their job with them), and every third / every packet forced through the re-run path."""
+    cfg = synth.TxConfig(sf=7, cr=4)
+    rng = np.random.default_rng(4100 + seg)
+    payloads = [bytes(rng.integers(0, 256, int(rng.integers(1, 48)), dtype=np.uint8)) for _ in range(24)]
+    gaps = [int(g) for g in rng.integers(0, 9 * cfg.sps, len(payloads))]
+    gaps[3] = 0; gaps[4] = 1; gaps[9] = cfg.sps // 2
+    st = synth.build_stream(payloads, cfg, gaps=gaps)
+    want, wpos = _serial(oracle_mod, st.iq, 7)
+    assert len(want) >= 20
+    for force in (0, 3, 1):
+        got, gpos, stats = sim(st.iq, 7, seg=seg, slots=40, early=early, decoupled=True, force_rerun=force)
+        assert got == want and gpos == wpos, (seg, force, stats)
+        assert stats["payload"] >= len(want) - 2, stats
+        if force == 0:
+            assert stats["rerun"] == 0, stats
+        else:
+            assert stats["rerun"] > 0, stats
+    # noise + a transmitter clock 40 ppm off (linear resampling): fine_sync moves the symbol clock inside payloads
+    stn = synth.build_stream(payloads, cfg, gaps=gaps, rng=np.random.default_rng(5), noise_sigma=synth.awgn_sigma_for_snr(40.0, cfg))
+    t = np.arange(int(stn.iq.size / (1 + 40e-6)) - 2, dtype=np.float64) * (1 + 40e-6)
+    i0 = t.astype(np.int64)
+    fr = (t - i0).astype(np.float32)
+    noisy = (stn.iq[i0] * (1 - fr) + stn.iq[i0 + 1] * fr).astype(np.complex64)
+    want, wpos = _serial(oracle_mod, noisy, 7)
+    assert len(want) >= 15
+    got, gpos, stats = sim(noisy, 7, seg=seg, slots=40, early=early, decoupled=True)
+    assert got == want and gpos == wpos, (seg, stats)
+    assert stats["moved"] > 0 and stats["rerun"] == 0, stats     # jobs split behind the packets that moved the clock, a probe from each true end
+    got, gpos, stats2 = sim(noisy, 7, seg=seg, slots=40, early=early, decoupled=True, force_rerun=2)
+    assert got == want and gpos == wpos, (seg, stats2)
+    print(seg, early, stats, stats2)
+
+
+def test_decoupled_pass_cut_mid_packet_and_other_coding_rates(sim, oracle_mod):
+    """Header-only jobs where the data ends inside a payload (the packet is pending, the stream resumes at its scan's start) and with the header FEC
+    branch carried across segments (CR 4/5 traffic, constructor CR 4/8: round 1b runs header-only jobs again)."""
+    for cr, ctor in ((1, 4), (2, 1), (3, 4)):
+        cfg = synth.TxConfig(sf=7, cr=cr)
+        rng = np.random.default_rng(77 + cr)
+        payloads = [bytes(rng.integers(0, 256, int(rng.integers(4, 40)), dtype=np.uint8)) for _ in range(12)]
+        st = synth.build_stream(payloads, cfg, gaps=[int(g) for g in rng.integers(0, 6 * cfg.sps, len(payloads))])
+        iq = st.iq[: st.iq.size - 30 * cfg.sps]  # the last packet loses its tail
+        want, wpos = _serial(oracle_mod, iq, 7, ctor_cr=ctor)
+        for seg in (24, 0):
+            got, gpos, stats = sim(iq, 7, ctor_cr=ctor, seg=seg, slots=24, decoupled=True)
+            ref = sim(iq, 7, ctor_cr=ctor, seg=seg, slots=24)
+            assert got == want and gpos == wpos, (cr, seg, stats)
+            assert stats["incomplete"] == ref[2]["incomplete"] == 1 and stats["pending"] >= 1, (stats, ref[2])
