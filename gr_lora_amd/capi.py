@@ -140,7 +140,7 @@ def load():
     L.lora_hip_demod_symbols_ex_device.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int, vp, vp, vp]
     L.lora_hip_last_timing.argtypes = [vp, C.POINTER(Timing)]
     L.lora_hip_last_plan.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
-    L.lora_hip_last_payload_pass.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
+    L.lora_hip_last_payload_pass.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
     L.lora_hip_decode_device_begin.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_uint32, vp, C.c_uint32]
     L.lora_hip_decode_device_end.argtypes = [vp]
     L.lora_hip_decode_device_prepass.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_uint32, vp, C.c_uint32]
@@ -428,10 +428,10 @@ class Handle:
         return bool(b.value), int(n.value)
 
     def payload_pass(self):
-        """dict(packets, rerun, symbols, ms) of the last pass's payload pass (all zero unless it ran decoupled): lora_hip_last_payload_pass."""
-        a, b, c, m = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_float(0)
-        self._check(self.L.lora_hip_last_payload_pass(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(m)))
-        return dict(packets=int(a.value), rerun=int(b.value), symbols=int(c.value), ms=float(m.value))
+        """dict(packets, moved, rerun, rounds, symbols, ms) of the last pass's payload pass (all zero unless it ran decoupled): lora_hip_last_payload_pass."""
+        a, mv, b, r, c, m = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_float(0)
+        self._check(self.L.lora_hip_last_payload_pass(self.h, C.byref(a), C.byref(mv), C.byref(b), C.byref(r), C.byref(c), C.byref(m)))
+        return dict(packets=int(a.value), moved=int(mv.value), rerun=int(b.value), rounds=int(r.value), symbols=int(c.value), ms=float(m.value))
 
     def trace(self):
         p = C.POINTER(Step)()

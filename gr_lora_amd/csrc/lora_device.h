@@ -172,27 +172,36 @@ int launch_envelope(const float2 *iq, const EnvStream *streams /* host table; fi
 
 int launch_walker(const DevParams &p, const LaunchCfg &c, void *stream);
 const char *walker_kernel_name(const DevParams &p);                        // the kernel launch_walker picks for this configuration
+// (walker3 symbol kernels) second reads: when symbol s moved the symbol clock (fine[s] != 0) and symbol s + 1 is its successor in the same packet
+// (offsets[s + 1] == offsets[s] + sps), the workgroup that demodulated s reads s + 1 again fine[s] samples further on and leaves shift[s + 1] = fine[s]
+// and the result in bins / fine [s + 1] of THIS set: on a clean signal the successor moves the clock straight back, and the payload pass's walk
+// gets past the pair without another round.  shift[] must be zero on entry; windows outside [0, max_start] are not read.
+struct DemodAlt { int32_t *shift; uint32_t *bins; int32_t *fine; int64_t max_start; };
 int launch_demod_symbols(const DevParams &p, const float2 *iq, const int64_t *d_offsets, uint32_t n,
-                         int demod, uint32_t *d_bins, int32_t *d_fine, float *scratch, void *stream,
-                         const uint32_t *d_out_idx = nullptr /* walker3 kernels only: result s goes to bins / fine [d_out_idx[s]] */);
+                         int demod, uint32_t *d_bins, int32_t *d_fine, float *scratch, void *stream, const DemodAlt *alt = nullptr);
 int launch_detect_windows(const DevParams &p, const float2 *iq, const int64_t *d_offsets, uint32_t n, void *d_out /* 24 B per window */, void *stream); // N4: lora_detect.inc.hip
 // The payload pass of a launch with LaunchCfg.skip_payload: every payload symbol of every packet demodulated on its own (launch_demod_symbols over
 // the zero-drift positions), then one workgroup per packet takes the symbols through demodulate()'s integer chain (:506-529, :866-881).
+constexpr int kPayloadHyp = 4;
 struct PayloadDesc {         // one packet (host-written)
-    uint32_t first;          // index of its first symbol in bins / fine
     uint32_t n_walk;         // symbols DECODE_PAYLOAD demodulates: payload_symbols, or 1 when that is <= 0 (:866-870 run behind the first symbol)
-    uint32_t n_fixed;        // symbols [0, n_fixed) were read at their true positions in an earlier round of the pass: their d_fine_sync is already accounted for
-    uint32_t pad;
+    uint32_t n_hyp;          // demodulated so far: symbols [hyp_from[h], hyp_to[h]) read hyp_shift[h] samples behind their zero-drift positions,
+    int32_t  hyp_shift[kPayloadHyp]; // results at bins / fine [hyp_base[h] + symbol]
+    int32_t  hyp_base[kPayloadHyp];
+    uint32_t hyp_from[kPayloadHyp];
+    uint32_t hyp_to[kPayloadHyp];    // (the symbols from hyp_to on would start less than two symbols before the end of the data, :91)
+    int64_t  room;           // symbol j read c samples behind its zero-drift position lies inside the data (:91) iff j sps + c <= room
     SkippedPayload sk;
 };
+enum PayloadWalk : uint32_t { kWalkComplete = 0, kWalkOutOfData = 1, kWalkNeedShift = 2 };
 struct PayloadOut {          // (device-written)
-    uint32_t first_moved;    // first symbol k >= n_fixed with d_fine_sync != 0 behind it (the symbols after it were read `moved_by` samples off), n_walk: none
-    int32_t  moved_by;
-    uint32_t frame_len;      // the frame as the bins stand: the serial decoder's once first_moved >= n_walk - 1
-    uint32_t pad;
+    uint32_t result;         // PayloadWalk: the walk along the symbols ended with the frame / at a symbol that does not fit into the data / at a symbol
+    uint32_t at;             // (`at`) that has not been demodulated `shift` samples behind its zero-drift position yet
+    int32_t  shift;          // kWalkComplete: samples the symbols moved the symbol clock by in all; kWalkNeedShift: the shift wanted
+    uint32_t frame_len;
     uint8_t  frame[kMaxFrame + 4];
 };
-int launch_payload_chain(const DevParams &p, const uint32_t *d_bins, const int32_t *d_fine, const PayloadDesc *descs, PayloadOut *outs, uint32_t n_packets, void *stream);
+int launch_payload_chain(const DevParams &p, const uint32_t *d_bins, const int32_t *d_fine, const DemodAlt &alt, const PayloadDesc *descs, PayloadOut *outs, uint32_t n_packets, void *stream);
 bool walker_has_skip_variant(const DevParams &p);                           // LaunchCfg.skip_payload is honoured (walker3, explicit header)
 int launch_ref_ifreq(const float2 *x, uint32_t n, float *d_arg, float *d_ifreq, void *stream); // diagnostics: the strict SYNC path's atan2f / ifreq
 int launch_cfo(const DevParams &p, const float2 *iq, const int64_t *d_offsets, uint32_t n, int mode, float *d_out, void *stream); // N4: explicit CFO estimate

@@ -192,12 +192,13 @@ struct lora_hip_decoder {
     int decoupled_policy = -1;         // -1 auto (few jobs for the device, few re-runs lately), 0 never, 1 whenever the kernels allow it
     bool launch_skip = false;          // the next launches run the header-only kernel variant (LaunchCfg.skip_payload)
     uint32_t dec_backoff = 0;          // auto: passes to sit out after one whose packets mostly had to be run again
-    uint32_t last_payload_packets = 0, last_payload_rerun = 0, last_payload_symbols = 0;
+    uint32_t last_payload_packets = 0, last_payload_rerun = 0, last_payload_symbols = 0, last_payload_moved = 0, last_payload_rounds = 0;
     float last_payload_ms = 0.0f;
     PinnedBuf<int64_t> p_pay_off;
     PinnedBuf<PayloadDesc> p_pay_desc;
     PinnedBuf<PayloadOut> p_pay_out;
-    DevBuf<int32_t> d_fine;
+    DevBuf<int32_t> d_fine, d_alt_shift, d_alt_fine;
+    DevBuf<uint32_t> d_alt_bins;
 };
 
 namespace {
@@ -676,56 +677,110 @@ lora_hip_status quiet_edges(lora_hip_decoder *h, const float2 *d_iq, const std::
 
 // The payload pass of a decoupled pass (lora_stitch.hpp payload_round): every payload symbol of every header-only packet demodulated at its
 // zero-drift position by the symbol-level kernels - all symbols of all packets in one launch, whatever CU is free - then one small workgroup per
-// packet for the integer chain (payload_chain_kernel).  Offsets go up in one copy; descriptors are read from and results written to page-locked
-// host memory directly, as the walkers' jobs and records are: one event wait, no copy-back.
+// packet walks its symbols in order (payload_chain_kernel).  A walk that meets a symbol whose predecessors moved the symbol clock by a shift nobody
+// has read it at yet stops there; the host has the packet's remaining symbols read at that shift (one more launch for all such packets) and the walks
+// run again with both sets of results to choose from - a +1 / -1 pair of moves, the usual case on a clean signal, costs one extra round however many
+// pairs there are; a clock that drifts steadily needs a round per sample of drift and is handed back after kPayloadHyp - 1 of them (kPayloadUnresolved:
+// the complete kernels decode that packet).  Offsets go up in one copy per round; descriptors are read from and results written to page-locked
+// host memory directly, as the walkers' jobs and records are.
 lora_hip_status run_payload_pass(lora_hip_decoder *h, const float2 *d_iq, std::vector<PayloadReq> &reqs, hipStream_t st)
 {
     const int64_t sps = (int64_t)h->P.sps;
-    size_t n_sym = 0, n_pk = 0;
-    for (const PayloadReq &q : reqs) {
-        const bool fits = q.start >= 0 && q.start + ((int64_t)q.n_walk + 1) * sps <= (int64_t)q.stream_len; // every symbol passes the loop-top check (:91)
-        if (fits) { n_sym += q.n_walk; n_pk++; }
+    const size_t np = reqs.size();
+    if (np == 0) return LORA_HIP_OK;
+    size_t total = 0;
+    for (const PayloadReq &q : reqs) total += q.n_walk;
+    const size_t cap_sym = total * (size_t)kPayloadHyp;
+    HIP_TRY(h, h->p_pay_off.reserve(total));
+    HIP_TRY(h, h->p_pay_desc.reserve(2 * np)); // [0, np): one per packet, kept across the rounds; [np, 2 np): the round's launch list
+    HIP_TRY(h, h->p_pay_out.reserve(np));
+    HIP_TRY(h, h->d_offsets.reserve(total));
+    HIP_TRY(h, h->d_bins.reserve(cap_sym));
+    HIP_TRY(h, h->d_fine.reserve(cap_sym));
+    HIP_TRY(h, h->d_alt_shift.reserve(cap_sym));
+    HIP_TRY(h, h->d_alt_bins.reserve(cap_sym));
+    HIP_TRY(h, h->d_alt_fine.reserve(cap_sym));
+    const bool no_alt = getenv("LORA_HIP_NO_SECOND_READS") != nullptr; // diagnostics / tests: every move of the symbol clock costs a round
+    int64_t buf_end = 0; // the pass's streams end here at the latest: second reads stay inside the buffer (whether they stay inside their stream is the walk's check)
+    for (const PayloadReq &q : reqs) buf_end = std::max<int64_t>(buf_end, (int64_t)(q.stream_off + q.stream_len));
+    const DemodAlt alt{no_alt ? nullptr : h->d_alt_shift.p, h->d_alt_bins.p, h->d_alt_fine.p, buf_end - 2 * sps};
+    PayloadDesc *descs = h->p_pay_desc.p, *launch = h->p_pay_desc.p + np;
+    // symbols [from, to) of packet q read `shift` samples behind their zero-drift positions fit into the data (:91)
+    auto fit_to = [&](const PayloadReq &q, int64_t shift) -> uint32_t {
+        const int64_t room = (int64_t)q.stream_len - 2 * sps - (q.start + shift); // symbol j fits iff j sps <= room
+        if (q.start + shift < 0 || room < 0) return 0u;
+        const int64_t n = room / sps + 1;
+        return (uint32_t)std::min<int64_t>(n, (int64_t)q.n_walk);
+    };
+    std::vector<uint32_t> active(np);
+    for (size_t i = 0; i < np; i++) {
+        PayloadReq &q = reqs[i];
+        q.status = kPayloadUnresolved; q.end_shift = 0; q.frame_len = 0;
+        PayloadDesc &d = descs[i];
+        d = PayloadDesc{};
+        d.n_walk = q.n_walk; d.sk = q.sk;
+        d.room = (int64_t)q.stream_len - 2 * sps - q.start;
+        active[i] = (uint32_t)i;
     }
-    h->last_payload_symbols += (uint32_t)n_sym;
-    for (PayloadReq &q : reqs) { q.clean = 0; q.frame_len = 0; }
-    if (n_pk == 0) return LORA_HIP_OK;
-    HIP_TRY(h, h->p_pay_off.reserve(n_sym));
-    HIP_TRY(h, h->p_pay_desc.reserve(n_pk));
-    HIP_TRY(h, h->p_pay_out.reserve(n_pk));
-    HIP_TRY(h, h->d_offsets.reserve(n_sym));
-    HIP_TRY(h, h->d_bins.reserve(n_sym));
-    HIP_TRY(h, h->d_fine.reserve(n_sym));
-    size_t at = 0, pk = 0;
-    for (const PayloadReq &q : reqs) {
-        if (!(q.start >= 0 && q.start + ((int64_t)q.n_walk + 1) * sps <= (int64_t)q.stream_len)) continue;
-        PayloadDesc &d = h->p_pay_desc.p[pk];
-        d.first = (uint32_t)at; d.n_walk = q.n_walk; d.sk = q.sk;
-        for (uint32_t k = 0; k < q.n_walk; k++) h->p_pay_off.p[at++] = (int64_t)q.stream_off + q.start + (int64_t)k * sps;
-        h->p_pay_out.p[pk].clean = 0; h->p_pay_out.p[pk].frame_len = 0;
-        pk++;
+    size_t used = 0; // entries of d_bins / d_fine handed out
+    float ms_total = 0.0f;
+    for (int round = 0; round < kPayloadHyp && !active.empty(); round++) {
+        // this round's reads: for every active packet the symbols from `at` on, `shift` behind their zero-drift positions
+        size_t n_sym = 0;
+        for (uint32_t i : active) {
+            PayloadReq &q = reqs[i];
+            PayloadDesc &d = descs[i];
+            const PayloadOut &o = h->p_pay_out.p[i];
+            const uint32_t from = round == 0 ? 0u : o.at;
+            const int32_t shift = round == 0 ? 0 : o.shift;
+            const uint32_t to = std::max(fit_to(q, shift), from);
+            const uint32_t hh = d.n_hyp++;
+            d.hyp_shift[hh] = shift; d.hyp_from[hh] = from; d.hyp_to[hh] = to;
+            d.hyp_base[hh] = (int32_t)(used + n_sym) - (int32_t)from;
+            for (uint32_t j = from; j < to; j++) h->p_pay_off.p[n_sym++] = (int64_t)q.stream_off + q.start + (int64_t)j * sps + shift;
+        }
+        if (used + n_sym > cap_sym) break; // (cannot happen: at most kPayloadHyp reads of each symbol)
+        for (size_t a = 0; a < active.size(); a++) launch[a] = descs[active[a]];
+        HIP_TRY(h, hipEventRecord(h->ev0, st));
+        if (n_sym) {
+            HIP_TRY(h, hipMemcpyAsync(h->d_offsets.p, h->p_pay_off.p, n_sym * sizeof(int64_t), hipMemcpyHostToDevice, st));
+            DemodAlt ar{alt.shift ? alt.shift + used : nullptr, alt.bins + used, alt.fine + used, alt.max_start};
+            if (ar.shift) HIP_TRY(h, hipMemsetAsync(ar.shift, 0, n_sym * sizeof(int32_t), st));
+            if (launch_demod_symbols(h->P, d_iq, h->d_offsets.p, (uint32_t)n_sym, (int)h->P.demod_mode, h->d_bins.p + used, h->d_fine.p + used, nullptr, st, &ar) != 0)
+                return fail(h, LORA_HIP_ERR_HIP, "payload pass: symbol launch failed: %s", hipGetErrorString(hipGetLastError()));
+        }
+        // (the walks' results land at the packets' own slots: launch entry a writes PayloadOut[a]; copied to slot active[a] below)
+        if (launch_payload_chain(h->P, h->d_bins.p, h->d_fine.p, alt, launch, h->p_pay_out.p, (uint32_t)active.size(), st) != 0)
+            return fail(h, LORA_HIP_ERR_HIP, "payload pass: chain launch failed: %s", hipGetErrorString(hipGetLastError()));
+        HIP_TRY(h, hipEventRecord(h->ev1, st));
+        HIP_TRY(h, hipEventRecord(h->ev_done, st));
+        HIP_TRY(h, hipEventSynchronize(h->ev_done));
+        used += n_sym;
+        h->last_payload_symbols += (uint32_t)n_sym;
+        float ms = 0.0f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        ms_total += ms;
+        // results sit at launch order: spread them to the packets' slots from the back (active[a] >= a)
+        for (size_t a = active.size(); a-- > 0;) if (active[a] != a) h->p_pay_out.p[active[a]] = h->p_pay_out.p[a];
+        std::vector<uint32_t> next;
+        for (uint32_t i : active) {
+            PayloadReq &q = reqs[i];
+            const PayloadOut &o = h->p_pay_out.p[i];
+            if (o.result == kWalkComplete && o.frame_len >= 3u && o.frame_len <= (uint32_t)sizeof q.frame) {
+                q.status = kPayloadDecoded; q.end_shift = o.shift; q.frame_len = o.frame_len;
+                std::memcpy(q.frame, o.frame, o.frame_len);
+            } else if (o.result == kWalkOutOfData) {
+                q.status = kPayloadOutOfData;
+            } else if (o.result == kWalkNeedShift && descs[i].n_hyp < (uint32_t)kPayloadHyp) {
+                next.push_back(i);
+            } // else: stays kPayloadUnresolved
+        }
+        active.swap(next);
+        h->last_payload_rounds++;
     }
-    HIP_TRY(h, hipMemcpyAsync(h->d_offsets.p, h->p_pay_off.p, n_sym * sizeof(int64_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(h, hipEventRecord(h->ev0, st));
-    if (launch_demod_symbols(h->P, d_iq, h->d_offsets.p, (uint32_t)n_sym, (int)h->P.demod_mode, h->d_bins.p, h->d_fine.p, nullptr, st) != 0)
-        return fail(h, LORA_HIP_ERR_HIP, "payload pass: symbol launch failed: %s", hipGetErrorString(hipGetLastError()));
-    if (launch_payload_chain(h->P, h->d_bins.p, h->d_fine.p, h->p_pay_desc.p, h->p_pay_out.p, (uint32_t)n_pk, st) != 0)
-        return fail(h, LORA_HIP_ERR_HIP, "payload pass: chain launch failed: %s", hipGetErrorString(hipGetLastError()));
-    HIP_TRY(h, hipEventRecord(h->ev1, st));
-    HIP_TRY(h, hipEventRecord(h->ev_done, st));
-    HIP_TRY(h, hipEventSynchronize(h->ev_done));
-    pk = 0;
-    for (PayloadReq &q : reqs) {
-        if (!(q.start >= 0 && q.start + ((int64_t)q.n_walk + 1) * sps <= (int64_t)q.stream_len)) continue;
-        const PayloadOut &o = h->p_pay_out.p[pk++];
-        q.clean = (o.clean && o.frame_len >= 3u && o.frame_len <= (uint32_t)sizeof q.frame) ? 1u : 0u;
-        q.frame_len = q.clean ? o.frame_len : 0u;
-        if (q.clean) std::memcpy(q.frame, o.frame, o.frame_len);
-    }
-    float ms = 0.0f;
-    HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    h->last_payload_ms += ms;
-    h->timing.walker_ms += ms;       // (the pass's device time: the header-only walkers and the payload pass's two kernels)
-    h->timing.total_device_ms += ms;
+    h->last_payload_ms += ms_total;
+    h->timing.walker_ms += ms_total;       // (the pass's device time: the header-only walkers and the payload pass's kernels)
+    h->timing.total_device_ms += ms_total;
     h->timing.walker_launches += 2;
     return LORA_HIP_OK;
 }
@@ -761,23 +816,23 @@ struct DeviceEnv {
     // as its longest packet, however few there are) and the traffic does not keep moving the symbol clock (such packets are run again whole).
     bool decoupled(size_t n_jobs)
     {
-        h->last_payload_packets = 0; h->last_payload_rerun = 0; h->last_payload_symbols = 0; h->last_payload_ms = 0.0f;
+        h->last_payload_packets = 0; h->last_payload_rerun = 0; h->last_payload_symbols = 0; h->last_payload_ms = 0.0f; h->last_payload_moved = 0; h->last_payload_rounds = 0;
         if (h->decoupled_policy == 0 || !walker_has_skip_variant(h->P) || tracing()) return false;
         if (h->decoupled_policy == 1) return true;
-        if (h->dec_backoff) { h->dec_backoff--; return false; }
+        if (h->dec_backoff) return false; // (counted down once per pass: count_jobs)
         const uint32_t full = resident_slots_alt() ? resident_slots_alt() : resident_slots();
         return 2u * (uint32_t)n_jobs <= full;
     }
     void set_skip_payload(bool on) { h->launch_skip = on; }
     int run_payload(std::vector<PayloadReq> &reqs) { return ::run_payload_pass(h, d_iq, reqs, st) == LORA_HIP_OK ? 0 : -1; }
-    void count_payload(uint32_t packets, uint32_t rerun)
+    void count_payload(uint32_t packets, uint32_t moved, uint32_t rerun)
     {
-        h->last_payload_packets += packets; h->last_payload_rerun += rerun;
+        h->last_payload_packets += packets; h->last_payload_rerun += rerun; h->last_payload_moved += moved;
         if (rerun) h->timing.slow_path_relaunches++;
-        if (h->decoupled_policy < 0 && packets >= 4u && 4u * rerun > packets) h->dec_backoff = 32; // more than a quarter run again: the complete kernels for a while
+        if (h->decoupled_policy < 0 && packets >= 4u && 4u * (rerun + moved) > packets) h->dec_backoff = 32; // more than a quarter left the zero-drift grid for good: the complete kernels for a while
         static const bool dbg = getenv("LORA_HIP_DEBUG") != nullptr;
-        if (dbg) fprintf(stderr, "[lora_hip] payload pass: %u packets, %u symbols, %.3f ms; %u packet(s) moved the symbol clock or ran out of data: their jobs run again by the complete kernels\n",
-                         packets, h->last_payload_symbols, h->last_payload_ms, rerun);
+        if (dbg) fprintf(stderr, "[lora_hip] payload pass: %u packets, %u symbol reads in %u round(s), %.3f ms; %u packet(s) ended off the zero-drift grid (their jobs split there), %u handed to the complete kernels\n",
+                         packets, h->last_payload_symbols, h->last_payload_rounds, h->last_payload_ms, moved, rerun);
     }
     RunOut &run_out(int which) { return h->run_out[which & 1]; }
     bool quiet_edges(const std::vector<StreamDesc> &streams, std::vector<std::vector<int64_t>> &edges)
@@ -795,7 +850,7 @@ struct DeviceEnv {
     int run_jobs_end(RunOut &out) { return ::run_jobs_end(h, out) == LORA_HIP_OK ? 0 : -1; }
     void publish(const AttemptRec &r, StreamDesc &sd) { ::publish(h, r, sd); }
     void append_trace(const RunOut &out, uint32_t job, uint32_t cap, int64_t base) { ::append_trace(h, out, job, cap, base); }
-    void count_jobs(uint32_t n) { h->timing.jobs += n; h->last_kernel_jobs = 0; } // (called once per pass, ahead of its main launch)
+    void count_jobs(uint32_t n) { h->timing.jobs += n; h->last_kernel_jobs = 0; if (h->dec_backoff) h->dec_backoff--; } // (called once per pass, ahead of its main launch)
     void count_probes(uint32_t n) { h->timing.probes += n; }
     void count_slow_path() { h->timing.slow_path_relaunches++; }
     void note_plan(bool burst_aware, size_t n_segs)
@@ -887,7 +942,7 @@ void lora_hip_destroy(lora_hip_decoder_t *h)
     if (h->d_up_ifreq) (void)hipFree(h->d_up_ifreq);
     if (h->d_down_ifreq) (void)hipFree(h->d_down_ifreq);
     if (h->d_up_ifreq_v) (void)hipFree(h->d_up_ifreq_v);
-    h->p_pay_off.release(); h->p_pay_desc.release(); h->p_pay_out.release(); h->d_fine.release();
+    h->p_pay_off.release(); h->p_pay_desc.release(); h->p_pay_out.release(); h->d_fine.release(); h->d_alt_shift.release(); h->d_alt_bins.release(); h->d_alt_fine.release();
     h->d_jobs.release(); h->d_results.release(); h->d_recs.release(); h->d_scratch.release();
     h->d_trace.release(); h->d_staging.release(); h->d_offsets.release(); h->d_bins.release();
     stream_pipe_release(h);
@@ -1888,10 +1943,12 @@ lora_hip_status lora_hip_last_plan(const lora_hip_decoder_t *h, uint32_t *burst_
 }
 
 // (the variant the last pass launched where the kernel exists in two workgroup sizes - walker3 SF9 / SF10: *_half with more jobs than CUs)
-lora_hip_status lora_hip_last_payload_pass(const lora_hip_decoder_t *h, uint32_t *packets, uint32_t *rerun, uint32_t *symbols, float *ms)
+lora_hip_status lora_hip_last_payload_pass(const lora_hip_decoder_t *h, uint32_t *packets, uint32_t *moved, uint32_t *rerun, uint32_t *rounds, uint32_t *symbols, float *ms)
 {
     if (!h) return LORA_HIP_ERR_ARG;
     if (packets) *packets = h->last_payload_packets;
+    if (moved) *moved = h->last_payload_moved;
+    if (rounds) *rounds = h->last_payload_rounds;
     if (rerun) *rerun = h->last_payload_rerun;
     if (symbols) *symbols = h->last_payload_symbols;
     if (ms) *ms = h->last_payload_ms;

@@ -305,7 +305,40 @@ int decode_begin(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
     if (segmenting && env.segment_symbols() == 0 && !no_plan && total > 2ull * seg) {
         std::vector<std::vector<int64_t>> edges;
         if (env.quiet_edges(streams, edges)) {
-            planned = plan_burst_segments(streams, edges, sps, slots, seg, cuts);
+            // a pass that will run decoupled wants one job per burst: header-only jobs cost an acquisition and a header each, whatever the packet's
+            // length, so nothing is gained by balancing them - and cuts at the gaps need no explicit probes (plan_burst_segments refuses with fewer
+            // bursts than workgroups, which is exactly when a pass is decoupled)
+            if (env.decoupled(1)) {
+                size_t nb = streams.size();
+                for (const auto &e : edges) nb += e.size();
+                if (edges.size() == streams.size() && env.decoupled(nb)) {
+                    // ... and stretches without a gap (back-to-back packets) are cut on the grid, as plan_burst_segments does
+                    cuts.assign(streams.size(), {});
+                    size_t n_segs = 0;
+                    for (size_t i = 0; i < streams.size(); i++) {
+                        int64_t prev = 0;
+                        static const uint64_t dsym = getenv("LORA_HIP_DEC_SEG_SYMBOLS") ? (uint64_t)atoi(getenv("LORA_HIP_DEC_SEG_SYMBOLS")) : 48u; // (48: config 4 at 2 s per pass 27.8 Gsamples/s; 32: 27.0, 64: 27.4, 96: 25.7)
+                        const uint64_t dseg = std::max<uint64_t>(dsym, 16u) * sps;
+                        auto grid_to = [&](int64_t b) {
+                            if (2u * (uint64_t)(b - prev) > 3u * dseg) {
+                                const uint64_t parts = ((uint64_t)(b - prev) + dseg - 1u) / dseg;
+                                for (uint64_t q = 1; q < parts; q++) cuts[i].push_back(prev + (int64_t)((uint64_t)(b - prev) * q / parts));
+                            }
+                        };
+                        for (int64_t c : edges[i]) {
+                            if (!(c > prev && (int64_t)streams[i].len - c > 8ll * sps)) continue;
+                            grid_to(c);
+                            cuts[i].push_back(c);
+                            prev = c;
+                        }
+                        grid_to((int64_t)streams[i].len);
+                        n_segs += cuts[i].size() + 1u;
+                    }
+                    planned = env.decoupled(n_segs);
+                    if (!planned) cuts.clear();
+                }
+            }
+            if (!planned) planned = plan_burst_segments(streams, edges, sps, slots, seg, cuts);
             // fewer bursts than slots, but the kernel also exists with half as many, larger workgroups (walker3 SF9 / SF10 as one or two per CU):
             // one wave of those
             const uint32_t alt = env.resident_slots_alt();

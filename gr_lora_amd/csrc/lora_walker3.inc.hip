@@ -1738,10 +1738,10 @@ __global__ __launch_bounds__(W3Geom<10>::T, W3Geom<10>::T512 ? 2 : 4) void walke
 __global__ __launch_bounds__(W3Geom<11>::T, W3Geom<11>::T512 ? 2 : 4) void walker3_kernel_sf11_grad(DevParams P, LaunchCfg C) { walker3_body<11, true>(P, C); }
 __global__ __launch_bounds__(W3Geom<12>::T, W3Geom<12>::T512 ? 2 : 4) void walker3_kernel_sf12_grad(DevParams P, LaunchCfg C) { walker3_body<12, true>(P, C); }
 
-// ---- symbol-level kernel: one group per symbol, for lora_hip_demod_symbols_device ------------------------------
+// ---- symbol-level kernel: one group per symbol, for lora_hip_demod_symbols_device and the payload pass -----------------
 template <int SF, bool GRAD, int HV = 0>
 __global__ __launch_bounds__((W3Geom<SF, HV>::T), (W3Geom<SF, HV>::T512 ? 2 : 4)) void demod_symbols_w3_kernel(DevParams P, const float2 *iq, const int64_t *offsets, uint32_t n,
-                                                                    uint32_t *bins, int32_t *fine, long long *stamps_out)
+                                                                    uint32_t *bins, int32_t *fine, long long *stamps_out, DemodAlt alt)
 {
     using G = W3Geom<SF, HV>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1750,22 +1750,56 @@ __global__ __launch_bounds__((W3Geom<SF, HV>::T), (W3Geom<SF, HV>::T512 ? 2 : 4)
     __syncthreads();
     int slot = 0;
     const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x / G::TG);
+    const W3DemodArgs DA{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode};
     for (uint32_t s0 = blockIdx.x * G::NG; s0 < n; s0 += gridDim.x * G::NG) {
         const bool valid = s0 + (uint32_t)grp < n;
         uint32_t b[G::NG];
         int32_t fs[G::NG];
         float en[G::NG];
         long long stamps[9];
-        if constexpr (GRAD) w3_demod_round_grad<SF, HV>(W3DemodArgs{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode}, L, iq + offsets[valid ? s0 + grp : s0], valid, false, slot, b, fs, en);
-        else w3_demod_round<SF, HV>(W3DemodArgs{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode}, L, iq + offsets[valid ? s0 + grp : s0], valid, false, slot, b, fs, en,
-                           stamps_out ? stamps : nullptr);
+        if constexpr (GRAD) w3_demod_round_grad<SF, HV>(DA, L, iq + offsets[valid ? s0 + grp : s0], valid, false, slot, b, fs, en);
+        else w3_demod_round<SF, HV>(DA, L, iq + offsets[valid ? s0 + grp : s0], valid, false, slot, b, fs, en, stamps_out ? stamps : nullptr);
         if (stamps_out && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && s0 == blockIdx.x * G::NG + gridDim.x * G::NG) // (second round of block 0: every wavefront's stamps)
             for (int i = 0; i < 9; i++) stamps_out[(threadIdx.x >> 6) * 9 + i] = stamps[i];
+        int32_t *fs_all = L.ws->sh.ibuf; // every group's d_fine_sync (the demodulator hands all groups' results to thread 0's wavefront only)
         if (threadIdx.x == 0) {
-            for (int g = 0; g < G::NG; g++)
+            for (int g = 0; g < G::NG; g++) {
                 if (s0 + (uint32_t)g < n) { bins[s0 + g] = b[g]; if (fine) fine[s0 + g] = fs[g]; }
+                fs_all[g] = fs[g];
+            }
         }
         __syncthreads();
+        if (alt.shift) { // second reads (DemodAlt): the successors of the symbols that moved the symbol clock, that far further on
+#pragma unroll
+            for (int g = 0; g < G::NG; g++) fs[g] = __builtin_amdgcn_readfirstlane(fs_all[g]);
+            bool any = false;
+            int64_t mine = -1; // this group's second window
+#pragma unroll
+            for (int g = 0; g < G::NG; g++) {
+                if (s0 + (uint32_t)g + 1u >= n || fs[g] == 0) continue; // (fs: uniform over the workgroup)
+                const int64_t o0 = offsets[s0 + g], o1 = offsets[s0 + g + 1];
+                const int64_t a = o1 + (int64_t)fs[g];
+                if (o1 != o0 + (int64_t)G::SPS || a < 0 || a > alt.max_start) continue;
+                any = true;
+                if (g == grp) mine = a;
+            }
+            if (any) {
+                uint32_t b2[G::NG];
+                int32_t f2[G::NG];
+                if constexpr (GRAD) w3_demod_round_grad<SF, HV>(DA, L, iq + (mine >= 0 ? mine : offsets[s0]), mine >= 0, false, slot, b2, f2, en);
+                else w3_demod_round<SF, HV>(DA, L, iq + (mine >= 0 ? mine : offsets[s0]), mine >= 0, false, slot, b2, f2, en, nullptr);
+                if (threadIdx.x == 0) {
+                    for (int g = 0; g < G::NG; g++) {
+                        if (s0 + (uint32_t)g + 1u >= n || fs[g] == 0) continue;
+                        const int64_t o0 = offsets[s0 + g], o1 = offsets[s0 + g + 1];
+                        const int64_t a = o1 + (int64_t)fs[g];
+                        if (o1 != o0 + (int64_t)G::SPS || a < 0 || a > alt.max_start) continue;
+                        alt.bins[s0 + g + 1] = b2[g]; alt.fine[s0 + g + 1] = f2[g]; alt.shift[s0 + g + 1] = fs[g];
+                    }
+                }
+                __syncthreads();
+            }
+        }
     }
 }
 

@@ -259,10 +259,12 @@ lora_hip_status lora_hip_last_timing(const lora_hip_decoder_t *h, lora_hip_timin
  * walker2_kernel_sf7/8[_grad] (wave per symbol), walker3_kernel_sf9..12[_grad] (workgroup per symbol), walker_kernel* (generic:
  * other decimations, LORA_HIP_NO_FAST).                                                                                        */
 const char     *lora_hip_walker_kernel_name(const lora_hip_decoder_t *h);
-/* The payload pass of the last pass when it ran decoupled (LORA_HIP_FLAG_NO_DECOUPLED above): packets whose payload it took, how many of them
- * were decoded again by the complete kernels, payload symbols demodulated, device time of its two kernels (part of lora_hip_timing_t.walker_ms);
- * all zero when the pass was not decoupled.                                                                                               */
-lora_hip_status lora_hip_last_payload_pass(const lora_hip_decoder_t *h, uint32_t *packets, uint32_t *rerun, uint32_t *symbols, float *ms);
+/* The payload pass of the last pass when it ran decoupled (LORA_HIP_FLAG_NO_DECOUPLED above): packets whose payload it took; how many of them
+ * ended off the zero-drift grid (their symbols moved the symbol clock by a net amount: the job is split there and probed like a segment boundary);
+ * how many it handed back to the complete kernels; rounds of symbol reads (1 + one per distinct clock offset met); symbol reads in all; device
+ * time of its kernels (part of lora_hip_timing_t.walker_ms).  All zero when the pass was not decoupled.                                  */
+lora_hip_status lora_hip_last_payload_pass(const lora_hip_decoder_t *h, uint32_t *packets, uint32_t *moved, uint32_t *rerun, uint32_t *rounds,
+                                           uint32_t *symbols, float *ms);
 
 /* How the last pass cut its streams into speculation segments (diagnostics): *burst_aware = 1 when the cuts were placed
  * in the gaps between bursts found by the energy-envelope pre-pass, 0 for the fixed grid (configured segment length,

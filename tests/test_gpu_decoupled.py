@@ -39,10 +39,15 @@ def test_decoupled_equals_ordinary_pass(sf, demod, monkeypatch):
     got, gi = _run(iq, offs, lens, demod, monkeypatch, "1", **kw)
     assert len(want) == 48 and wi["packets"] == 0 and not wi["kernel"].endswith("_skip")
     assert gi["kernel"].endswith("_skip"), gi
-    assert gi["packets"] >= 48 and gi["rerun"] == 0 and gi["symbols"] > 48 * 20, gi    # clean signal: no packet moves the symbol clock
+    # clean signal: a symbol with bin 0 moves the symbol clock by +1 and its successor moves it back - one more round of reads, nothing handed back
+    assert gi["packets"] >= 48 and gi["rerun"] == 0 and gi["moved"] == 0 and gi["rounds"] <= 2 and gi["symbols"] > 48 * 20, gi
     assert got == want
     if demod == 2:
         assert [g[0][15:] for g in got if g[1] == 0] == expect[0]
+    if sf == 9:     # without the second reads every move of the symbol clock is a round of its own: the +1 / -1 pairs need three
+        monkeypatch.setenv("LORA_HIP_NO_SECOND_READS", "1")
+        got2, g2 = _run(iq, offs, lens, demod, monkeypatch, "1", **kw)
+        assert got2 == want and g2["rounds"] >= gi["rounds"] and g2["rerun"] == 0, (gi, g2)
 
 
 @pytest.mark.parametrize("sf,cr", [(9, 1), (9, 4), (10, 2), (11, 1), (11, 3), (12, 1), (12, 4)])
@@ -67,14 +72,16 @@ def _drifting(sf, n, seed, ppm=60e-6, snr_db=42.0):
 
 @pytest.mark.parametrize("sf,demod", [(9, 2), (9, 0), (10, 2)])
 def test_packets_that_move_the_symbol_clock_are_decoded_again(sf, demod, monkeypatch):
-    """a transmitter clock 60 ppm off + noise: fine_sync moves the symbol clock inside most payloads; those packets (and what their jobs found behind
-    them) come from the complete kernels' re-run - the output is the ordinary pass's, which tests/test_gpu_a16.py holds to the oracle's traces"""
+    """a transmitter clock 60 ppm off + noise: fine_sync moves the symbol clock inside most payloads, for good.  Packets the payload pass follows to
+    their end leave their job split at the packet's true end (a probe from there decides what stands of the job's scan behind it); packets that drift
+    through more offsets than the pass reads are decoded by the complete kernels.  Either way the output is the ordinary pass's, which
+    tests/test_gpu_a16.py holds to the oracle's traces."""
     cfg, iq = _drifting(sf, 16, 7 + sf)
     offs, lens = [0], [iq.size]
     want, _ = _run(iq, offs, lens, demod, monkeypatch, "0", sf=sf, cr=4)
     got, gi = _run(iq, offs, lens, demod, monkeypatch, "1", sf=sf, cr=4)
     assert len(want) >= 12
-    assert gi["packets"] > 0 and gi["rerun"] > 0, gi
+    assert gi["packets"] > 0 and gi["moved"] + gi["rerun"] > 0 and gi["rounds"] >= 2, gi
     assert got == want
 
 
@@ -85,7 +92,7 @@ def test_data_ending_inside_a_payload_and_streaming(monkeypatch, oracle_mod):
     cut = iq[: iq.size - 25 * cfg.sps]
     want, _ = _run(cut, [0], [cut.size], 2, monkeypatch, "0", sf=9, cr=4)
     got, gi = _run(cut, [0], [cut.size], 2, monkeypatch, "1", sf=9, cr=4)
-    assert got == want and len(want) == 11 and gi["rerun"] >= 1, gi
+    assert got == want and len(want) == 11 and gi["packets"] >= 12 and gi["rerun"] == 0, gi
     res = {}
     for mode in ("0", "1"):
         monkeypatch.setenv("LORA_HIP_DECOUPLED", mode)

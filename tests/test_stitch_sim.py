@@ -28,13 +28,13 @@ def sim(oracle_mod):
     L.stitch_sim_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int,
                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
 
-    def run(iq, sf, ctor_cr=4, demod=2, reduced=False, seg=0, slots=512, tails=True, plan=False, early=False, decoupled=False, force_rerun=0):
+    def run(iq, sf, ctor_cr=4, demod=2, reduced=False, seg=0, slots=512, tails=True, plan=False, early=False, decoupled=False, force_rerun=0, auto=False):
         a = np.ascontiguousarray(iq, dtype=np.complex64)
         out = np.zeros(1 << 20, dtype=np.uint8)
         lens = np.zeros(4096, dtype=np.int32)
         hp = np.zeros(4096, dtype=np.int64)
         st = np.zeros(12, dtype=np.uint32)
-        mode = int(tails) | (2 if plan else 0) | (4 if early else 0) | (8 if decoupled else 0) | ((force_rerun & 0xff) << 8)
+        mode = int(tails) | (2 if plan else 0) | (4 if early else 0) | (8 if decoupled else 0) | (16 if auto else 0) | ((force_rerun & 0xff) << 8)
         n = L.stitch_sim_decode(a.ctypes.data, a.size, sf, ctor_cr, 1, int(reduced), demod, seg, slots, mode, out.ctypes.data, out.size,
                                 lens.ctypes.data, hp.ctypes.data, 4096, st.ctypes.data)
         assert n >= 0, n
@@ -321,3 +321,19 @@ def test_decoupled_pass_cut_mid_packet_and_other_coding_rates(sim, oracle_mod):
             ref = sim(iq, 7, ctor_cr=ctor, seg=seg, slots=24)
             assert got == want and gpos == wpos, (cr, seg, stats)
             assert stats["incomplete"] == ref[2]["incomplete"] == 1 and stats["pending"] >= 1, (stats, ref[2])
+
+
+def test_decoupled_pass_one_job_per_burst(sim, oracle_mod):
+    """the device's per-pass rule (jobs for at most half the workgroup slots): with the gaps between bursts known, a decoupled pass gets one job per
+    burst - every cut in a gap, no explicit probe, no serial fallback - and a pass with more bursts than that stays an ordinary one"""
+    cfg = synth.TxConfig(sf=7, cr=4)
+    rng = np.random.default_rng(11)
+    payloads = [bytes(rng.integers(0, 256, int(rng.integers(8, 48)), dtype=np.uint8)) for _ in range(20)]
+    st = synth.build_stream(payloads, cfg, rng=rng, gap_symbols=(3.0, 9.0))
+    want, wpos = _serial(oracle_mod, st.iq, 7)
+    got, gpos, stats = sim(st.iq, 7, slots=128, plan=True, early=True, auto=True)
+    assert got == want and gpos == wpos, stats
+    # (bursts longer than 72 symbols are cut on a 48-symbol grid as well: those cuts fall inside packets and may cost an explicit probe)
+    assert stats["payload"] >= 20 and 19 <= stats["jobs"] <= 64 and stats["probes"] <= 24 and stats["slow"] == 0 and stats["planned"] == 1, stats
+    got, gpos, stats = sim(st.iq, 7, slots=24, plan=True, early=True, auto=True)     # 20 bursts for 24 slots: not a decoupled pass
+    assert got == want and gpos == wpos and stats["payload"] == 0, stats

@@ -21,7 +21,9 @@ LORA_HIP_STRICT_SYNC=0 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 >
 python bench.py --path work 2>/dev/null | tail -1 > gpurun_out/work_line.json
 python bench.py --config 4 --steps 30 --warmup 5 2>/dev/null | tail -1 > gpurun_out/cfg4_line.json
 python bench.py --config 4 --seconds 8 --steps 30 --warmup 5 2>/dev/null | tail -1 > gpurun_out/cfg4_8s_line.json
-python bench.py --config 4 --seconds 2 --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/cfg4_2s_line.json
+python bench.py --config 4 --seconds 2 --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/cfg4_2s_line.json                               # few jobs for the device: a decoupled pass (header-only jobs + payload pass)
+LORA_HIP_DECOUPLED=0 python bench.py --config 4 --seconds 2 --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/cfg4_2s_ordinary_line.json   # ... and the same pass by the complete kernels
+PROFILE_STEPS=20 tools/profile_round.sh cfg4_2s --config 4 --seconds 2   # kernel stats of the decoupled pass: walker3_kernel_sf9_skip, demod_symbols_w3_kernel, payload_chain_kernel
 python bench.py --demod 0 2>/dev/null | tail -1 > gpurun_out/default_grad_line.json
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/torchrun1_line.json
 python bench.py --streams 1 --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/streams1_line.json
