@@ -199,6 +199,9 @@ struct lora_hip_decoder {
     PinnedBuf<PayloadOut> p_pay_out;
     DevBuf<int32_t> d_fine, d_alt_shift, d_alt_fine;
     DevBuf<uint32_t> d_alt_bins;
+    hipStream_t pay_stream = nullptr;  // the payload pass runs here, beside the explicit probes of the same pass on the caller's stream
+    hipEvent_t ev_pay0 = nullptr, ev_pay1 = nullptr, ev_pay_done = nullptr;
+    struct PayState { std::vector<uint32_t> active; size_t used = 0, cap_sym = 0, n_sym = 0; int round = 0; float ms = 0.0f; bool open = false; } pay;
 };
 
 namespace {
@@ -683,87 +686,113 @@ lora_hip_status quiet_edges(lora_hip_decoder *h, const float2 *d_iq, const std::
 // pairs there are; a clock that drifts steadily needs a round per sample of drift and is handed back after kPayloadHyp - 1 of them (kPayloadUnresolved:
 // the complete kernels decode that packet).  Offsets go up in one copy per round; descriptors are read from and results written to page-locked
 // host memory directly, as the walkers' jobs and records are.
-lora_hip_status run_payload_pass(lora_hip_decoder *h, const float2 *d_iq, std::vector<PayloadReq> &reqs, hipStream_t st)
+// (In two halves: payload_pass_begin puts the first round on the handle's payload stream and returns - the scheduler launches the pass's explicit
+// probes on the caller's stream meanwhile, the device has room for both - payload_pass_end waits, reads the walks' results and runs the further
+// rounds.  The IQ is known to be complete: the pass's main launch has read it and has been waited for.)
+static bool payload_fits(const PayloadReq &q, int64_t sps, int64_t shift, uint32_t from, uint32_t *to)
+{ // symbols [from, *to) of packet q read `shift` samples behind their zero-drift positions lie inside the data (:91)
+    const int64_t room = (int64_t)q.stream_len - 2 * sps - (q.start + shift); // symbol j fits iff j sps <= room
+    uint32_t n = 0;
+    if (q.start + shift >= 0 && room >= 0) n = (uint32_t)std::min<int64_t>(room / sps + 1, (int64_t)q.n_walk);
+    *to = std::max(n, from);
+    return true;
+}
+
+static lora_hip_status payload_launch_round(lora_hip_decoder *h, const float2 *d_iq, std::vector<PayloadReq> &reqs)
 {
+    lora_hip_decoder::PayState &ps = h->pay;
     const int64_t sps = (int64_t)h->P.sps;
     const size_t np = reqs.size();
-    if (np == 0) return LORA_HIP_OK;
-    size_t total = 0;
-    for (const PayloadReq &q : reqs) total += q.n_walk;
-    const size_t cap_sym = total * (size_t)kPayloadHyp;
-    HIP_TRY(h, h->p_pay_off.reserve(total));
-    HIP_TRY(h, h->p_pay_desc.reserve(2 * np)); // [0, np): one per packet, kept across the rounds; [np, 2 np): the round's launch list
-    HIP_TRY(h, h->p_pay_out.reserve(np));
-    HIP_TRY(h, h->d_offsets.reserve(total));
-    HIP_TRY(h, h->d_bins.reserve(cap_sym));
-    HIP_TRY(h, h->d_fine.reserve(cap_sym));
-    HIP_TRY(h, h->d_alt_shift.reserve(cap_sym));
-    HIP_TRY(h, h->d_alt_bins.reserve(cap_sym));
-    HIP_TRY(h, h->d_alt_fine.reserve(cap_sym));
+    const hipStream_t st = h->pay_stream;
+    PayloadDesc *descs = h->p_pay_desc.p, *launch = h->p_pay_desc.p + np;
     const bool no_alt = getenv("LORA_HIP_NO_SECOND_READS") != nullptr; // diagnostics / tests: every move of the symbol clock costs a round
     int64_t buf_end = 0; // the pass's streams end here at the latest: second reads stay inside the buffer (whether they stay inside their stream is the walk's check)
     for (const PayloadReq &q : reqs) buf_end = std::max<int64_t>(buf_end, (int64_t)(q.stream_off + q.stream_len));
     const DemodAlt alt{no_alt ? nullptr : h->d_alt_shift.p, h->d_alt_bins.p, h->d_alt_fine.p, buf_end - 2 * sps};
-    PayloadDesc *descs = h->p_pay_desc.p, *launch = h->p_pay_desc.p + np;
-    // symbols [from, to) of packet q read `shift` samples behind their zero-drift positions fit into the data (:91)
-    auto fit_to = [&](const PayloadReq &q, int64_t shift) -> uint32_t {
-        const int64_t room = (int64_t)q.stream_len - 2 * sps - (q.start + shift); // symbol j fits iff j sps <= room
-        if (q.start + shift < 0 || room < 0) return 0u;
-        const int64_t n = room / sps + 1;
-        return (uint32_t)std::min<int64_t>(n, (int64_t)q.n_walk);
-    };
-    std::vector<uint32_t> active(np);
+    // this round's reads: for every active packet the symbols from `at` on, `shift` behind their zero-drift positions
+    size_t n_sym = 0;
+    for (uint32_t i : ps.active) {
+        PayloadReq &q = reqs[i];
+        PayloadDesc &d = descs[i];
+        const PayloadOut &o = h->p_pay_out.p[i];
+        const uint32_t from = ps.round == 0 ? 0u : o.at;
+        const int32_t shift = ps.round == 0 ? 0 : o.shift;
+        uint32_t to = from;
+        payload_fits(q, sps, shift, from, &to);
+        const uint32_t hh = d.n_hyp++;
+        d.hyp_shift[hh] = shift; d.hyp_from[hh] = from; d.hyp_to[hh] = to;
+        d.hyp_base[hh] = (int32_t)(ps.used + n_sym) - (int32_t)from;
+        for (uint32_t j = from; j < to; j++) h->p_pay_off.p[n_sym++] = (int64_t)q.stream_off + q.start + (int64_t)j * sps + shift;
+    }
+    if (ps.used + n_sym > ps.cap_sym) return fail(h, LORA_HIP_ERR_INTERNAL, "payload pass: more reads than symbols x rounds");
+    for (size_t a = 0; a < ps.active.size(); a++) launch[a] = descs[ps.active[a]];
+    HIP_TRY(h, hipEventRecord(h->ev_pay0, st));
+    if (n_sym) {
+        HIP_TRY(h, hipMemcpyAsync(h->d_offsets.p, h->p_pay_off.p, n_sym * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        DemodAlt ar{alt.shift ? alt.shift + ps.used : nullptr, alt.bins + ps.used, alt.fine + ps.used, alt.max_start};
+        if (ar.shift) HIP_TRY(h, hipMemsetAsync(ar.shift, 0, n_sym * sizeof(int32_t), st));
+        if (launch_demod_symbols(h->P, d_iq, h->d_offsets.p, (uint32_t)n_sym, (int)h->P.demod_mode, h->d_bins.p + ps.used, h->d_fine.p + ps.used, nullptr, st, &ar) != 0)
+            return fail(h, LORA_HIP_ERR_HIP, "payload pass: symbol launch failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    // (launch entry a writes PayloadOut[a]; payload_pass_end spreads them to the packets' own slots)
+    if (launch_payload_chain(h->P, h->d_bins.p, h->d_fine.p, alt, launch, h->p_pay_out.p, (uint32_t)ps.active.size(), st) != 0)
+        return fail(h, LORA_HIP_ERR_HIP, "payload pass: chain launch failed: %s", hipGetErrorString(hipGetLastError()));
+    HIP_TRY(h, hipEventRecord(h->ev_pay1, st));
+    HIP_TRY(h, hipEventRecord(h->ev_pay_done, st));
+    ps.n_sym = n_sym;
+    return LORA_HIP_OK;
+}
+
+lora_hip_status payload_pass_begin(lora_hip_decoder *h, const float2 *d_iq, std::vector<PayloadReq> &reqs)
+{
+    lora_hip_decoder::PayState &ps = h->pay;
+    ps = lora_hip_decoder::PayState{};
+    const size_t np = reqs.size();
+    if (np == 0) return LORA_HIP_OK;
+    size_t total = 0;
+    for (const PayloadReq &q : reqs) total += q.n_walk;
+    ps.cap_sym = total * (size_t)kPayloadHyp;
+    HIP_TRY(h, h->p_pay_off.reserve(total));
+    HIP_TRY(h, h->p_pay_desc.reserve(2 * np)); // [0, np): one per packet, kept across the rounds; [np, 2 np): the round's launch list
+    HIP_TRY(h, h->p_pay_out.reserve(np));
+    HIP_TRY(h, h->d_offsets.reserve(total));
+    HIP_TRY(h, h->d_bins.reserve(ps.cap_sym));
+    HIP_TRY(h, h->d_fine.reserve(ps.cap_sym));
+    HIP_TRY(h, h->d_alt_shift.reserve(ps.cap_sym));
+    HIP_TRY(h, h->d_alt_bins.reserve(ps.cap_sym));
+    HIP_TRY(h, h->d_alt_fine.reserve(ps.cap_sym));
+    const int64_t sps = (int64_t)h->P.sps;
+    ps.active.resize(np);
     for (size_t i = 0; i < np; i++) {
         PayloadReq &q = reqs[i];
         q.status = kPayloadUnresolved; q.end_shift = 0; q.frame_len = 0;
-        PayloadDesc &d = descs[i];
+        PayloadDesc &d = h->p_pay_desc.p[i];
         d = PayloadDesc{};
         d.n_walk = q.n_walk; d.sk = q.sk;
         d.room = (int64_t)q.stream_len - 2 * sps - q.start;
-        active[i] = (uint32_t)i;
+        ps.active[i] = (uint32_t)i;
     }
-    size_t used = 0; // entries of d_bins / d_fine handed out
-    float ms_total = 0.0f;
-    for (int round = 0; round < kPayloadHyp && !active.empty(); round++) {
-        // this round's reads: for every active packet the symbols from `at` on, `shift` behind their zero-drift positions
-        size_t n_sym = 0;
-        for (uint32_t i : active) {
-            PayloadReq &q = reqs[i];
-            PayloadDesc &d = descs[i];
-            const PayloadOut &o = h->p_pay_out.p[i];
-            const uint32_t from = round == 0 ? 0u : o.at;
-            const int32_t shift = round == 0 ? 0 : o.shift;
-            const uint32_t to = std::max(fit_to(q, shift), from);
-            const uint32_t hh = d.n_hyp++;
-            d.hyp_shift[hh] = shift; d.hyp_from[hh] = from; d.hyp_to[hh] = to;
-            d.hyp_base[hh] = (int32_t)(used + n_sym) - (int32_t)from;
-            for (uint32_t j = from; j < to; j++) h->p_pay_off.p[n_sym++] = (int64_t)q.stream_off + q.start + (int64_t)j * sps + shift;
-        }
-        if (used + n_sym > cap_sym) break; // (cannot happen: at most kPayloadHyp reads of each symbol)
-        for (size_t a = 0; a < active.size(); a++) launch[a] = descs[active[a]];
-        HIP_TRY(h, hipEventRecord(h->ev0, st));
-        if (n_sym) {
-            HIP_TRY(h, hipMemcpyAsync(h->d_offsets.p, h->p_pay_off.p, n_sym * sizeof(int64_t), hipMemcpyHostToDevice, st));
-            DemodAlt ar{alt.shift ? alt.shift + used : nullptr, alt.bins + used, alt.fine + used, alt.max_start};
-            if (ar.shift) HIP_TRY(h, hipMemsetAsync(ar.shift, 0, n_sym * sizeof(int32_t), st));
-            if (launch_demod_symbols(h->P, d_iq, h->d_offsets.p, (uint32_t)n_sym, (int)h->P.demod_mode, h->d_bins.p + used, h->d_fine.p + used, nullptr, st, &ar) != 0)
-                return fail(h, LORA_HIP_ERR_HIP, "payload pass: symbol launch failed: %s", hipGetErrorString(hipGetLastError()));
-        }
-        // (the walks' results land at the packets' own slots: launch entry a writes PayloadOut[a]; copied to slot active[a] below)
-        if (launch_payload_chain(h->P, h->d_bins.p, h->d_fine.p, alt, launch, h->p_pay_out.p, (uint32_t)active.size(), st) != 0)
-            return fail(h, LORA_HIP_ERR_HIP, "payload pass: chain launch failed: %s", hipGetErrorString(hipGetLastError()));
-        HIP_TRY(h, hipEventRecord(h->ev1, st));
-        HIP_TRY(h, hipEventRecord(h->ev_done, st));
-        HIP_TRY(h, hipEventSynchronize(h->ev_done));
-        used += n_sym;
-        h->last_payload_symbols += (uint32_t)n_sym;
+    ps.open = true;
+    return payload_launch_round(h, d_iq, reqs);
+}
+
+lora_hip_status payload_pass_end(lora_hip_decoder *h, const float2 *d_iq, std::vector<PayloadReq> &reqs)
+{
+    lora_hip_decoder::PayState &ps = h->pay;
+    if (!ps.open) return LORA_HIP_OK;
+    ps.open = false;
+    for (;;) {
+        HIP_TRY(h, hipEventSynchronize(h->ev_pay_done));
+        ps.used += ps.n_sym;
+        h->last_payload_symbols += (uint32_t)ps.n_sym;
+        h->last_payload_rounds++;
         float ms = 0.0f;
-        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-        ms_total += ms;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_pay0, h->ev_pay1));
+        ps.ms += ms;
         // results sit at launch order: spread them to the packets' slots from the back (active[a] >= a)
-        for (size_t a = active.size(); a-- > 0;) if (active[a] != a) h->p_pay_out.p[active[a]] = h->p_pay_out.p[a];
+        for (size_t a = ps.active.size(); a-- > 0;) if (ps.active[a] != a) h->p_pay_out.p[ps.active[a]] = h->p_pay_out.p[a];
         std::vector<uint32_t> next;
-        for (uint32_t i : active) {
+        for (uint32_t i : ps.active) {
             PayloadReq &q = reqs[i];
             const PayloadOut &o = h->p_pay_out.p[i];
             if (o.result == kWalkComplete && o.frame_len >= 3u && o.frame_len <= (uint32_t)sizeof q.frame) {
@@ -771,16 +800,19 @@ lora_hip_status run_payload_pass(lora_hip_decoder *h, const float2 *d_iq, std::v
                 std::memcpy(q.frame, o.frame, o.frame_len);
             } else if (o.result == kWalkOutOfData) {
                 q.status = kPayloadOutOfData;
-            } else if (o.result == kWalkNeedShift && descs[i].n_hyp < (uint32_t)kPayloadHyp) {
+            } else if (o.result == kWalkNeedShift && h->p_pay_desc.p[i].n_hyp < (uint32_t)kPayloadHyp) {
                 next.push_back(i);
             } // else: stays kPayloadUnresolved
         }
-        active.swap(next);
-        h->last_payload_rounds++;
+        ps.active.swap(next);
+        ps.round++;
+        if (ps.active.empty() || ps.round >= kPayloadHyp) break;
+        const lora_hip_status s = payload_launch_round(h, d_iq, reqs);
+        if (s != LORA_HIP_OK) return s;
     }
-    h->last_payload_ms += ms_total;
-    h->timing.walker_ms += ms_total;       // (the pass's device time: the header-only walkers and the payload pass's kernels)
-    h->timing.total_device_ms += ms_total;
+    h->last_payload_ms += ps.ms;
+    h->timing.walker_ms += ps.ms;       // (the pass's device time: the header-only walkers and the payload pass's kernels)
+    h->timing.total_device_ms += ps.ms;
     h->timing.walker_launches += 2;
     return LORA_HIP_OK;
 }
@@ -812,8 +844,9 @@ struct DeviceEnv {
         static const bool off = getenv("LORA_HIP_NO_EARLY_PROBE") != nullptr;
         return !off && h->P.use_fast && h->P.decim == 8u && walker3_covers(h->P.sf);
     }
-    // Decoupled pass: worth it when the launch leaves most of the device idle (a packet's symbols are a serial chain on one CU: the pass lasts as long
-    // as its longest packet, however few there are) and the traffic does not keep moving the symbol clock (such packets are run again whole).
+    // Decoupled pass: worth it while the jobs fit the device at once (a packet's symbols are a serial chain on one CU: the pass lasts as long as its
+    // longest job, however few there are - header-only jobs are short whatever the packet's length, and their payloads fill the CUs the jobs leave
+    // idle) and the traffic does not keep moving the symbol clock for good (such packets cost a probe each, or are run again whole).
     bool decoupled(size_t n_jobs)
     {
         h->last_payload_packets = 0; h->last_payload_rerun = 0; h->last_payload_symbols = 0; h->last_payload_ms = 0.0f; h->last_payload_moved = 0; h->last_payload_rounds = 0;
@@ -821,10 +854,12 @@ struct DeviceEnv {
         if (h->decoupled_policy == 1) return true;
         if (h->dec_backoff) return false; // (counted down once per pass: count_jobs)
         const uint32_t full = resident_slots_alt() ? resident_slots_alt() : resident_slots();
-        return 2u * (uint32_t)n_jobs <= full;
+        static const uint32_t fill = getenv("LORA_HIP_DEC_MAX_FILL") ? (uint32_t)atoi(getenv("LORA_HIP_DEC_MAX_FILL")) : 100u; // percent of the workgroup slots (config 4, 8 s per pass: 54.5 Gsamples/s ordinary, 76.0 decoupled with ~200 jobs)
+        return 100u * (uint32_t)n_jobs <= fill * full;
     }
     void set_skip_payload(bool on) { h->launch_skip = on; }
-    int run_payload(std::vector<PayloadReq> &reqs) { return ::run_payload_pass(h, d_iq, reqs, st) == LORA_HIP_OK ? 0 : -1; }
+    int run_payload_begin(std::vector<PayloadReq> &reqs) { return ::payload_pass_begin(h, d_iq, reqs) == LORA_HIP_OK ? 0 : -1; }
+    int run_payload_end(std::vector<PayloadReq> &reqs) { return ::payload_pass_end(h, d_iq, reqs) == LORA_HIP_OK ? 0 : -1; }
     void count_payload(uint32_t packets, uint32_t moved, uint32_t rerun)
     {
         h->last_payload_packets += packets; h->last_payload_rerun += rerun; h->last_payload_moved += moved;
@@ -919,7 +954,9 @@ lora_hip_status lora_hip_create(const lora_hip_config_t *cfg, lora_hip_decoder_t
     if (s == LORA_HIP_OK && (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess || hipEventCreate(&h->ev_done) != hipSuccess ||
                              hipEventCreate(&h->ev_pre0) != hipSuccess || hipEventCreate(&h->ev_pre1) != hipSuccess ||
                              hipEventCreateWithFlags(&h->ev_dep, hipEventDisableTiming) != hipSuccess ||
-                             hipStreamCreateWithFlags(&h->pre_stream, hipStreamNonBlocking) != hipSuccess))
+                             hipStreamCreateWithFlags(&h->pre_stream, hipStreamNonBlocking) != hipSuccess ||
+                             hipStreamCreateWithFlags(&h->pay_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&h->ev_pay0) != hipSuccess ||
+                             hipEventCreate(&h->ev_pay1) != hipSuccess || hipEventCreate(&h->ev_pay_done) != hipSuccess))
         s = LORA_HIP_ERR_HIP;
     if (s != LORA_HIP_OK) { lora_hip_destroy(h); return s; }
     h->stream_cr = h->P.ctor_cr;
@@ -948,9 +985,10 @@ void lora_hip_destroy(lora_hip_decoder_t *h)
     stream_pipe_release(h);
     h->p_jobs.release(); h->p_res.release(); h->p_recs.release();
     h->d_balance.release(); h->d_env_E.release(); h->d_env_buf.release(); h->p_env_streams.release(); h->p_env_buf.release();
-    for (hipEvent_t e : {h->ev0, h->ev1, h->ev_done, h->ev_pre0, h->ev_pre1, h->ev_dep})
+    for (hipEvent_t e : {h->ev0, h->ev1, h->ev_done, h->ev_pre0, h->ev_pre1, h->ev_dep, h->ev_pay0, h->ev_pay1, h->ev_pay_done})
         if (e) (void)hipEventDestroy(e);
     if (h->pre_stream) (void)hipStreamDestroy(h->pre_stream);
+    if (h->pay_stream) (void)hipStreamDestroy(h->pay_stream);
     delete h;
 }
 

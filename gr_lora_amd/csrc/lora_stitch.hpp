@@ -15,7 +15,7 @@
 //   bool early_probe();   (the jobs record their FIND_SFD entry states and their tail probes may stop behind the first one: Job.tail_stop_sfd)
 //   bool decoupled(size_t n_jobs);   (run this pass's segment jobs header-only and the payloads in the symbol-parallel payload pass)
 //   void set_skip_payload(bool);     (the launches that follow run the kernels' header-only variant, LaunchCfg.skip_payload)
-//   int  run_payload(std::vector<PayloadReq> &);   (0 = ok: clean / frame of every request filled in)   void count_payload(uint32_t packets, uint32_t moved, uint32_t rerun);
+//   int  run_payload_begin(std::vector<PayloadReq> &) / run_payload_end(same);   (0 = ok; launch / wait: status, end_shift and frame of every request filled in)   void count_payload(uint32_t packets, uint32_t moved, uint32_t rerun);
 #pragma once
 #include <algorithm>
 #include <chrono>
@@ -300,7 +300,7 @@ int decode_begin(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
 
     // auto mode on a batch worth cutting up: look for the gaps between bursts and plan the cuts around them
     std::vector<std::vector<int64_t>> cuts;
-    bool planned = false;
+    bool planned = false, balanced = false; // balanced: plan_burst_segments' plan - at least as many bursts as workgroups, every job whole packets
     static const bool no_plan = getenv("LORA_HIP_NO_BURST_PLAN") != nullptr;
     if (segmenting && env.segment_symbols() == 0 && !no_plan && total > 2ull * seg) {
         std::vector<std::vector<int64_t>> edges;
@@ -317,8 +317,8 @@ int decode_begin(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
                     size_t n_segs = 0;
                     for (size_t i = 0; i < streams.size(); i++) {
                         int64_t prev = 0;
-                        static const uint64_t dsym = getenv("LORA_HIP_DEC_SEG_SYMBOLS") ? (uint64_t)atoi(getenv("LORA_HIP_DEC_SEG_SYMBOLS")) : 48u; // (48: config 4 at 2 s per pass 27.8 Gsamples/s; 32: 27.0, 64: 27.4, 96: 25.7)
-                        const uint64_t dseg = std::max<uint64_t>(dsym, 16u) * sps;
+                        static const uint64_t dsym = getenv("LORA_HIP_DEC_SEG_SYMBOLS") ? (uint64_t)atoi(getenv("LORA_HIP_DEC_SEG_SYMBOLS")) : 24u; // (config 4 at 2 s per pass: 24 symbols 48.0 Gsamples/s, 32: 46.1, 16: 38.3 - the scan for preambles is what a header-only job spends most of its time on, and short segments spread it over the idle CUs)
+                        const uint64_t dseg = std::max<uint64_t>(dsym, 8u) * sps;
                         auto grid_to = [&](int64_t b) {
                             if (2u * (uint64_t)(b - prev) > 3u * dseg) {
                                 const uint64_t parts = ((uint64_t)(b - prev) + dseg - 1u) / dseg;
@@ -338,13 +338,13 @@ int decode_begin(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
                     if (!planned) cuts.clear();
                 }
             }
-            if (!planned) planned = plan_burst_segments(streams, edges, sps, slots, seg, cuts);
+            if (!planned) balanced = planned = plan_burst_segments(streams, edges, sps, slots, seg, cuts);
             // fewer bursts than slots, but the kernel also exists with half as many, larger workgroups (walker3 SF9 / SF10 as one or two per CU):
             // one wave of those
             const uint32_t alt = env.resident_slots_alt();
             if (!planned && alt && alt < slots) {
                 const uint64_t seg_alt = std::max<uint64_t>(64ull * sps, (total + alt - alt / 16u - 1) / (alt - alt / 16u));
-                planned = plan_burst_segments(streams, edges, sps, alt, seg_alt, cuts);
+                balanced = planned = plan_burst_segments(streams, edges, sps, alt, seg_alt, cuts);
             }
         }
     }
@@ -399,9 +399,12 @@ int decode_begin(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
     ctx.rpj1 = recs_for(max_span, sps) + (segmenting ? ctx.rpj2 : 0u);
     ctx.trace_cap = tracing ? (uint32_t)std::min<uint64_t>(2ull * (max_span / sps) + 64ull, 1ull << 22) : 0u;
     env.count_jobs((uint32_t)jobs.size());
-    // Few jobs for the device (a gateway's short pass: a handful of packets per channel): a packet's symbols are a serial chain on ONE CU while
-    // most CUs idle.  Decoupled pass: the jobs stop behind every header and skip the payload, whose symbols the payload pass demodulates all at once.
-    ctx.decoupled = segmenting && env.decoupled(jobs.size());
+    // Decoupled pass: the jobs stop behind every header and skip the payload, whose symbols the payload pass demodulates all at once.  It pays
+    // wherever the ordinary pass leaves the device short of work or makes it do work twice: few packets (a packet's symbols are a serial chain on ONE
+    // CU, the others idle), or continuous traffic cut on the grid (every job first scans the rest of a packet another job decodes).  It does not pay
+    // for the balanced plan - bursty traffic with at least a burst per workgroup, every job whole packets: there all CUs demodulate payload already
+    // (BASELINE config 3, 256 packets: SF9 -8 %, SF12 -1 % decoupled; config 4: +100 % at 4 s per pass, +40 % at 8 s, +14 % at 32 s).
+    ctx.decoupled = segmenting && !balanced && env.decoupled(jobs.size());
     env.set_skip_payload(ctx.decoupled);
     ctx.tp0 = std::chrono::steady_clock::now();
     const int s = env.run_jobs_begin(jobs, ctx.rpj1, ctx.trace_cap, env.run_out(0)); // (result holders are kept by the environment between calls)
@@ -422,13 +425,24 @@ int decode_begin(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
 //  * Unresolved: the rest of the job is run again from that packet's header by the complete kernels (Job.start_at_header, same limits, same tail
 //    probe), all such jobs in one launch, and spliced in.
 // What the stitch then sees are ordinary records, jobs and segments.
-template <class Env>
-int payload_round(Env &env, const std::vector<StreamDesc> &streams, PassCtx &ctx, RunOut &R1)
-{
-    const uint32_t sps = env.sps();
+// (In two halves, so that the pass's explicit probes run while the device works on the payloads: payload_begin hands the requests to the payload
+// pass and returns; payload_end takes the results and re-lays the pass.  It returns 1 when jobs were split, cut short or run again - the probes
+// planned meanwhile are then planned again.)
+struct PayloadRound {
     struct Ref { size_t k; uint32_t a; };
     std::vector<Ref> refs;
     std::vector<PayloadReq> reqs;
+    bool open = false;
+};
+
+template <class Env>
+int payload_begin(Env &env, const std::vector<StreamDesc> &streams, const PassCtx &ctx, const RunOut &R1, PayloadRound &pr)
+{
+    const uint32_t sps = env.sps();
+    typedef PayloadRound::Ref Ref;
+    std::vector<Ref> &refs = pr.refs;
+    std::vector<PayloadReq> &reqs = pr.reqs;
+    refs.clear(); reqs.clear(); pr.open = false;
     for (size_t k = 0; k < ctx.jobs.size(); k++) {
         const uint32_t nall = std::min(std::min(R1.res[k].n_attempts, R1.cap), R1.rpj);
         const StreamDesc &sd = streams[ctx.segs[k].stream];
@@ -446,8 +460,20 @@ int payload_round(Env &env, const std::vector<StreamDesc> &streams, PassCtx &ctx
         }
     }
     if (reqs.empty()) return 0;
-    int s = env.run_payload(reqs);
-    if (s != 0) return s;
+    pr.open = true;
+    return env.run_payload_begin(reqs);
+}
+
+template <class Env>
+int payload_end(Env &env, const std::vector<StreamDesc> &streams, PassCtx &ctx, RunOut &R1, PayloadRound &pr)
+{
+    if (!pr.open) return 0;
+    pr.open = false;
+    typedef PayloadRound::Ref Ref;
+    std::vector<Ref> &refs = pr.refs;
+    std::vector<PayloadReq> &reqs = pr.reqs;
+    int s = env.run_payload_end(reqs);
+    if (s != 0) return s < 0 ? s : -1;
 
     // in place: frames and true end positions; per job, where it is split and where it ends early
     struct Plan { std::vector<uint32_t> split; int term = -1; uint32_t term_kind = 0; }; // split: behind these attempts; term: the job ends with this attempt (1 pending, 2 run again)
@@ -579,7 +605,7 @@ int payload_round(Env &env, const std::vector<StreamDesc> &streams, PassCtx &ctx
         for (size_t a = 0; a < nrows[k].recs.size(); a++) R1.recs[k * stride + a] = nrows[k].recs[a];
     }
     ctx.segs.swap(nsegs); ctx.jobs.swap(njobs); ctx.first_seg.swap(nfirst);
-    return 0;
+    return 1;
 }
 
 template <class Env>
@@ -622,7 +648,7 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
         const uint32_t nall = std::min(R1.res[k].n_attempts, R1.cap);
         for (uint32_t a = 0; a < nall; a++) {
             const AttemptRec &r = R1.rec(k, a);
-            if (r.hdr_pos >= 0 && (r.status == kAttemptFrame || r.status == kAttemptOutOfData)) return true;
+            if (r.hdr_pos >= 0 && (r.status == kAttemptFrame || r.status == kAttemptOutOfData || r.status == kAttemptHeaderOnly)) return true;
         }
         return false;
     };
@@ -684,8 +710,12 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
             if (dbg_t) fprintf(stderr, "[lora_hip] %zu segment job(s) run again with the header FEC branch their predecessor's tail probe reported\n", rjobs.size());
         }
     }
-    if (ctx.decoupled) { // the payloads of the header-only jobs; from here on the records are ordinary ones
-        s = payload_round(env, streams, ctx, R1);
+    // the payloads of the header-only jobs: the payload pass starts here and is collected behind the launch of the explicit probes below - which are
+    // planned on the records as they stand (a header-only record says where its packet ends if nothing moves the symbol clock) and planned again in the
+    // rare pass whose payloads change that (payload_end: jobs split, cut short or run again)
+    PayloadRound pround;
+    if (ctx.decoupled) {
+        s = payload_begin(env, streams, ctx, R1, pround);
         if (s != 0) return s;
     }
     env.set_skip_payload(false);
@@ -693,6 +723,10 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
     std::vector<Probe> probes;
     std::vector<size_t> first_probe(streams.size() + 1, 0);
     std::vector<Job> pjobs;
+    RunOut &R2 = env.run_out(1);
+    for (int planning = 0; planning < 2; planning++) {
+    probes.clear(); pjobs.clear();
+    first_probe.assign(streams.size() + 1, 0);
     for (size_t i = 0; i < streams.size(); i++) {
         first_probe[i] = probes.size();
         const size_t f = first_seg[i], e = first_seg[i + 1];
@@ -743,7 +777,7 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
             const uint32_t nall = std::min(R1.res[k].n_attempts, R1.cap);
             for (uint32_t a = 0; a < nall && !shared; a++) {
                 const AttemptRec &r = R1.rec(k, a);
-                if (r.hdr_pos < 0 || (r.status != kAttemptFrame && r.status != kAttemptOutOfData)) continue;
+                if (r.hdr_pos < 0 || (r.status != kAttemptFrame && r.status != kAttemptOutOfData && r.status != kAttemptHeaderOnly)) continue;
                 for (uint32_t z = 0; z < r.n_sfd && z < (uint32_t)kMaxSfdRec; z++) shared = shared || (r.sfd_pos[z] == ppos && r.sfd_fails[z] == pfails);
             }
         }
@@ -755,12 +789,16 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
         probes[q].job = (int)pjobs.size(); probes[q].tail_of = -1;
         pjobs.push_back(j);
     }
-    RunOut &R2 = env.run_out(1);
     R2.res.clear(); R2.recs.clear();
     if (!pjobs.empty()) {
         env.count_probes((uint32_t)pjobs.size());
         s = env.run_jobs(pjobs, rpj2, 0, R2);
         if (s != 0) return s;
+    }
+    if (!pround.open) break;
+    s = payload_end(env, streams, ctx, R1, pround); // from here on the records are ordinary ones
+    if (s < 0) return s;
+    if (s == 0) break; // (1: the pass was re-laid - its probes are planned again)
     }
     if (dbg_jobs) {
         for (size_t k = 0; k < pjobs.size(); k++) {

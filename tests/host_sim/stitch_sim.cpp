@@ -29,13 +29,14 @@ struct SimEnv {
     int decoupled_mode = 0;  // 1: every pass decoupled (header-only segment jobs + payload pass)
     bool skip = false;
     uint32_t n_payload = 0, n_rerun = 0;
-    bool decoupled(size_t n) const { return decoupled_mode == 1 || (decoupled_mode == 2 && 2 * n <= slots); }
+    bool decoupled(size_t n) const { return decoupled_mode == 1 || (decoupled_mode == 2 && n <= slots); }
     void set_skip_payload(bool on) { skip = on; }
     uint32_t n_moved = 0, n_pending = 0;
     void count_payload(uint32_t p, uint32_t m, uint32_t r) { n_payload += p; n_moved += m; n_rerun += r; }
     // the payload pass, by the oracle: the packet decoded from its header by the complete state machine - its frame, and how far from the zero-drift
     // end it ended (the device finds the same two things by demodulating the symbols on their own and following their d_fine_sync)
-    int run_payload(std::vector<PayloadReq> &reqs)
+    int run_payload_begin(std::vector<PayloadReq> &) { return 0; }
+    int run_payload_end(std::vector<PayloadReq> &reqs)
     {
         std::vector<oracle_attempt_t> tmp(2);
         for (PayloadReq &q : reqs) {
@@ -163,7 +164,7 @@ extern "C" int stitch_sim_decode(const float *iq, size_t n_items, int sf, int ct
     env.tail_probes = (tail_probes & 1) != 0;
     env.burst_plan = (tail_probes & 2) != 0;
     env.early = (tail_probes & 4) != 0;
-    env.decoupled_mode = (tail_probes & 8) ? 1 : (tail_probes & 16) ? 2 : 0; // 2: the device's per-pass rule (at most half the slots busy)
+    env.decoupled_mode = (tail_probes & 8) ? 1 : (tail_probes & 16) ? 2 : 0; // 2: the device's per-pass rule (the jobs fit the device at once)
     env.payload_force_rerun = (uint32_t)(tail_probes >> 8) & 0xffu;
     std::vector<StreamDesc> sds(1);
     sds[0].off = 0; sds[0].len = n_items; sds[0].id = 0; sds[0].cr_in = (uint32_t)ctor_cr; sds[0].abs_base = 0;

@@ -107,9 +107,18 @@ def test_data_ending_inside_a_payload_and_streaming(monkeypatch, oracle_mod):
     assert res["1"] == res["0"] and [r[0] for r in res["1"]] == o.frames()
 
 
+@pytest.mark.parametrize("sf", [9, 10, 11, 12])
+def test_ordinary_kernels_on_small_workloads(oracle_mod, sf, monkeypatch):
+    """Small workloads run decoupled when the choice is left to the library - so the suite's small SF9-SF12 cases exercise the header-only kernels and
+    the payload pass.  The complete kernels' payload rounds on the same cases: the SF x CR sweep of tests/test_gpu_configs.py with LORA_HIP_DECOUPLED=0."""
+    import test_gpu_configs as G
+    monkeypatch.setenv("LORA_HIP_DECOUPLED", "0")
+    G.test_config3_sf_cr_sweep(oracle_mod, sf)
+
+
 def test_per_pass_choice(monkeypatch):
-    """auto (no LORA_HIP_DECOUPLED): a gateway's short pass - 8 channels x 2 s of SF9, a few packets each: far fewer jobs than CUs - runs decoupled;
-    a config-3 cell (256 packets: a job per CU) does not; LORA_HIP_FLAG_NO_DECOUPLED keeps the ordinary pass"""
+    """auto (no LORA_HIP_DECOUPLED): a gateway's pass - 8 continuous channels x 2 s of SF9 - runs decoupled, and so does a sparse bursty one; a config-3
+    cell (256 packets: the balanced plan, a job of whole packets per CU) does not; LORA_HIP_FLAG_NO_DECOUPLED keeps the ordinary pass"""
     from gr_lora_amd import capi
     monkeypatch.delenv("LORA_HIP_DECOUPLED", raising=False)
     cfg, iq, offs, lens, expect = bench.make_gateway_workload(list(range(8)), 2.0, 9)

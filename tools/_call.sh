@@ -1,13 +1,15 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/c30
+mkdir -p gpurun_out/c34
 export LORA_BENCH_CACHE=/dev/shm/lora_bench
-for ds in 32 48 64 96 64; do
-  LORA_HIP_DEC_SEG_SYMBOLS=$ds timeout 100 python bench.py --no-cpu-baseline --config 4 --seconds 2 --steps 40 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('cfg4 2s dec seg $ds', d['value'], d['ms_per_step'], d['roofline'].get('kernel_ms_per_pass'), d['config']['bit_exact_vs_expected'])" >> gpurun_out/c30/bench.txt
-done
-LORA_HIP_DEC_SEG_SYMBOLS=32 LORA_HIP_DEBUG=1 timeout 100 python bench.py --no-cpu-baseline --config 4 --seconds 2 --steps 2 --warmup 1 2>&1 | grep -E "payload pass|round1|segment plan|run_jobs host|serial fallback" | tail -6 >> gpurun_out/c30/bench.txt
-cd /tmp && export TMPDIR=/tmp
-timeout 200 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/c30/prof -o cfg4 -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --config 4 --seconds 2 --steps 40 > $GRAFT_REPO_ROOT/gpurun_out/c30/prof_line.json 2>/dev/null
-cd $GRAFT_REPO_ROOT
-find gpurun_out/c30/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/c30/cfg4_2s_kernel_stats.csv
-rm -rf gpurun_out/c30/prof
-cat gpurun_out/c30/bench.txt; head -12 gpurun_out/c30/cfg4_2s_kernel_stats.csv | cut -c1-160
+run() { tag="$1"; shift; for m in 0 auto; do if [ $m = auto ]; then unset LORA_HIP_DECOUPLED; else export LORA_HIP_DECOUPLED=$m; fi; timeout 200 python bench.py --no-cpu-baseline "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tag decoupled=$m', d['value'], d['ms_per_step'], d['roofline'].get('kernel_ms_per_pass'), d['config']['bit_exact_vs_expected'], d['roofline'].get('kernel'))" >> gpurun_out/c34/bench.txt 2>&1; done; }
+run "cfg4 4s" --config 4 --seconds 4 --steps 30 --warmup 3
+run "cfg4 8s" --config 4 --seconds 8 --steps 20 --warmup 3
+run "cfg4 16s" --config 4 --seconds 16 --steps 12 --warmup 3
+run "cfg4 32s" --config 4 --steps 12 --warmup 3
+run "cfg3 sf9" --config 3 --sf 9 --steps 30
+run "cfg3 sf12" --config 3 --sf 12 --steps 8
+run "cfg3 sf9 128" --config 3 --sf 9 --packets 128 --steps 30
+run "cfg3 sf9 192" --config 3 --sf 9 --packets 192 --steps 30
+run "cfg3 sf12 64" --config 3 --sf 12 --packets 64 --steps 12
+run "cfg3 sf11 128" --config 3 --sf 11 --packets 128 --steps 12
+cat gpurun_out/c34/bench.txt
