@@ -21,14 +21,16 @@ stats = newest(os.path.join(src, "stats", "**", "*kernel_stats.csv"))
 assert stats, "no kernel_stats.csv"
 shutil.copy(stats[0], os.path.join("profiles", "%s_%s_kernel_stats.csv" % (rnd, tag)))
 # average duration of the walker kernel in that summary, per pass (a pass may launch it more than once: launches_per_pass below)
-_walker_rows = [r for r in csv.DictReader(open(stats[0])) if "walker" in r["Name"]]
+# (a decoupled pass is three kernels: the header-only walker, the payload pass's symbol kernel and its chain kernel)
+PASS_KERNELS = ("walker", "demod_symbols", "payload_chain")
+_walker_rows = [r for r in csv.DictReader(open(stats[0])) if any(k in r["Name"] for k in PASS_KERNELS)]
 
 def per_dispatch(kind, counter):
     out = collections.defaultdict(list)  # (kernel, grid) -> values
     for path in newest(os.path.join(src, kind, "**", "*counter_collection.csv")):
         acc, meta = collections.defaultdict(float), {}
         for row in csv.DictReader(open(path)):
-            if row["Counter_Name"] != counter or not any(k in row["Kernel_Name"] for k in ("walker", "envelope_kernel", "edges_kernel")):
+            if row["Counter_Name"] != counter or not any(k in row["Kernel_Name"] for k in PASS_KERNELS + ("envelope_kernel", "edges_kernel")):
                 continue
             acc[row["Dispatch_Id"]] += float(row["Counter_Value"])
             meta[row["Dispatch_Id"]] = (row["Kernel_Name"].split("(")[0], row["Grid_Size"])
@@ -48,12 +50,12 @@ line = json.loads([l for l in open(os.path.join(src, "stats.log")).read().splitl
 launches = max(1.0, float(line["roofline"].get("launches_per_pass", 1.0)))
 disp = {}
 fetch_raw = write_raw = pre_fetch = pre_write = 0.0
-walker_keys = [k for k in sorted(set(fetch) | set(write)) if "walker" in k[0]]
+walker_keys = [k for k in sorted(set(fetch) | set(write)) if any(p in k[0] for p in PASS_KERNELS)]
 for key in sorted(set(fetch) | set(write)):
     f = sum(fetch.get(key, [0])) / max(1, len(fetch.get(key, [])))
     w = sum(write.get(key, [0])) / max(1, len(write.get(key, [])))
     disp["%s grid %s" % key] = {"fetch_kb_avg": f, "write_kb_avg": w, "dispatches_fetch_pass": len(fetch.get(key, []))}
-    if "walker" in key[0]:   # (a pass may launch the walker more than once - probe jobs - with another grid size: every grid counts once per pass)
+    if any(p in key[0] for p in PASS_KERNELS):   # (a pass may launch the walker more than once - probe jobs - with another grid size: every grid counts once per pass)
         fetch_raw += f * 1024.0
         write_raw += w * 1024.0
     else: # the segment-planning pre-pass (envelope_kernel, edges_kernel)
