@@ -21,7 +21,7 @@ for tag in ("sq_sf7","sq_sf9","sq_sf12"):
             "lds_bank_conflict_fraction (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE)": round(c["SQ_LDS_BANK_CONFLICT"]/max(c["SQ_LDS_IDX_ACTIVE"],1),4),
             "mfma_ops": c.get("SQ_INSTS_VALU_MFMA_MOPS_F32",0)}}
 json.dump(out,open("profiles/%s_sq_counters.json" % RND,"w"),indent=1)
-for a,b in (("default_line","default_bench_line"),("default_grad_line","default_grad_bench_line"),("work_line","work_bench_line"),("cfg4_line","cfg4_bench_line"),("cfg4_8s_line","cfg4_8s_bench_line"),("cfg4_2s_line","cfg4_2s_bench_line"),("torchrun1_line","torchrun_world1_bench_line"),("streams1_line","streams1_bench_line"),("mux_cfg4_2s_line","mux_cfg4_2s_bench_line"),("split1_line","split_world1_bench_line"),("default_fast_sync_line","default_fast_sync_bench_line")):
+for a,b in (("default_line","default_bench_line"),("default_grad_line","default_grad_bench_line"),("work_line","work_bench_line"),("cfg4_line","cfg4_bench_line"),("cfg4_8s_line","cfg4_8s_bench_line"),("cfg4_2s_line","cfg4_2s_bench_line"),("torchrun1_line","torchrun_world1_bench_line"),("streams1_line","streams1_bench_line"),("mux_cfg4_2s_line","mux_cfg4_2s_bench_line"),("split1_line","split_world1_bench_line"),("default_fast_sync_line","default_fast_sync_bench_line"),("cfg4_2s_ordinary_line","cfg4_2s_ordinary_bench_line")):
     shutil.copy("gpurun_out/%s.json"%a,"profiles/%s_%s.json"%(RND,b))
 for tag in ["sf7","sf8","sf9","sf10","sf11","sf12","sf9_1024","sf7_grad","sf9_grad","sf12_grad"]:
     line=json.load(open("profiles/%s_%s_bench_line.json"%(RND,tag))); pmc=json.load(open("profiles/%s_%s_pmc_traffic.json"%(RND,tag)))
