@@ -540,6 +540,13 @@ def main():
                          "launches_per_pass": launches / max(1, args.steps),
                          "algorithmic_bytes_per_pass": 8 * n_items},
         }
+        pp = hs[0].payload_pass()
+        if pp["packets"]:
+            # a decoupled pass: `kernel` is the header-only walker variant, `kernel_ms_per_pass` the SUM over the pass's kernels - header-only
+            # jobs, the payload pass's symbol and chain kernels, the explicit probes - which overlap (two streams, and the passes of the pipeline among
+            # themselves): the job's own fraction of the roofline is value x 8 B / peak
+            res["roofline"]["decoupled_pass"] = {"last_pass": pp, "job_frac_of_hbm_peak": round(value * 1e6 * 8.0 / 1e9 / HBM_PEAK_GBS, 5),
+                                                 "note": "kernel_ms_per_pass sums kernels that overlap; see DESIGN 4.13 / 5.5"}
         if grad_line is not None:
             res["reference_default_demodulator"] = grad_line
         if world == 1 and not args.no_cpu_baseline:

@@ -689,13 +689,12 @@ lora_hip_status quiet_edges(lora_hip_decoder *h, const float2 *d_iq, const std::
 // (In two halves: payload_pass_begin puts the first round on the handle's payload stream and returns - the scheduler launches the pass's explicit
 // probes on the caller's stream meanwhile, the device has room for both - payload_pass_end waits, reads the walks' results and runs the further
 // rounds.  The IQ is known to be complete: the pass's main launch has read it and has been waited for.)
-static bool payload_fits(const PayloadReq &q, int64_t sps, int64_t shift, uint32_t from, uint32_t *to)
-{ // symbols [from, *to) of packet q read `shift` samples behind their zero-drift positions lie inside the data (:91)
+static uint32_t payload_fit_end(const PayloadReq &q, int64_t sps, int64_t shift, uint32_t from)
+{ // symbols [from, result) of packet q, read `shift` samples behind their zero-drift positions, lie inside the data (:91)
     const int64_t room = (int64_t)q.stream_len - 2 * sps - (q.start + shift); // symbol j fits iff j sps <= room
     uint32_t n = 0;
     if (q.start + shift >= 0 && room >= 0) n = (uint32_t)std::min<int64_t>(room / sps + 1, (int64_t)q.n_walk);
-    *to = std::max(n, from);
-    return true;
+    return std::max(n, from);
 }
 
 static lora_hip_status payload_launch_round(lora_hip_decoder *h, const float2 *d_iq, std::vector<PayloadReq> &reqs)
@@ -717,8 +716,7 @@ static lora_hip_status payload_launch_round(lora_hip_decoder *h, const float2 *d
         const PayloadOut &o = h->p_pay_out.p[i];
         const uint32_t from = ps.round == 0 ? 0u : o.at;
         const int32_t shift = ps.round == 0 ? 0 : o.shift;
-        uint32_t to = from;
-        payload_fits(q, sps, shift, from, &to);
+        const uint32_t to = payload_fit_end(q, sps, shift, from);
         const uint32_t hh = d.n_hyp++;
         d.hyp_shift[hh] = shift; d.hyp_from[hh] = from; d.hyp_to[hh] = to;
         d.hyp_base[hh] = (int32_t)(ps.used + n_sym) - (int32_t)from;

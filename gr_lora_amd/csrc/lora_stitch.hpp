@@ -122,20 +122,6 @@ struct PayloadReq {
     uint8_t  frame[kMaxFrame + 4];
 };
 
-// records of `out` re-laid with a larger stride (rows grow when a re-run job's attempts are spliced into a row)
-inline void restride(RunOut &out, uint32_t new_rpj)
-{
-    if (new_rpj <= out.rpj) return;
-    const size_t nj = out.res.size();
-    RecStore n;
-    n.resize_uninit(nj * (size_t)new_rpj);
-    for (size_t j = 0; j < nj; j++)
-        for (uint32_t a = 0; a < out.rpj; a++) n[j * new_rpj + a] = out.recs[j * out.rpj + a];
-    out.recs.p.swap(n.p); std::swap(out.recs.n, n.n); std::swap(out.recs.cap, n.cap);
-    out.rpj = new_rpj;
-    if (out.cap < new_rpj) out.cap = new_rpj;
-}
-
 // A completed attempt of the TRUE trajectory: replay its DETECT pushes, take the
 // SNR at the trigger (:756), publish the frame if there is one.
 template <class Env>
@@ -501,15 +487,13 @@ int payload_end(Env &env, const std::vector<StreamDesc> &streams, PassCtx &ctx, 
     if (n_moved == 0 && n_rerun == 0 && n_pending == 0) return 0;
 
     // jobs to run again (complete kernels), one launch
-    std::vector<Job> rjobs;
-    std::vector<size_t> rk;
+    std::vector<Job> rjobs; // (in job order: the re-lay below takes their results in the same order)
     for (size_t k = 0; k < plan.size(); k++) {
         if (plan[k].term < 0 || plan[k].term_kind != 2u) continue;
         const AttemptRec &r = R1.rec(k, (uint32_t)plan[k].term);
         Job j = ctx.jobs[k];
         j.start = r.hdr_pos; j.start_at_header = 1; j.cr_prev = r.cr_prev;
         rjobs.push_back(j);
-        rk.push_back(k);
     }
     RunOut &R3 = env.run_out(1);
     R3.res.clear(); R3.recs.clear();

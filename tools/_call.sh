@@ -1,15 +1,12 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/c34
+mkdir -p gpurun_out/c37
 export LORA_BENCH_CACHE=/dev/shm/lora_bench
-run() { tag="$1"; shift; for m in 0 auto; do if [ $m = auto ]; then unset LORA_HIP_DECOUPLED; else export LORA_HIP_DECOUPLED=$m; fi; timeout 200 python bench.py --no-cpu-baseline "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tag decoupled=$m', d['value'], d['ms_per_step'], d['roofline'].get('kernel_ms_per_pass'), d['config']['bit_exact_vs_expected'], d['roofline'].get('kernel'))" >> gpurun_out/c34/bench.txt 2>&1; done; }
-run "cfg4 4s" --config 4 --seconds 4 --steps 30 --warmup 3
-run "cfg4 8s" --config 4 --seconds 8 --steps 20 --warmup 3
-run "cfg4 16s" --config 4 --seconds 16 --steps 12 --warmup 3
-run "cfg4 32s" --config 4 --steps 12 --warmup 3
-run "cfg3 sf9" --config 3 --sf 9 --steps 30
-run "cfg3 sf12" --config 3 --sf 12 --steps 8
-run "cfg3 sf9 128" --config 3 --sf 9 --packets 128 --steps 30
-run "cfg3 sf9 192" --config 3 --sf 9 --packets 192 --steps 30
-run "cfg3 sf12 64" --config 3 --sf 12 --packets 64 --steps 12
-run "cfg3 sf11 128" --config 3 --sf 11 --packets 128 --steps 12
-cat gpurun_out/c34/bench.txt
+prof() { tag=$1; shift; (cd /tmp && export TMPDIR=/tmp && env "$@" timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/c37/prof_$tag -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --config 4 --seconds 2 --steps 30 > /dev/null 2>&1); find gpurun_out/c37/prof_$tag -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/c37/$tag.csv; rm -rf gpurun_out/c37/prof_$tag; echo "== $tag"; python - <<PY
+import csv
+for r in csv.DictReader(open('gpurun_out/c37/$tag.csv')):
+    if any(k in r['Name'] for k in ('walker','demod','payload')): print(r['Name'][:60], r['Calls'], round(float(r['AverageNs'])/1e3,1))
+PY
+}
+prof default A=1
+prof nosecond LORA_HIP_NO_SECOND_READS=1
+prof grad A=1 LORA_BENCH_DEMOD0=1
