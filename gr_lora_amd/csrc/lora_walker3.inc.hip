@@ -847,8 +847,11 @@ __device__ __forceinline__ void w3_tables_to_lds(const DevParams &P, const W3Lds
 #ifndef LORA_W3_SFD_K
 #define LORA_W3_SFD_K 0x1111   // FIND_SFD windows per group and round
 #endif
-template <int SF, int HV = 0> struct W3Acq {
-    static constexpr int KD = (LORA_W3_DET_K >> (4 * (SF - 9))) & 15, KS = (LORA_W3_SFD_K >> (4 * (SF - 9))) & 15;
+// (WIDE: the header-only variants scan two DETECT windows per group and round - a header-only job spends most of its time looking for the next preamble;
+// config 4 at 8 s per pass +6 %, at 2 s +1 %, a sparse SF12 pass +3.5 %.  The complete kernels keep one: their passes are payload rounds, and a
+// trigger voids the later windows of a round - config 3 at SF9 -2.8 % with two.)
+template <int SF, int HV = 0, bool WIDE = false> struct W3Acq {
+    static constexpr int KD = WIDE ? 2 : (LORA_W3_DET_K >> (4 * (SF - 9))) & 15, KS = (LORA_W3_SFD_K >> (4 * (SF - 9))) & 15;
     static constexpr int NQD = KD * W3Geom<SF, HV>::NG, NQS = KS * W3Geom<SF, HV>::NG; // windows per round
     static_assert(KD >= 1 && KS >= 1 && NQD <= 8 && NQS <= 8, "results are kept for at most 8 windows per round");
 };
@@ -862,11 +865,11 @@ struct alignas(16) W3AcqScratch { // in the demodulator's LDS data array
 // ---- DETECT (:340-366): sums of c1 conj(c2), |c1|^2, |c2|^2 over the symbol pairs of the windows q = grp KD + k at x0 + q sps.
 // A group's KD windows are consecutive: its KD + 1 symbols are read once, the energy of a symbol serves the two windows it
 // belongs to (summed in the same order either way).  out[q] = {re, im, e1, e2}, uniform.
-template <int SF, int HV = 0>
-__device__ __forceinline__ void w3_detect_round(const float2 *__restrict__ x0, int n_valid, W3AcqScratch *sc, float (&out)[W3Acq<SF, HV>::NQD][4])
+template <int SF, int HV = 0, bool WIDE = false>
+__device__ __forceinline__ void w3_detect_round(const float2 *__restrict__ x0, int n_valid, W3AcqScratch *sc, float (&out)[W3Acq<SF, HV, WIDE>::NQD][4])
 {
     using G = W3Geom<SF, HV>;
-    constexpr int KD = W3Acq<SF, HV>::KD, NQ = W3Acq<SF, HV>::NQD, GW = G::GW;
+    constexpr int KD = W3Acq<SF, HV, WIDE>::KD, NQ = W3Acq<SF, HV, WIDE>::NQD, GW = G::GW;
     int tt = threadIdx.x;
     asm volatile("" : "+v"(tt)); // keeps per-thread offsets out of the caller's loop-invariant set (they would be parked in scratch)
     const int grp = __builtin_amdgcn_readfirstlane(tt / G::TG), t = tt % G::TG, gwave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
@@ -1405,9 +1408,9 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
         W3AcqScratch *acq = reinterpret_cast<W3AcqScratch *>(L.data);
 
         if (plan_mode == kPlanDetect) { // :752-768, detect_preamble_autocorr :340-366
-            constexpr int NQ = W3Acq<SF, HV>::NQD;
+            constexpr int NQ = W3Acq<SF, HV, SKIP>::NQD;
             float a[NQ][4];
-            w3_detect_round<SF, HV>(X + pos, n_in_data < NQ ? n_in_data : NQ, acq, a);
+            w3_detect_round<SF, HV, SKIP>(X + pos, n_in_data < NQ ? n_in_data : NQ, acq, a);
             if (t0) {
                 W2State St = S;
                 for (int g = 0; g < NQ; g++) {
