@@ -1,11 +1,21 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/c38
+mkdir -p gpurun_out/c39
 export LORA_BENCH_CACHE=/dev/shm/lora_bench
-{
-echo "## cfg4 2s"; REPS=2 bash tools/ab.sh "--config 4 --seconds 2 --steps 40" ab/def.so ab/detk2.so
-echo "## cfg4 8s"; REPS=1 bash tools/ab.sh "--config 4 --seconds 8 --steps 20" ab/def.so ab/detk2.so
-echo "## cfg3 sf9"; REPS=1 bash tools/ab.sh "--config 3 --sf 9 --steps 30" ab/def.so ab/detk2.so
-echo "## cfg3 sf11"; REPS=1 bash tools/ab.sh "--config 3 --sf 11 --steps 12" ab/def.so ab/detk2.so
-echo "## cfg3 sf12 64 packets"; REPS=1 bash tools/ab.sh "--config 3 --sf 12 --packets 64 --steps 12" ab/def.so ab/detk2.so
-} > gpurun_out/c38/ab.txt 2>&1
-cat gpurun_out/c38/ab.txt
+rocprofv3 -L 2>/dev/null | grep -o -E "\b(TCC_[A-Z0-9_]*(DRAM|MALL|IO|GMI|RDREQ|WRREQ)[A-Z0-9_]*|MALL[A-Z0-9_]*|[A-Z0-9_]*HBM[A-Z0-9_]*)\b" | sort -u > gpurun_out/c39/counters.txt
+wc -l gpurun_out/c39/counters.txt; head -60 gpurun_out/c39/counters.txt | tr '\n' ' '
+cd /tmp && export TMPDIR=/tmp
+for c in TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum; do
+  timeout 120 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/c39/$c -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --config 3 --sf 12 > $GRAFT_REPO_ROOT/gpurun_out/c39/$c.log 2>&1; echo "$c rc=$?"
+done
+cd $GRAFT_REPO_ROOT
+python - <<'PY'
+import csv,glob,collections
+for c in ("TCC_EA0_RDREQ_sum","TCC_EA0_RDREQ_DRAM_sum","TCC_EA0_RDREQ_32B_sum","TCC_BUBBLE_sum"):
+    fs=glob.glob("gpurun_out/c39/%s/**/*counter_collection.csv"%c, recursive=True)
+    if not fs: print(c,"no file"); continue
+    acc=collections.defaultdict(float); name={}
+    for r in csv.DictReader(open(fs[0])):
+        if "walker3_kernel_sf12" in r["Kernel_Name"] and r["Counter_Name"]==c: acc[r["Dispatch_Id"]]+=float(r["Counter_Value"])
+    v=sorted(acc.values()); print(c, "dispatches", len(v), "median per dispatch", v[len(v)//2] if v else None)
+PY
+find gpurun_out/c39 -type f ! -name "*.txt" ! -name "*.log" -delete
