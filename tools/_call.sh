@@ -1,21 +1,12 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/c39
+mkdir -p gpurun_out/c40
 export LORA_BENCH_CACHE=/dev/shm/lora_bench
-rocprofv3 -L 2>/dev/null | grep -o -E "\b(TCC_[A-Z0-9_]*(DRAM|MALL|IO|GMI|RDREQ|WRREQ)[A-Z0-9_]*|MALL[A-Z0-9_]*|[A-Z0-9_]*HBM[A-Z0-9_]*)\b" | sort -u > gpurun_out/c39/counters.txt
-wc -l gpurun_out/c39/counters.txt; head -60 gpurun_out/c39/counters.txt | tr '\n' ' '
-cd /tmp && export TMPDIR=/tmp
-for c in TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum; do
-  timeout 120 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/c39/$c -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --config 3 --sf 12 > $GRAFT_REPO_ROOT/gpurun_out/c39/$c.log 2>&1; echo "$c rc=$?"
-done
-cd $GRAFT_REPO_ROOT
-python - <<'PY'
-import csv,glob,collections
-for c in ("TCC_EA0_RDREQ_sum","TCC_EA0_RDREQ_DRAM_sum","TCC_EA0_RDREQ_32B_sum","TCC_BUBBLE_sum"):
-    fs=glob.glob("gpurun_out/c39/%s/**/*counter_collection.csv"%c, recursive=True)
-    if not fs: print(c,"no file"); continue
-    acc=collections.defaultdict(float); name={}
-    for r in csv.DictReader(open(fs[0])):
-        if "walker3_kernel_sf12" in r["Kernel_Name"] and r["Counter_Name"]==c: acc[r["Dispatch_Id"]]+=float(r["Counter_Value"])
-    v=sorted(acc.values()); print(c, "dispatches", len(v), "median per dispatch", v[len(v)//2] if v else None)
-PY
-find gpurun_out/c39 -type f ! -name "*.txt" ! -name "*.log" -delete
+timeout 300 python -m pytest tests/test_gpu_strict_sync.py tests/test_golden.py tests/test_gpu_a16.py -m gpu -x -q 2>&1 | tail -4 > gpurun_out/c40/tests1.txt
+timeout 400 python -m pytest tests/test_gpu_fullsize.py -m gpu -x -q -k "grad_vs_reference_fixture and (sf9 or sf10 or sf11 or sf12)" 2>&1 | tail -4 > gpurun_out/c40/tests2.txt
+cp gr_lora_amd/liblora_hip.so ab/par.so
+{
+echo "## sf9";  REPS=2 bash tools/ab.sh "--config 3 --sf 9 --steps 30" ab/def.so ab/par.so
+echo "## sf12"; REPS=1 bash tools/ab.sh "--config 3 --sf 12 --steps 8" ab/def.so ab/par.so
+echo "## sf11"; REPS=1 bash tools/ab.sh "--config 3 --sf 11 --steps 12" ab/def.so ab/par.so
+} > gpurun_out/c40/ab.txt 2>&1
+cat gpurun_out/c40/tests1.txt gpurun_out/c40/tests2.txt gpurun_out/c40/ab.txt
