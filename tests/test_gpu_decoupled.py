@@ -1,9 +1,11 @@
-"""Decoupled passes (gr_lora_amd/csrc/lora_stitch.hpp payload_round; include/lora_hip.h LORA_HIP_FLAG_NO_DECOUPLED): the state-machine jobs run the
-header-only kernel variant (walker3_kernel_sf*_skip, LaunchCfg.skip_payload) - a packet's attempt ends behind its header, the job goes on where the payload
-would end had no symbol moved the symbol clock - and the payload pass demodulates every payload symbol of every packet at once (demod_symbols_w3_kernel)
-and takes them through the integer chain (payload_chain_kernel).  Required: the frames, header positions and end positions of the ordinary pass - on the
-config-3 cells against the compiled reference's fixtures, with a drifting transmitter clock (packets whose symbols move the clock are decoded again by the
-complete kernels), with the data ending inside a payload, through the streaming entry point - and the per-pass choice (few jobs for the device)."""
+"""Decoupled passes (gr_lora_amd/csrc/lora_stitch.hpp payload_begin / payload_end; include/lora_hip.h LORA_HIP_FLAG_NO_DECOUPLED): the
+state-machine jobs run the header-only kernel variant (walker3_kernel_sf*_skip, LaunchCfg.skip_payload) - a packet's attempt ends behind its header, the job
+goes on where the payload would end had no symbol moved the symbol clock - and the payload pass demodulates every payload symbol of every packet at once
+(demod_symbols_w3_kernel, second reads behind symbols that move the clock) and walks each packet's symbols through the integer chain
+(payload_chain_kernel).  Required: the frames, header positions and end positions of the ordinary pass - on config-3 cells against the compiled
+reference's fixtures, with a drifting transmitter clock (jobs split at packets that end off the zero-drift grid and probed from the true end; packets that
+drift through more offsets than the pass reads handed to the complete kernels), with the data ending inside a payload, through the streaming entry point -
+and the per-pass choice."""
 import numpy as np
 import pytest
 
@@ -71,7 +73,7 @@ def _drifting(sf, n, seed, ppm=60e-6, snr_db=42.0):
 
 
 @pytest.mark.parametrize("sf,demod", [(9, 2), (9, 0), (10, 2)])
-def test_packets_that_move_the_symbol_clock_are_decoded_again(sf, demod, monkeypatch):
+def test_packets_that_move_the_symbol_clock_for_good(sf, demod, monkeypatch):
     """a transmitter clock 60 ppm off + noise: fine_sync moves the symbol clock inside most payloads, for good.  Packets the payload pass follows to
     their end leave their job split at the packet's true end (a probe from there decides what stands of the job's scan behind it); packets that drift
     through more offsets than the pass reads are decoded by the complete kernels.  Either way the output is the ordinary pass's, which
