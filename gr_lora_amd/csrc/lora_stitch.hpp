@@ -368,6 +368,13 @@ int decode_begin(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
     // ---- round 1: every segment speculatively
     std::vector<Job> &jobs = ctx.jobs;
     jobs.assign(segs.size(), Job{});
+    // Decoupled pass: the jobs stop behind every header and skip the payload, whose symbols the payload pass demodulates all at once.  It pays
+    // wherever the ordinary pass leaves the device short of work or makes it do work twice: few packets (a packet's symbols are a serial chain on ONE
+    // CU, the others idle), or continuous traffic cut on the grid (every job first scans the rest of a packet another job decodes).  It does not pay
+    // for the balanced plan - bursty traffic with at least a burst per workgroup, every job whole packets: there all CUs demodulate payload already
+    // (BASELINE config 3, 256 packets: SF9 -8 %, SF12 -1 % decoupled; config 4: +100 % at 4 s per pass, +40 % at 8 s, +14 % at 32 s).
+    ctx.decoupled = segmenting && !balanced && env.decoupled(jobs.size());
+
     uint64_t max_span = 0;
     for (size_t k = 0; k < segs.size(); k++) {
         const StreamDesc &sd = streams[segs[k].stream];
@@ -378,19 +385,15 @@ int decode_begin(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
         // tail probe: past its own limit the job continues as the next segment's probe (same limit an explicit probe gets)
         const bool has_next = k + 1 < segs.size() && segs[k + 1].stream == segs[k].stream;
         static const bool no_tail = getenv("LORA_HIP_NO_TAIL") != nullptr; // diagnostics: separate probe jobs, as the generic kernels need
-        j.probe_limit = (segmenting && has_next && !no_tail) ? std::min<int64_t>((int64_t)sd.len, segs[k + 1].b1 + 16ll * sps) : 0;
+        // (a decoupled pass probes in a launch of its own: it runs beside the payload pass, on CUs that would idle, instead of lengthening every
+        // header-only job by a second acquisition - config 4 at 2 s per pass 49.4 -> 54.0 Gsamples/s, at 8 s the same either way)
+        j.probe_limit = (segmenting && has_next && !no_tail && !ctx.decoupled) ? std::min<int64_t>((int64_t)sd.len, segs[k + 1].b1 + 16ll * sps) : 0;
         j.tail_stop_sfd = (j.probe_limit && env.early_probe()) ? 1u : 0u;
         max_span = std::max<uint64_t>(max_span, (uint64_t)(segs[k].b1 - segs[k].b0));
     }
     ctx.rpj1 = recs_for(max_span, sps) + (segmenting ? ctx.rpj2 : 0u);
     ctx.trace_cap = tracing ? (uint32_t)std::min<uint64_t>(2ull * (max_span / sps) + 64ull, 1ull << 22) : 0u;
     env.count_jobs((uint32_t)jobs.size());
-    // Decoupled pass: the jobs stop behind every header and skip the payload, whose symbols the payload pass demodulates all at once.  It pays
-    // wherever the ordinary pass leaves the device short of work or makes it do work twice: few packets (a packet's symbols are a serial chain on ONE
-    // CU, the others idle), or continuous traffic cut on the grid (every job first scans the rest of a packet another job decodes).  It does not pay
-    // for the balanced plan - bursty traffic with at least a burst per workgroup, every job whole packets: there all CUs demodulate payload already
-    // (BASELINE config 3, 256 packets: SF9 -8 %, SF12 -1 % decoupled; config 4: +100 % at 4 s per pass, +40 % at 8 s, +14 % at 32 s).
-    ctx.decoupled = segmenting && !balanced && env.decoupled(jobs.size());
     env.set_skip_payload(ctx.decoupled);
     ctx.tp0 = std::chrono::steady_clock::now();
     const int s = env.run_jobs_begin(jobs, ctx.rpj1, ctx.trace_cap, env.run_out(0)); // (result holders are kept by the environment between calls)
