@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 HARNESS = textwrap.dedent(r'''
     #include <cstdio>
+    #include <cstdlib>
     #include <fstream>
     #include <iterator>
     #include <vector>
@@ -22,11 +23,12 @@ HARNESS = textwrap.dedent(r'''
         std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
         const gr_complex *iq = reinterpret_cast<const gr_complex *>(raw.data());
         const long long n = (long long)(raw.size() / sizeof(gr_complex));
-        gr::lora::decoder::sptr blk = gr::lora::decoder::make(1e6f, 125000, 7, false, 4, true, false, false);
+        const int sf = argc > 2 ? atoi(argv[2]) : 7, cr = argc > 3 ? atoi(argv[3]) : 4;   // (default: the known-answer capture's configuration)
+        gr::lora::decoder::sptr blk = gr::lora::decoder::make(1e6f, 125000, (uint8_t)sf, false, (uint8_t)cr, true, false, false);
         if (blk->mock_name != "decoder" || blk->mock_in->item_size != (int)sizeof(gr_complex) || blk->mock_out->max_streams != 0) return 3;
         if (blk->mock_ports.size() != 2 || blk->mock_ports[0] != "frames" || blk->mock_ports[1] != "control") return 4;
         const int m = blk->mock_output_multiple;          // 2 * samples per symbol (decoder_impl.cc:91)
-        if (m != 2 * 1024) return 5;
+        if (m != 2 * (8 << sf)) return 5;
         long long pos = 0;                                  // the scheduler: offers multiples of m, advances by what was consumed
         while (n - pos >= m) {
             int offer = (int)(((n - pos < 16 * m ? n - pos : 16 * m) / m) * m);
@@ -76,6 +78,29 @@ def test_shim_block_decodes_known_answer(tmp_path):
     assert "Bins per symbol: \t128" in lines and "Samples per symbol: \t1024" in lines and "Decimation: \t\t8" in lines   # the banner, :94-96
     frames = [l for l in lines if l and all(c in "0123456789abcdef" for c in l)]
     assert frames == ["049040deadbeef700d"] * 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idx", [3, 8, 15])
+def test_shim_block_in_the_reference_default_mode_vs_compiled_reference(tmp_path, idx):
+    """The block as a gr-lora user would compare it with upstream: LORA_HIP_DEMOD=grad selects the reference's shipped estimator (decoder_impl.cc:499),
+    and what the block publishes on "frames" is what the compiled reference published on the same IQ (tests/golden/golden.json "ref", made from
+    oracle/_ref = lib/decoder_impl.cc itself): SF7, SF9 and SF10 cases of the golden set, byte for byte behind the loratap header."""
+    import json
+    import numpy as np
+    import test_golden as G
+    case = G.GOLD["cases"][idx]
+    assert not case["implicit"] and case["crc"] and not case["reduced_rate"] and not case["disable_drift_correction"], case["sf"]
+    cfg, st = G._stream(case)
+    iq_path = tmp_path / "case.cf32"
+    np.ascontiguousarray(st.iq, dtype=np.complex64).tofile(str(iq_path))
+    exe = _build(tmp_path)
+    env = dict(os.environ, LORA_HIP_DEMOD="grad")
+    res = subprocess.run([str(exe), str(iq_path), str(case["sf"]), str(case["cr"])], timeout=180, capture_output=True, env=env)
+    assert res.returncode == 0, (res.returncode, res.stderr.decode()[-400:])
+    frames = [l for l in res.stdout.decode().split("\n") if l and all(c in "0123456789abcdef" for c in l)]
+    assert frames == [f[30:] for f in case["ref"]["frames"]], (case["sf"], case["cr"])
+    assert len(frames) >= 1
 
 
 XLATING_HARNESS = textwrap.dedent(r'''
