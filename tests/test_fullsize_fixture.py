@@ -37,3 +37,28 @@ def test_oracle_grad_equals_reference_fixture(oracle_mod, tag):
     # the gradient estimator is not the transmitter's inverse on every symbol: the reference itself loses a few payloads on
     # clean input; what is pinned is that everyone loses the SAME ones
     assert 0.9 * fx["packets"] < total_as_sent <= fx["packets"]
+
+
+_FIX_FFT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_oracle_fft.json")
+
+
+def test_fft_fixture_covers_the_cells_the_gpu_suite_leaves_to_it():
+    """tests/golden/fullsize_oracle_fft.json (tests/golden/make_fullsize_fft_golden.py): the six config-3 cells, complete and made by the parity build"""
+    fx = json.load(open(_FIX_FFT))
+    assert sorted(fx) == sorted("config3-sf%d-cr%d" % (sf, cr) for sf in (10, 11, 12) for cr in (2, 3))
+    for tag, e in fx.items():
+        assert e["demod"] == 2 and "parity build" in e["source"] and e["packets"] == 256 and len(e["per_stream"]) == e["streams"] == 8, tag
+        assert sum(s["frames"] for s in e["per_stream"]) == 256 and all(len(s["header_pos"]) == s["frames"] for s in e["per_stream"]), tag
+
+
+@pytest.mark.slow
+def test_oracle_fft_reproduces_its_fixture_cell(oracle_mod):
+    """one cell regenerated here (SF10 CR 4/6, seconds): the committed fixture is what the oracle in this tree publishes"""
+    fx = json.load(open(_FIX_FFT))["config3-sf10-cr2"]
+    cfg, iq, offs, lens, expect = bench.make_workload(fx["sf"], fx["cr"], fx["packets"], fx["payload"], fx["streams"], seed=fx["seed"])
+    assert int(iq.size) == fx["n_items"]
+    for k, want in enumerate(fx["per_stream"]):
+        o = oracle_mod.Oracle(demod=fx["demod"], **fx["decoder_kw"])
+        o.run(iq[offs[k]:offs[k] + lens[k]])
+        f = o.frames()
+        assert len(f) == want["frames"] and _digest(f) == want["sha256"] and o.frame_positions() == want["header_pos"], k

@@ -117,14 +117,33 @@ def test_sf8_profile_workload_grad_vs_reference_fixture():
 @pytest.mark.parametrize("sf", [7, 8, 9, 10, 11, 12])
 def test_config3_full_size(oracle_mod, sf):
     n = 256
-    for cr in ((1, 2, 3, 4) if sf <= 9 else (1, 4)):   # BASELINE config 3: CR 4/5 - 4/8 (the oracle's O(sps^2) SYNC makes SF10+ cells minutes each: CR 4/6, 4/7
-                                                      # there are held to the compiled reference's fixtures above, which need no oracle run)
+    for cr in ((1, 2, 3, 4) if sf <= 9 else (1, 4)):   # BASELINE config 3: CR 4/5 - 4/8 (the oracle's O(sps^2) SYNC makes SF10+ cells long on a test box: CR 4/6, 4/7
+                                                      # there are held to the oracle's pre-computed fixture, test_config3_full_size_fft_vs_oracle_fixture below)
         cfg, iq, offs, lens, expect = bench.make_workload(sf, cr, n, 32, 8, seed=100 * sf + cr)
         kw = dict(sf=sf, cr=4, reduced_rate=(sf > 10))
         want = _oracle_streams(oracle_mod, iq, offs, lens, 2, **kw)
         got = _gpu_streams(iq, offs, lens, 2, **kw)
         _assert_same(got, want, ("config3", sf, cr))
         assert sum(len(g[0]) for g in got) == n
+
+
+_FIX_FFT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_oracle_fft.json")
+
+
+@pytest.mark.parametrize("sf", [10, 11, 12])
+@pytest.mark.parametrize("cr", [2, 3])
+def test_config3_full_size_fft_vs_oracle_fixture(sf, cr):
+    """the six cells test_config3_full_size leaves out (SF10-12 at CR 4/6, 4/7, FFT demodulator, 256 packets): every frame and every header
+    position against what the parity build of the oracle published on the same IQ, computed offline (tests/golden/make_fullsize_fft_golden.py)"""
+    fx = json.load(open(_FIX_FFT))["config3-sf%d-cr%d" % (sf, cr)]
+    cfg, iq, offs, lens, expect = bench.make_workload(fx["sf"], fx["cr"], fx["packets"], fx["payload"], fx["streams"], seed=fx["seed"])
+    assert int(iq.size) == fx["n_items"]
+    got = _gpu_streams(iq, offs, lens, fx["demod"], **fx["decoder_kw"])
+    for s, ((gf, gp), want) in enumerate(zip(got, fx["per_stream"])):
+        assert len(gf) == want["frames"], (sf, cr, s, len(gf), want["frames"])
+        assert gp == want["header_pos"], (sf, cr, s, sum(a != b for a, b in zip(gp, want["header_pos"])))
+        assert _digest(gf) == want["sha256"], (sf, cr, s)
+    assert sum(len(g[0]) for g in got) == fx["packets"]
 
 
 def test_config4_64_channels(oracle_mod):
