@@ -774,6 +774,14 @@ lora_hip_status payload_pass_begin(lora_hip_decoder *h, const float2 *d_iq, std:
     return payload_launch_round(h, d_iq, reqs);
 }
 
+// an error between payload_pass_begin and the end of payload_pass_end: nothing of the pass may still be running on pay_stream (its kernels read and
+// write the page-locked p_pay_desc / p_pay_out / p_pay_off) when the caller retries or reuses the handle
+void payload_pass_abort(lora_hip_decoder *h)
+{
+    if (h->pay_stream) (void)hipStreamSynchronize(h->pay_stream);
+    h->pay = lora_hip_decoder::PayState{};
+}
+
 lora_hip_status payload_pass_end(lora_hip_decoder *h, const float2 *d_iq, std::vector<PayloadReq> &reqs)
 {
     lora_hip_decoder::PayState &ps = h->pay;
@@ -856,6 +864,7 @@ struct DeviceEnv {
         return 100u * (uint32_t)n_jobs <= fill * full;
     }
     void set_skip_payload(bool on) { h->launch_skip = on; }
+    void abort_payload() { ::payload_pass_abort(h); }
     int run_payload_begin(std::vector<PayloadReq> &reqs) { return ::payload_pass_begin(h, d_iq, reqs) == LORA_HIP_OK ? 0 : -1; }
     int run_payload_end(std::vector<PayloadReq> &reqs) { return ::payload_pass_end(h, d_iq, reqs) == LORA_HIP_OK ? 0 : -1; }
     void count_payload(uint32_t packets, uint32_t moved, uint32_t rerun)

@@ -15,6 +15,7 @@
 //   bool early_probe();   (the jobs record their FIND_SFD entry states and their tail probes may stop behind the first one: Job.tail_stop_sfd)
 //   bool decoupled(size_t n_jobs);   (run this pass's segment jobs header-only and the payloads in the symbol-parallel payload pass)
 //   void set_skip_payload(bool);     (the launches that follow run the kernels' header-only variant, LaunchCfg.skip_payload)
+//   void abort_payload();   (an error return between the two calls below: wait for whatever the payload pass has in flight and forget it)
 //   int  run_payload_begin(std::vector<PayloadReq> &) / run_payload_end(same);   (0 = ok; launch / wait: status, end_shift and frame of every request filled in)   void count_payload(uint32_t packets, uint32_t moved, uint32_t rerun);
 #pragma once
 #include <algorithm>
@@ -701,7 +702,11 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
     // planned on the records as they stand (a header-only record says where its packet ends if nothing moves the symbol clock) and planned again in the
     // rare pass whose payloads change that (payload_end: jobs split, cut short or run again)
     PayloadRound pround;
+    // whatever goes wrong between payload_begin and payload_end (a failed probe launch, a failed round of the payload pass itself), the pass's kernels may
+    // still be reading and writing the handle's page-locked staging buffers on their own stream: every early return drains it first
+    struct PayloadGuard { Env &env; bool armed; ~PayloadGuard() { if (armed) env.abort_payload(); } } pguard{env, false};
     if (ctx.decoupled) {
+        pguard.armed = true;
         s = payload_begin(env, streams, ctx, R1, pround);
         if (s != 0) return s;
     }
@@ -785,6 +790,7 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
     if (!pround.open) break;
     s = payload_end(env, streams, ctx, R1, pround); // from here on the records are ordinary ones
     if (s < 0) return s;
+    pguard.armed = false;
     if (s == 0) break; // (1: the pass was re-laid - its probes are planned again)
     }
     if (dbg_jobs) {

@@ -13,7 +13,8 @@
 // by ONE lane per candidate.  The products are made by the whole workgroup, a chunk of taps at a time, into LDS; wave 0 adds them up.
 // Measured (profiles/r04_strict_sync_*): a dependent v_add_f32 chain runs at 8 shader clocks per tap on one wavefront whatever feeds it
 // (8 k clocks per SYNC at SF7, 262 k at SF12), the exact arctangents cost about as much again at SF7: 7-8 % of a pass at every
-// spreading factor.  LORA_HIP_FLAG_FAST_SYNC skips it (the closed-form maximum stands: one sample beside the reference at SF11 / SF12).
+// spreading factor (6-8 %: the figure include/lora_hip.h quotes as well).  Pinned to ONE arithmetic environment - glibc 2.35's atan2f, VOLK's generic
+// sequential dot product (oracle/ref_build) - as the flag's description in include/lora_hip.h says.  LORA_HIP_FLAG_FAST_SYNC skips it (the closed-form maximum stands: one sample beside the reference at SF11 / SF12).
 #pragma once
 
 namespace strict {

@@ -50,7 +50,13 @@ typedef enum lora_hip_demod {
                                       within rounding of that maximum is re-evaluated with the reference's own arithmetic (glibc's atan2f, the unwrap of
                                       :231-240, one sequential float sum per shift as volk_32f_x2_dot_prod_32f_generic adds) and the FIRST maximum of those
                                       sums wins, as in :399-407 - on a clean preamble two adjacent shifts tie to ~6 / sps^2 of the peak and the float
-                                      arithmetic alone decides.  Costs 1.5-4 % of a pass; FFT demodulators publish the same bytes either way. */
+                                      arithmetic alone decides.  Costs 6-8 % of a pass at every spreading factor (measured: profiles/r04_default_fast_sync_bench_line.json,
+                                      profiles/r05_ab_acquisition_experiments.txt); FFT demodulators publish the same bytes either way.
+                                      WHAT "the reference's own arithmetic" IS PINNED TO: atan2f as glibc 2.35 computes it (fdlibm's float algorithm) and VOLK's
+                                      GENERIC dot product (one sequential float sum) - the build oracle/ref_build compiles and tests/test_ref_pin.py holds.  A
+                                      GNU Radio install whose VOLK dispatches a SIMD kernel (several partial sums) or whose libm rounds atan2f differently
+                                      decides these ties its own way; no reference build agrees with another one there (tests/test_ref_pin.py::
+                                      test_sync_shift_depends_on_volk_summation_order). */
 #define LORA_HIP_FLAG_NO_DECOUPLED 8u /* never run a pass decoupled.  A decoupled pass (chosen per pass when its jobs would leave most CUs idle - a gateway's short
                                        * pass, a few packets per channel; SF9-12 at decimation 8, explicit header): the state-machine jobs stop behind every header
                                        * and skip the payload, all payload symbols are demodulated at once at their zero-drift positions, and a packet whose symbols
@@ -247,8 +253,9 @@ lora_hip_status lora_hip_demod_symbols_device(lora_hip_decoder_t *h, const void 
                                               uint32_t *bins_out, void *hip_stream);
 
 /* Same, and additionally fine_out[i] = d_fine_sync after fine_sync(bin_idx, max(D/4, 2)) on that window
- * (decoder_impl.cc:300-338, called from demodulate() :514-518).  fine_out may be NULL; non-NULL needs the
- * wave-per-symbol demodulator (SF7 / SF8 at decimation 8, demod FFT or FFT_COMPAT), else BAD_CONFIG.        */
+ * (decoder_impl.cc:300-338, called from demodulate() :514-518).  fine_out may be NULL; non-NULL needs one of the
+ * fast demodulator families (SF7-SF12 at decimation 8: wave-per-symbol at SF7 / SF8, workgroup-per-symbol at SF9-SF12,
+ * every demod mode), else BAD_CONFIG.                                                                          */
 lora_hip_status lora_hip_demod_symbols_ex_device(lora_hip_decoder_t *h, const void *d_iq, size_t total_items,
                                                  const int64_t *offsets, size_t n, int demod,
                                                  uint32_t *bins_out, int32_t *fine_out, void *hip_stream);

@@ -35,6 +35,7 @@ struct SimEnv {
     void count_payload(uint32_t p, uint32_t m, uint32_t r) { n_payload += p; n_moved += m; n_rerun += r; }
     // the payload pass, by the oracle: the packet decoded from its header by the complete state machine - its frame, and how far from the zero-drift
     // end it ended (the device finds the same two things by demodulating the symbols on their own and following their d_fine_sync)
+    void abort_payload() {}
     int run_payload_begin(std::vector<PayloadReq> &) { return 0; }
     int run_payload_end(std::vector<PayloadReq> &reqs)
     {
