@@ -47,7 +47,9 @@ struct alignas(16) W2Plan {
     int32_t resolve_prev; // kPlanDecode: spec[buf ^ 1] holds the previous round, to be resolved now
     int32_t n_win;        // windows the workers evaluate this round (kPlanDecode: 0 = resolve-only round)
     int32_t prev_n;       // kPlanDecode with resolve_prev: windows of the previous round (it ended n_win * sps before pos)
-    int32_t pad;
+    int32_t zmode;        // kPlanDecode / kPlanSfd: the round evaluates its windows with the ZM instantiations - every ifreq value formed as the reference forms
+                          // it next to a sample of exactly zero (std::arg(0) = 0; lora_kernels.hip, ifreq_prod_z).  Planned when a window of the previous
+                          // round came back POISONED (kPoisonBin / W2SfdOut.pz): the fast evaluations notice such a sample but do not handle it
 };
 
 struct alignas(16) W2State {
@@ -116,14 +118,6 @@ __device__ __forceinline__ void w2_block_argmax_first(float &v, int &idx, float 
         const int oi = ((int *)red)[16 + w];
         if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
     }
-}
-
-// branch-free instantaneous_frequency of one pair from their phases (:236-239)
-__device__ __forceinline__ float unwrap_diff(float pp, float p2)
-{
-    p2 = ((double)(p2 - pp) > M_PI) ? (float)((double)p2 - 2.0 * M_PI) : p2;
-    p2 = ((double)(p2 - pp) < -M_PI) ? (float)((double)p2 + 2.0 * M_PI) : p2;
-    return p2 - pp;
 }
 
 // ---- thread-0 bookkeeping (mirrors end_step / the loop-top checks of walker_body) ---------------------
@@ -311,8 +305,8 @@ __device__ __forceinline__ void w2_detect_windows(const float2 *__restrict__ p, 
 
 // FIND_SFD (:385-390, :283-298, :801-803): Pearson correlation of the window's ifreq with the ideal
 // downchirp ifreq, and -- for an upchirp (c < -0.97) -- fine_sync(-1, 4*D) over the 63 lags.
-struct W2SfdOut { float c; int32_t fine; };
-template <int SF>
+struct W2SfdOut { float c; int32_t fine; int32_t pz; }; // pz: the window holds a sample of exactly zero (its sums are NaN): to be evaluated again with ZM = true
+template <int SF, bool ZM = false>
 __device__ __forceinline__ W2SfdOut w2_sfd_window(const float2 *p, const float *Tv, const float *Tdd, float *scr /* this wavefront's 72 floats */,
                                                           float down_ifreq_sd, float down_ifreq_dsum, double sync_a, double sync_b)
 {
@@ -332,7 +326,7 @@ __device__ __forceinline__ W2SfdOut w2_sfd_window(const float2 *p, const float *
             const v2f b0 = dpp2<kDppWaveRor1>(a[j]), b1 = dpp2<kDppWaveRor1>(a[j + 1]);
             const v2f p0 = (lane == 0) ? bprev : b0, p1 = (lane == 0) ? b0 : b1;
             bprev = b1;
-            const v2f fp = ifreq_prod_pk(p0, a[j], p1, a[j + 1]);
+            const v2f fp = ZM ? ifreq_prod_pk_z(p0, a[j], p1, a[j + 1]) : ifreq_prod_pk(p0, a[j], p1, a[j + 1]);
             f[j] = (j == 0 && lane == 0) ? 0.0f : fp.x;
             f[j + 1] = fp.y;
         }
@@ -347,12 +341,13 @@ __device__ __forceinline__ W2SfdOut w2_sfd_window(const float2 *p, const float *
         a0 += fk; a1 += fk * fk; a2 += fk * d; // f[j] is 0 for the non-existent k = -1
     }
     a0 = wave_sum_rows(a0); a1 = wave_sum_rows(a1); a2 = wave_sum_rows(a2);
+    if (!ZM && poisoned(a0)) return W2SfdOut{0.0f, 0, 1}; // (uniform)
     const float n = (float)(SPS - 1);
     const float average = a0 / n;
     const float var = fmaxf(a1 / n - average * average, 0.0f);
     const float sd = sqrtf(var) * down_ifreq_sd;
     const float c = (a2 - average * down_ifreq_dsum) / sd / n;
-    if (!(c < -0.97f) || c > 0.96f) return W2SfdOut{c, 0};
+    if (!(c < -0.97f) || c > 0.96f) return W2SfdOut{c, 0, 0};
     // fine_sync(-1, 32) (:300-321): c_i = sum_{k<sps} fe[k] * v[sps + i + k], i = -31 .. 31, with fe[sps-1] = fe[sps-2].
     // v is the ifreq of concatenated upchirps: v[m] = a + b*(m mod sps) except the one wrap sample per period
     // (m mod sps == sps-1), up to float noise ~1e-5 of the sums.  With t = (i+k) mod sps that gives, exactly in
@@ -412,7 +407,7 @@ __device__ __forceinline__ W2SfdOut w2_sfd_window(const float2 *p, const float *
         if (ov > c_i || (ov == c_i && oi < li)) { c_i = ov; li = oi; }
     }
     const int32_t lag = (c_i > 0.0f) ? li - 31 : 0;
-    return W2SfdOut{c, -lag};
+    return W2SfdOut{c, -lag, 0};
 }
 
 // SYNC (:770-783, detect_upchirp :392-413): this thread's best shift of the sliding correlation of f[0 .. 2 sps) with the
@@ -508,6 +503,28 @@ __device__ __attribute__((noinline)) void w2_sync_exact_ifreq(const float2 *__re
     for (int k = 0; k < NI; k++) fl[threadIdx.x + (uint32_t)k * kW2] = strict::ref_ifreq(am[k], an[k]); // (the last one, 0, is overwritten by the caller: :243)
 }
 
+// ---- the ZM evaluations (a window that holds a sample of exactly zero): they run in rounds of their own (W2Plan.zmode), for the rare window only; inside them
+// every ifreq value is a call of ifreq_prod_z -----------------------------------------------------------------------------------------------------
+#ifndef LORA_W2_ZM_ATTR
+#define LORA_W2_ZM_ATTR __forceinline__ // (as calls - noinline - they cost the gradient kernels 7 % in register allocation, and the calls themselves faulted: profiles/r05_ab_zero_samples.txt)
+#endif
+template <int SF>
+__device__ LORA_W2_ZM_ATTR W2SfdOut w2_sfd_window_zm(const float2 *p, const float *Tv, const float *Tdd, float *scr, float down_ifreq_sd, float down_ifreq_dsum, double sync_a, double sync_b)
+{
+    return w2_sfd_window<SF, true>(p, Tv, Tdd, scr, down_ifreq_sd, down_ifreq_dsum, sync_a, sync_b);
+}
+struct W2DemodZ { uint32_t s; int32_t fine; float en; };
+template <int SF, bool GRAD>
+__device__ LORA_W2_ZM_ATTR W2DemodZ w2_demod_zm(uint32_t enable_fine_sync, uint32_t demod_mode, bool want_energy, WaveTabs T, const float2 *x)
+{
+    DevParams Q{}; // (only the fields the demodulators read)
+    Q.enable_fine_sync = enable_fine_sync; Q.demod_mode = demod_mode;
+    W2DemodZ r{0u, 0, 0.0f};
+    if constexpr (GRAD) wave_demod_symbol_grad<SF, true>(Q, T.v, x, want_energy, r.s, r.fine, r.en);
+    else wave_demod_symbol<SF, 0, true>(Q, T, x, r.s, r.fine, want_energy ? &r.en : nullptr, nullptr);
+    return r;
+}
+
 // ---- the kernel -----------------------------------------------------------------------------------------
 // GRAD: the reference's shipped demodulator (max_frequency_gradient_idx, :466-491, :499) in the decode rounds instead of the
 // dechirp + FFT: wave_demod_symbol_grad.  The FFT twiddle block is then not needed in LDS.
@@ -566,8 +583,8 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     for (uint32_t i = threadIdx.x; i < sps; i += kW2) ddl[i] = P.down_ifreq[i] - P.down_ifreq_avg;
 
     // plan for the next round from the TRUE state (control thread only)
-    auto plan_from = [&](W2State &S, W2Plan &pl) {
-        pl.buf = 0; pl.resolve_prev = 0; pl.n_win = kW2Workers; pl.pos = S.pos; pl.prev_n = 0; pl.pad = 0;
+    auto plan_from = [&](W2State &S, W2Plan &pl, bool zreq = false /* a window of this round came back poisoned: the next round's are evaluated by the ZM instantiations */) {
+        pl.buf = 0; pl.resolve_prev = 0; pl.n_win = kW2Workers; pl.pos = S.pos; pl.prev_n = 0; pl.zmode = zreq ? 1 : 0;
         if (!S.done) (void)w2_pre_step(S, job, rec_cap, sps);
         if (S.done) { pl.mode = kPlanExit; return; }
         if (S.fin_pending) { pl.mode = kPlanFinalize; return; }
@@ -632,7 +649,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         const int64_t plan_pos = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(pl_pp >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)pl_pp));
         const int32_t plan_mode = __builtin_amdgcn_readfirstlane(pl_in.mode), plan_buf = __builtin_amdgcn_readfirstlane(pl_in.buf);
         const int32_t plan_resolve_prev = __builtin_amdgcn_readfirstlane(pl_in.resolve_prev), plan_n_win = __builtin_amdgcn_readfirstlane(pl_in.n_win);
-        const int32_t plan_prev_n = __builtin_amdgcn_readfirstlane(pl_in.prev_n);
+        const int32_t plan_prev_n = __builtin_amdgcn_readfirstlane(pl_in.prev_n), plan_z = __builtin_amdgcn_readfirstlane(pl_in.zmode);
         W2Plan &next = W.plan[(it + 1u) & 1u];
         if (plan_mode == kPlanExit) break;
         const int64_t pos = plan_pos;
@@ -766,7 +783,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
 #pragma unroll
                 for (int k = 0; k < NI; k++) {
                     const uint32_t i = 1u + threadIdx.x + (uint32_t)k * kW2;
-                    if (i < 2u * sps) f2[i - 1] = ifreq_prod(xb[k], xa[k]);
+                    if (i < 2u * sps) f2[i - 1] = ifreq_prod_z(xb[k], xa[k]); // (closed-form-only SYNC, once per packet: the zero-aware form directly)
                 }
             }
             __syncthreads();
@@ -817,11 +834,13 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 const bool kvalid = !is_ctl && wave < plan_n_win && kpos + 2 * (int64_t)sps <= n_items;
                 float c = 0.0f;
                 int32_t fine = 0;
+                int32_t pz = 0;
                 if (kvalid) {
-                    const W2SfdOut r = w2_sfd_window<SF>(X + kpos, T.v, T.dd, T.scratch + wave * 72, P.down_ifreq_sd, P.down_ifreq_dsum, P.sync_a, P.sync_b);
-                    c = r.c; fine = r.fine;
+                    const W2SfdOut r = plan_z ? w2_sfd_window_zm<SF>(X + kpos, T.v, T.dd, T.scratch + wave * 72, P.down_ifreq_sd, P.down_ifreq_dsum, P.sync_a, P.sync_b)
+                                              : w2_sfd_window<SF>(X + kpos, T.v, T.dd, T.scratch + wave * 72, P.down_ifreq_sd, P.down_ifreq_dsum, P.sync_a, P.sync_b);
+                    c = r.c; fine = r.fine; pz = r.pz;
                 }
-                if (lane == 0 && !is_ctl) { W.specf[wave][k] = c; W.speci[k][wave][0] = kvalid ? 1 : 0; W.speci[k][wave][1] = fine; }
+                if (lane == 0 && !is_ctl) { W.specf[wave][k] = c; W.speci[k][wave][0] = kvalid ? 1 : 0; W.speci[k][wave][1] = fine; W.speci[k][wave][2] = pz; }
             }
             __syncthreads();
             if (is_ctl) { // the whole control wavefront, uniformly, on a register copy of the state (as the decode rounds do)
@@ -829,10 +848,13 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 const int qw = lane % kW2Workers, qk = lane / kW2Workers; // lane q fetches window q = qk * workers + qw
                 const float my_c = lane < kSfdWin ? W.specf[qw][qk] : 0.0f;
                 const int32_t my_v = lane < kSfdWin ? W.speci[qk][qw][0] : 0, my_f = lane < kSfdWin ? W.speci[qk][qw][1] : 0;
+                const int32_t my_p = lane < kSfdWin ? W.speci[qk][qw][2] : 0;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                bool zreq = false;
                 for (int w = 0; w < kSfdWin; w++) {
                     if (w > 0 && !w2_pre_step(L, job, rec_cap, sps)) break;
                     if (!__builtin_amdgcn_readlane(my_v, w)) break;
+                    if (__builtin_amdgcn_readlane(my_p, w)) { zreq = true; break; } // a sample of exactly zero in this window: it opens a round of ZM evaluations
                     const float cw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int32_t, my_c), w));
                     int32_t fw = 0;
                     if (cw > 0.96f) { // :792
@@ -854,7 +876,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                     w2_end_step(L, job, C, recs, trace, kPause, consumed, -1, 0, 0.0f, t_start, t0);
                 }
                 W2Plan np;
-                plan_from(L, np);
+                plan_from(L, np, zreq);
                 if (t0) { next = np; S = L; }
             }
             continue;
@@ -920,13 +942,17 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 int32_t wfine = 0;
                 float wen = 0.0f;
                 if (dvalid) {
-                    if constexpr (GRAD) wave_demod_symbol_grad<SF>(P, FT.v, X + dwpos, P.implicit != 0u, ws, wfine, wen); // ws = bin_idx itself
+                    if (plan_z) { // (uniform) a round of ZM evaluations: a window of the previous round holds a sample of exactly zero
+                        const W2DemodZ z = w2_demod_zm<SF, GRAD>(P.enable_fine_sync, P.demod_mode, P.implicit != 0u, FT, X + dwpos);
+                        ws = z.s; wfine = z.fine; wen = z.en;
+                    } else
+                    if constexpr (GRAD) wave_demod_symbol_grad<SF>(P, FT.v, X + dwpos, P.implicit != 0u, ws, wfine, wen); // ws = bin_idx itself; kPoisonBin: see W2Plan.zmode
                     else wave_demod_symbol<SF, kWaveFmode<SF>>(P, FT, X + dwpos, ws, wfine, P.implicit != 0u ? &wen : nullptr, zs_mine);
                 }
                 if (lane == 0) { W.speci[plan_buf][widx][0] = dvalid ? (int32_t)ws : -1; W.speci[plan_buf][widx][1] = wfine; W.speci[plan_buf][widx][2] = __builtin_bit_cast(int32_t, wen); }
             }
         } else { // the whole control wavefront, uniformly (identical values in every lane); t0 does the stores
-            bool predicted = true;
+            bool predicted = true, zreq = false;
             const long long tr0 = clock64();
             uint32_t wpk[2] = {W.words_pk[0], W.words_pk[1]};
             W2State L = S; // the resolve works on a register copy: every field access in LDS is a ~130-cycle round trip
@@ -941,7 +967,9 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                     if (w > 0 && !w2_pre_step(L, job, rec_cap, sps)) break;
                     const int32_t sw = __builtin_amdgcn_readlane(my_s, w);
                     int32_t fw = __builtin_amdgcn_readlane(my_f, w);
-                    if (!(L.state == kDecodeHeader || L.state == kDecodePayload) || sw < 0) break;
+                    if (!(L.state == kDecodeHeader || L.state == kDecodePayload)) break;
+                    if (sw == (int32_t)kPoisonBin) { zreq = true; break; } // a sample of exactly zero in this window: it opens a round of ZM evaluations
+                    if (sw < 0) break;
                     const bool is_first = L.state == kDecodeHeader;
                     const int32_t st_w = L.state;
                     const uint32_t sres = (uint32_t)sw;
@@ -960,7 +988,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                     if (L.done || fw != 0) break; // later windows started at the wrong sample
                 }
                 // is the round the workers are computing right now the true continuation?
-                predicted = !L.done && !L.fin_pending && (L.state == kDecodeHeader || L.state == kDecodePayload) && L.pos == dpos &&
+                predicted = !zreq && !L.done && !L.fin_pending && (L.state == kDecodeHeader || L.state == kDecodePayload) && L.pos == dpos &&
                             w2_pre_step(L, job, rec_cap, sps);
             }
             const long long tr2 = clock64();
@@ -973,9 +1001,9 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                     n_next = rem < kW2Win ? (rem > 0 ? rem : 0) : kW2Win; // 0: nothing left to demodulate, only resolve
                 }
                 np.mode = kPlanDecode; np.pos = dpos + (int64_t)dn * sps; np.buf = plan_buf ^ 1; np.resolve_prev = 1; np.n_win = n_next;
-                np.prev_n = dn; np.pad = 0;
+                np.prev_n = dn; np.zmode = 0;
             } else {
-                plan_from(L, np); // this round's results are discarded
+                plan_from(L, np, zreq); // this round's results are discarded
             }
             const long long tr3 = clock64();
             if (t0) {

@@ -290,8 +290,8 @@ __device__ __forceinline__ void w3_atan2_x4(v2f y0, v2f x0, v2f y1, v2f x1, v2f 
 {
     const float ax00 = fabsf(x0.x), ay00 = fabsf(y0.x), ax01 = fabsf(x0.y), ay01 = fabsf(y0.y);
     const float ax10 = fabsf(x1.x), ay10 = fabsf(y1.x), ax11 = fabsf(x1.y), ay11 = fabsf(y1.y);
-    const float m00 = fmaxf(fmaxf(ax00, ay00), 1.0e-37f), m01 = fmaxf(fmaxf(ax01, ay01), 1.0e-37f); // atan2(0, 0) = 0
-    const float m10 = fmaxf(fmaxf(ax10, ay10), 1.0e-37f), m11 = fmaxf(fmaxf(ax11, ay11), 1.0e-37f);
+    const float m00 = fmaxf(ax00, ay00), m01 = fmaxf(ax01, ay01); // atan2(0, 0) = NaN: a zero product means a SAMPLE of exactly zero - the NaN poisons the sums it feeds and
+    const float m10 = fmaxf(ax10, ay10), m11 = fmaxf(ax11, ay11); // the window is evaluated again by the ZM instantiations (lean_atan2_pk, lora_wave_demod.inc.hip)
     v2f a0, a1;
     a0.x = fminf(ax00, ay00) * __builtin_amdgcn_rcpf(m00);
     a1.x = fminf(ax10, ay10) * __builtin_amdgcn_rcpf(m10);
@@ -325,9 +325,14 @@ __device__ __forceinline__ void w3_atan2_x4(v2f y0, v2f x0, v2f y1, v2f x1, v2f 
 // the ifreq of a thread's 16 chunk samples a[c] (n = c CH + base): f[c] = ifreq[n - 1] = arg(x[n] conj(x[n-1])), with the
 // predecessors x[n-1] loaded by the caller (a second, cache-hot round of coalesced loads: cheaper than moving the neighbour
 // lane's sample over with DPP and patching lane 0 from a boundary load - 8 VALU instructions per sample pair)
-template <bool FIRST>
+template <bool FIRST, bool ZM = false>
 __device__ __forceinline__ void w3_ifreq16(const v2f (&a)[16], const v2f (&ap)[16], bool n0_thread, float (&f)[16])
 {
+    if constexpr (ZM) { // every value as the reference forms it next to a sample of exactly zero (ifreq_prod_z, out of line)
+#pragma unroll
+        for (int c = 0; c < 16; c++) f[c] = (FIRST && c == 0 && n0_thread) ? 0.0f : ifreq_prod_z(make_float2(ap[c].x, ap[c].y), make_float2(a[c].x, a[c].y));
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < 16; c += 4) {
         if (c == 8) __builtin_amdgcn_sched_barrier(0);
@@ -348,7 +353,10 @@ __device__ __forceinline__ void w3_ifreq16(const v2f (&a)[16], const v2f (&ap)[1
 // want_energy.  Called by all threads of the workgroup (barriers inside); the results of every group come back uniform.
 struct W3DemodOut { uint32_t s[4]; int32_t fine[4]; float en[4]; int slot; };
 struct W3DemodArgs { const float2 *down, *ctab; const float *up_ifreq_v; uint32_t enable_fine_sync, demod_mode; };
-template <int SF, int HV = 0>
+// fine[g] of a POISONED window (a sample of exactly zero: the NaN of its products has reached the window's fine_sync sums): the caller has the round evaluated
+// again by the ZM = true instantiation, which forms every ifreq value as the reference does (std::arg(0) = 0: lora_kernels.hip, ifreq_prod_z)
+constexpr int32_t kFinePoison = 0x7ffffff0;
+template <int SF, int HV = 0, bool ZM = false>
 __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds<SF, HV> &L, const float2 *__restrict__ x, bool valid, bool want_energy, int &slot,
                                                uint32_t (&s_out)[W3Geom<SF, HV>::NG], int32_t (&fine_out)[W3Geom<SF, HV>::NG], float (&en_out)[W3Geom<SF, HV>::NG],
                                                long long *stamps = nullptr /* tools/demod_bench.py --stamps: clock per phase */)
@@ -357,6 +365,7 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
     LORA_W3STAMP(0);
     using G = W3Geom<SF, HV>;
     constexpr int N = G::N, SPS = G::SPS, TG = G::TG, CH = G::CH, M2 = G::M2, AR = G::AR, SA = G::SA, PAIRS = G::PAIRS, ROUNDS = G::ROUNDS, NG = G::NG, VT = G::VT, U = G::U;
+    constexpr bool LATE_F = G::LATE_F || ZM; // fine_sync's ifreq from a second read of the window: SF12 (registers), and every ZM evaluation
     int tt = threadIdx.x;
     asm volatile("" : "+v"(tt)); // keeps per-thread table addresses out of the caller's loop-invariant set
     const int grp = __builtin_amdgcn_readfirstlane(tt / TG), t = tt % TG;
@@ -367,7 +376,7 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
     v2f *data = L.data + (size_t)grp * G::data_entries;
     const uint32_t tu = (uint32_t)t;
 
-    float f[G::LATE_F ? 1 : PAIRS][16]; // ifreq[n - 1] of this thread's samples (kept from pass 1 unless LATE_F)
+    float f[LATE_F ? 1 : PAIRS][16]; // ifreq[n - 1] of this thread's samples (kept from pass 1 unless LATE_F)
     v2f hold[ROUNDS > 1 ? PAIRS : 1][8]; // SF12: rows 8..15 of pass 1 wait here for round 1
     float en = 0.0f;
 
@@ -382,7 +391,7 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
         for (int p = 0; p < PAIRS; p++) {
             const int base = p * TG + t;
             const uint32_t ob = 8u * ((uint32_t)(p * TG) + tu);
-            v2f a[16], ap[G::LATE_F ? 1 : 16], d[16];
+            v2f a[16], ap[LATE_F ? 1 : 16], d[16];
 #pragma unroll
             for (int c = 0; c < 16; c++) a[c] = nxt[c];
             if (p + 1 < PAIRS) { // the next pair's samples: in flight under this pair's arithmetic
@@ -390,7 +399,7 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
 #pragma unroll
                 for (int c = 0; c < 16; c++) nxt[c] = w3_ld2(xb, obn, (uint32_t)(c * CH * 8));
             }
-            if constexpr (!G::LATE_F) {
+            if constexpr (!LATE_F) {
                 if (want_fine) {
                     ap[0] = w3_ld2(xb, (p == 0) ? (ob >= 8u ? ob - 8u : 0u) : ob - 8u, 0u);
 #pragma unroll
@@ -404,7 +413,7 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
 #pragma unroll
                 for (int c = 0; c < 16; c++) en += a[c].x * a[c].x + a[c].y * a[c].y;
             }
-            if constexpr (!G::LATE_F) {
+            if constexpr (!LATE_F) {
                 if (want_fine) {
 #pragma unroll
                     for (int q = 0; q < 16; q += 4) {
@@ -414,8 +423,8 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
                         im1 = (v2f){a[q + 2].y * ap[q + 2].x - a[q + 2].x * ap[q + 2].y, a[q + 3].y * ap[q + 3].x - a[q + 3].x * ap[q + 3].y};
                         re1 = (v2f){a[q + 2].x * ap[q + 2].x + a[q + 2].y * ap[q + 2].y, a[q + 3].x * ap[q + 3].x + a[q + 3].y * ap[q + 3].y};
                         w3_atan2_x4(im0, re0, im1, re1, o0, o1);
-                        f[G::LATE_F ? 0 : p][q] = (p == 0 && q == 0 && t == 0) ? 0.0f : o0.x; // n = 0 has no predecessor in the window
-                        f[G::LATE_F ? 0 : p][q + 1] = o0.y; f[G::LATE_F ? 0 : p][q + 2] = o1.x; f[G::LATE_F ? 0 : p][q + 3] = o1.y;
+                        f[LATE_F ? 0 : p][q] = (p == 0 && q == 0 && t == 0) ? 0.0f : o0.x; // n = 0 has no predecessor in the window
+                        f[LATE_F ? 0 : p][q + 1] = o0.y; f[LATE_F ? 0 : p][q + 2] = o1.x; f[LATE_F ? 0 : p][q + 3] = o1.y;
                     }
                 }
             }
@@ -458,7 +467,7 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
 #pragma unroll
                 for (int c = 0; c < 16; c++) en += a[c].x * a[c].x + a[c].y * a[c].y;
             }
-            if constexpr (!G::LATE_F) {
+            if constexpr (!LATE_F) {
                 if (want_fine) {
                     // x[n - 1], eight at a time (a + all 16 predecessors + the dechirp table would not fit the register budget)
 #pragma unroll
@@ -480,8 +489,8 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
 #else
                             w3_atan2_x4(im0, re0, im1, re1, o0, o1);
 #endif
-                            f[G::LATE_F ? 0 : p][q] = (p == 0 && q == 0 && t == 0) ? 0.0f : o0.x; // n = 0 has no predecessor in the window
-                            f[G::LATE_F ? 0 : p][q + 1] = o0.y; f[G::LATE_F ? 0 : p][q + 2] = o1.x; f[G::LATE_F ? 0 : p][q + 3] = o1.y;
+                            f[LATE_F ? 0 : p][q] = (p == 0 && q == 0 && t == 0) ? 0.0f : o0.x; // n = 0 has no predecessor in the window
+                            f[LATE_F ? 0 : p][q + 1] = o0.y; f[LATE_F ? 0 : p][q + 2] = o1.x; f[LATE_F ? 0 : p][q + 3] = o1.y;
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -643,7 +652,7 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
                 v0[c] = w3_ld1(vb, 4u * nb, (uint32_t)(c * CH * 4 - 4)); v1[c] = w3_ld1(vb, 4u * nb, (uint32_t)(c * CH * 4)); v2[c] = w3_ld1(vb, 4u * nb, (uint32_t)(c * CH * 4 + 4));
             }
             float fl[16];
-            if constexpr (G::LATE_F) { // second read of the window
+            if constexpr (LATE_F) { // second read of the window
                 const uint32_t ob = 8u * nb;
                 v2f a[16], ap[16];
 #pragma unroll
@@ -651,16 +660,16 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
                 ap[0] = w3_ld2(xb, (p == 0) ? (ob >= 8u ? ob - 8u : 0u) : ob - 8u, 0u);
 #pragma unroll
                 for (int c = 1; c < 16; c++) ap[c] = w3_ld2(xb, ob, (uint32_t)(c * CH * 8 - 8));
-                if (p == 0) w3_ifreq16<true>(a, ap, t == 0, fl);
-                else w3_ifreq16<false>(a, ap, false, fl);
+                if (p == 0) w3_ifreq16<true, ZM>(a, ap, t == 0, fl);
+                else w3_ifreq16<false, ZM>(a, ap, false, fl);
             }
 #pragma unroll
             for (int c = 0; c < 16; c++) {
-                const float fk = G::LATE_F ? fl[c] : f[G::LATE_F ? 0 : p][c];
+                const float fk = LATE_F ? fl[c] : f[LATE_F ? 0 : p][c];
                 cs[0] += fk * v0[c]; cs[1] += fk * v1[c]; cs[2] += fk * v2[c];
             }
             if (p == PAIRS - 1 && t == TG - 1) { // ifreq[sps-1] = ifreq[sps-2] (:243): the duplicated tap at k = sps-1
-                const float flast = G::LATE_F ? fl[15] : f[G::LATE_F ? 0 : p][15];
+                const float flast = LATE_F ? fl[15] : f[LATE_F ? 0 : p][15];
                 const uint32_t ko = 4u * (uint32_t)(SPS - 1);
                 cs[0] += flast * w3_ld1(vb, ko, 0u); cs[1] += flast * w3_ld1(vb, ko, 4u); cs[2] += flast * w3_ld1(vb, ko, 8u);
             }
@@ -678,6 +687,7 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
         if (co[g][0] > mx) { mx = co[g][0]; lag = -1; }
         if (co[g][1] > mx) { mx = co[g][1]; lag = 0; }
         if (co[g][2] > mx) { mx = co[g][2]; lag = 1; }
+        if (!ZM && poisoned(co[g][0] + co[g][1] + co[g][2])) lag = -kFinePoison; // (every group's sums reach thread 0's wavefront, whose replay looks at them)
         fine_out[g] = __builtin_amdgcn_readfirstlane(-lag);
     }
 }
@@ -689,7 +699,7 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
 // (volk_32f_accumulator_s32f / D, :475-476) is three DPP adds, its left neighbour one lane permute - across wavefront and
 // chunk boundaries through a small LDS array (one value per wavefront, chunk and pair) - and the largest drop above 0.1
 // (:479-488) a first-maximum reduction over the group.  s_out[g] is demodulate()'s bin_idx itself.
-template <int SF, int HV = 0>
+template <int SF, int HV = 0, bool ZM = false>
 __device__ __forceinline__ void w3_demod_round_grad(const W3DemodArgs &P, const W3Lds<SF, HV> &L, const float2 *__restrict__ x, bool valid, bool want_energy, int &slot,
                                                     uint32_t (&s_out)[W3Geom<SF, HV>::NG], int32_t (&fine_out)[W3Geom<SF, HV>::NG], float (&en_out)[W3Geom<SF, HV>::NG])
 {
@@ -727,6 +737,10 @@ __device__ __forceinline__ void w3_demod_round_grad(const W3DemodArgs &P, const 
                 const uint32_t obn = (p == PAIRS - 1 && t == TG - 1) ? ob - 8u : ob;
 #pragma unroll
                 for (int c = 0; c < 8; c++) an[c] = w3_ld2(xb, (8 * h + c == 15) ? obn : ob, (uint32_t)((8 * h + c) * CH * 8 + 8));
+                if constexpr (ZM) {
+#pragma unroll
+                    for (int c = 0; c < 8; c++) f[p][8 * h + c] = ifreq_prod_z(make_float2(a[8 * h + c].x, a[8 * h + c].y), make_float2(an[c].x, an[c].y));
+                } else
 #pragma unroll
                 for (int c = 0; c < 8; c += 4) {
                     const int q = 8 * h + c;
@@ -757,6 +771,7 @@ __device__ __forceinline__ void w3_demod_round_grad(const W3DemodArgs &P, const 
     __syncthreads();
     float bv = 0.1f; // max_gradient = 0.1f (:479)
     int bi = 0x7fffffff;
+    float gsum = 0.0f; // (carries the poison of a zero sample when there is no fine_sync sum to carry it)
     if (valid) {
         const int perm_addr = ((lane - 8) & 63) << 2;
 #pragma unroll
@@ -774,6 +789,7 @@ __device__ __forceinline__ void w3_demod_round_grad(const W3DemodArgs &P, const 
                     left = (cc >= 0) ? edge[(pp * 16 + cc) * GW + ww] : 0.0f;
                 }
                 const float g = left - Apc; // samples_ifreq_avg[i - 1] - samples_ifreq_avg[i] (:482)
+                gsum += Apc;
                 const int i = (c * CH + p * TG + t) >> 3;
                 if (i >= 1 && g > bv) { bv = g; bi = i; } // strict '>' and ascending i: the first maximum
             }
@@ -794,7 +810,15 @@ __device__ __forceinline__ void w3_demod_round_grad(const W3DemodArgs &P, const 
 #pragma unroll
         for (int g = 0; g < NG; g++) en_out[g] = eo[g][0];
     }
-    if (!want_fine) return;
+    if (!want_fine) {
+        if constexpr (!ZM) { // (no fine_sync sums: the bin averages themselves say whether a window was poisoned - one more exchange, in this configuration only)
+            float g1[1] = {gsum}, go[NG][1];
+            w3_group_sums<SF, 1, HV>(g1, ws, slot, grp, gwave, go, all);
+#pragma unroll
+            for (int g = 0; g < NG; g++) fine_out[g] = poisoned(go[g][0]) ? kFinePoison : 0;
+        }
+        return;
+    }
     float cs[3] = {0.f, 0.f, 0.f};
     if (valid) { // fine_sync (:300-338), lags -1, 0, +1: c_lag = sum_k f[k] v[(bin_idx + 1) 8 + sps + lag + k]
         uint32_t bin_idx = s_out[0];
@@ -820,6 +844,7 @@ __device__ __forceinline__ void w3_demod_round_grad(const W3DemodArgs &P, const 
         if (co[g][0] > mx) { mx = co[g][0]; lag = -1; }
         if (co[g][1] > mx) { mx = co[g][1]; lag = 0; }
         if (co[g][2] > mx) { mx = co[g][2]; lag = 1; }
+        if (!ZM && poisoned(co[g][0] + co[g][1] + co[g][2])) lag = -kFinePoison; // (the bin averages next to the zero sample are NaN as well: the round is evaluated again)
         fine_out[g] = __builtin_amdgcn_readfirstlane(-lag);
     }
 }
@@ -933,8 +958,9 @@ __device__ __forceinline__ void w3_detect_round(const float2 *__restrict__ x0, i
 // prefix sums of f and (t - sps) f in double.  Thread tau owns the LEN shifts i0 = LEN tau ..: it computes f on
 // A = [i0, i0 + LEN) and on B = [i0 + n, i0 + n + LEN) straight from the samples, the workgroup scans the A and B sums,
 // and the thread slides over its shifts.  Returns the best correlation and its (first) shift.
-struct W3SyncOut { float bv; int bi; int slot; };
+struct W3SyncOut { float bv; int bi; int slot; int pz; }; // pz: the window holds a sample of exactly zero (the sums are NaN): to be evaluated again with ZM = true
 // ifreq[base .. base + 16) straight from the samples: f[j] = arg(x[base + j + 1] conj(x[base + j]))
+template <bool ZM>
 __device__ __forceinline__ void w3_sync_ifreq16(const __attribute__((address_space(1))) v2f *xv, int base, float (&f)[16])
 {
     v2f xs[17];
@@ -942,11 +968,11 @@ __device__ __forceinline__ void w3_sync_ifreq16(const __attribute__((address_spa
     for (int j = 0; j <= 16; j++) xs[j] = xv[base + j];
 #pragma unroll
     for (int j = 0; j < 16; j += 2) {
-        const v2f fp = ifreq_prod_pk(xs[j], xs[j + 1], xs[j + 1], xs[j + 2]);
+        const v2f fp = ZM ? ifreq_prod_pk_z(xs[j], xs[j + 1], xs[j + 1], xs[j + 2]) : ifreq_prod_pk(xs[j], xs[j + 1], xs[j + 1], xs[j + 2]);
         f[j] = fp.x; f[j + 1] = fp.y;
     }
 }
-template <int SF, int HV = 0>
+template <int SF, int HV = 0, bool ZM = false>
 __device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double sync_b, const float2 *__restrict__ x, W3Shared *wsp, int slot,
                                                        const float *__restrict__ strict_u /* d_upchirp_ifreq, or nullptr: closed form only */, float *strict_buf)
 {
@@ -968,8 +994,8 @@ __device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double syn
     if constexpr (CHUNKED) {
 #pragma unroll 1
         for (int q = 0; q < LEN; q += 16) {
-            w3_sync_ifreq16(xv, i0 + q, fa);
-            w3_sync_ifreq16(xv, i0 + n + q, fb);
+            w3_sync_ifreq16<ZM>(xv, i0 + q, fa);
+            w3_sync_ifreq16<ZM>(xv, i0 + n + q, fb);
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 s0A += (double)fa[j]; gA += (double)(i0 + q + j - SPS) * (double)fa[j];
@@ -984,7 +1010,7 @@ __device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double syn
         for (int j = 0; j <= LEN; j++) xa[j] = xv[i0 + j];
 #pragma unroll
         for (int j = 0; j < LEN; j += 2) {
-            const v2f fp = ifreq_prod_pk(xa[j], xa[j + 1], xa[j + 1], xa[j + 2 <= LEN ? j + 2 : LEN]);
+            const v2f fp = ZM ? ifreq_prod_pk_z(xa[j], xa[j + 1], xa[j + 1], xa[j + 2 <= LEN ? j + 2 : LEN]) : ifreq_prod_pk(xa[j], xa[j + 1], xa[j + 1], xa[j + 2 <= LEN ? j + 2 : LEN]);
             fa[j] = fp.x; fa[j + 1] = fp.y;
         }
     }
@@ -994,7 +1020,7 @@ __device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double syn
         for (int j = 0; j <= LEN; j++) xb[j] = xv[i0 + n + j];
 #pragma unroll
         for (int j = 0; j < LEN; j += 2) {
-            const v2f fp = ifreq_prod_pk(xb[j], xb[j + 1], xb[j + 1], xb[j + 2 <= LEN ? j + 2 : LEN]);
+            const v2f fp = ZM ? ifreq_prod_pk_z(xb[j], xb[j + 1], xb[j + 1], xb[j + 2 <= LEN ? j + 2 : LEN]) : ifreq_prod_pk(xb[j], xb[j + 1], xb[j + 1], xb[j + 2 <= LEN ? j + 2 : LEN]);
             fb[j] = fp.x; fb[j + 1] = fp.y;
         }
     }
@@ -1028,6 +1054,7 @@ __device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double syn
         ex[q] += pre; tot[q] = all;
     }
     const double flast = dr[64];
+    if (!ZM && w3_ub(poisoned((float)(tot[0] + tot[2])))) return W3SyncOut{0.0f, 0x7fffffff, slot, 1}; // (the same totals in every thread)
     // prefix sums over t < i0 and t < i0 + n:  F(i0) = exA,  F(i0 + n) = F(sps - 1) + exB,  F(sps - 1) = totA - f[sps-1]
     const double F0 = ex[0], G0 = ex[1];
     const double F1 = (tot[0] - flast) + ex[2], G1 = (tot[1] - (double)(SPS - 1 - SPS) * flast) + ex[3];
@@ -1039,8 +1066,8 @@ __device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double syn
     if constexpr (CHUNKED) {
 #pragma unroll 1
         for (int q = 0; q < LEN; q += 16) {
-            w3_sync_ifreq16(xv, i0 + q, fa);
-            w3_sync_ifreq16(xv, i0 + n + q, fb);
+            w3_sync_ifreq16<ZM>(xv, i0 + q, fa);
+            w3_sync_ifreq16<ZM>(xv, i0 + n + q, fb);
 #pragma unroll
             for (int rr = 0; rr < 16; rr++) {
                 const float c = (float)(sync_a * s0 + sync_b * s1);
@@ -1091,15 +1118,15 @@ __device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double syn
             bv = ev;
         }
     }
-    return W3SyncOut{bv, bi, slot};
+    return W3SyncOut{bv, bi, slot, 0};
 }
 
 // ---- FIND_SFD (:385-390, :283-298, :801-803): the windows q = k NG + grp, k < KS, at x0 + q sps ---------------------------
 // Pearson correlation of each window's ifreq with the ideal downchirp ifreq (one pass); for an upchirp (c < -0.97)
 // fine_sync(-1, 4 D) over the 63 lags in closed form (see w2_sfd_window for the derivation).  c[q] and fine[q] come back uniform.
-struct W3SfdOut { float c[8]; int32_t fine[8]; };
+struct W3SfdOut { float c[8]; int32_t fine[8]; uint32_t pz; }; // pz bit q: window q holds a sample of exactly zero (its sums are NaN): to be evaluated again with ZM = true
 struct W3SfdArgs { const float *down_ifreq, *up_ifreq_v; float down_ifreq_avg, down_ifreq_sd, down_ifreq_dsum; double sync_a, sync_b; };
-template <int SF, int HV = 0>
+template <int SF, int HV = 0, bool ZM = false>
 __device__ LORA_W3_SFD_INLINE W3SfdOut w3_sfd_round(W3SfdArgs P, const float2 *__restrict__ x0, int n_valid, W3AcqScratch *sc)
 {
     using G = W3Geom<SF, HV>;
@@ -1130,8 +1157,8 @@ __device__ LORA_W3_SFD_INLINE W3SfdOut w3_sfd_round(W3SfdArgs P, const float2 *_
                 dd[0] = w3_ld1(ddb, base >= 1 ? 4u * (uint32_t)(base - 1) : 0u, 0u);
 #pragma unroll
                 for (int c = 1; c < 16; c++) dd[c] = w3_ld1(ddb, 4u * (uint32_t)base, (uint32_t)(c * CH * 4 - 4));
-                if (p == 0) w3_ifreq16<true>(a, ap, t == 0, f);
-                else w3_ifreq16<false>(a, ap, false, f);
+                if (p == 0) w3_ifreq16<true, ZM>(a, ap, t == 0, f);
+                else w3_ifreq16<false, ZM>(a, ap, false, f);
 #pragma unroll
                 for (int c = 0; c < 16; c++) {
                     const float fk = f[c];
@@ -1164,12 +1191,14 @@ __device__ LORA_W3_SFD_INLINE W3SfdOut w3_sfd_round(W3SfdArgs P, const float2 *_
     bool any_up = false;
 #pragma unroll
     for (int q = 0; q < 8; q++) { R.c[q] = 0.0f; R.fine[q] = 0; }
+    R.pz = 0u;
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int w = 0; w < GW; w++) { s0 += sc->part[q][w][0]; s1 += sc->part[q][w][1]; s2 += sc->part[q][w][2]; }
         s0 = w3_uni(s0); s1 = w3_uni(s1); s2 = w3_uni(s2);
+        if (!ZM && q < n_valid && poisoned(s0)) R.pz |= 1u << q;
         const float nf = (float)(SPS - 1);
         const float average = s0 / nf;
         const float var = fmaxf(s1 / nf - average * average, 0.0f);
@@ -1319,6 +1348,27 @@ __device__ __forceinline__ void w3_touch(const float2 *X, int64_t first_item, in
 // SKIP (LaunchCfg.skip_payload): the header-only variant.  A packet's attempt ends behind its header: the record (kAttemptHeaderOnly) carries d_phdr, the
 // header block's spare codewords and d_payload_symbols, and the job goes on in DETECT where DECODE_PAYLOAD would end if no symbol moved the symbol
 // clock.  The payload symbols are demodulated by the payload pass - all of them at once, over the whole device - and the host checks the assumption.
+// ---- the ZM evaluation of a decode round (a window of the previous round holds a sample of exactly zero: kFinePoison), out of line: it runs in a round of its
+// own, for the rare window only, and must neither grow the ordinary round's code nor take part in its register allocation ----------------------------------
+#ifndef LORA_W3_ZM_ATTR
+#define LORA_W3_ZM_ATTR __attribute__((noinline)) // (inlined into the round loop it cost SF9-SF12 another 1.5-4 %: profiles/r05_ab_zero_samples.txt)
+#endif
+template <int SF, bool GRAD, int HV>
+__device__ LORA_W3_ZM_ATTR W3DemodOut w3_demod_round_zm(W3DemodArgs DA, W3Lds<SF, HV> L, const float2 *xg, bool dvalid, bool want_energy, int slot)
+{
+    constexpr int NG = W3Geom<SF, HV>::NG;
+    uint32_t sq[NG];
+    int32_t fq[NG];
+    float eq[NG];
+    if constexpr (GRAD) w3_demod_round_grad<SF, HV, true>(DA, L, xg, dvalid, want_energy, slot, sq, fq, eq);
+    else w3_demod_round<SF, HV, true>(DA, L, xg, dvalid, want_energy, slot, sq, fq, eq);
+    W3DemodOut o{};
+#pragma unroll
+    for (int g = 0; g < NG; g++) { o.s[g] = sq[g]; o.fine[g] = fq[g]; o.en[g] = eq[g]; }
+    o.slot = slot;
+    return o;
+}
+
 template <int SF, bool GRAD, int HV = 0, bool SKIP = false>
 __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg &C)
 {
@@ -1348,8 +1398,8 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
     w3_tables_to_lds<SF, HV>(P, L);
 
     // plan for the next round from the TRUE state (thread 0 only)
-    auto plan_from = [&](W2State &St, W2Plan &pl) {
-        pl.buf = 0; pl.resolve_prev = 0; pl.n_win = NG; pl.pos = St.pos; pl.prev_n = 0; pl.pad = 0;
+    auto plan_from = [&](W2State &St, W2Plan &pl, bool zreq = false /* a window of this round came back poisoned (a sample of exactly zero): the next round is a ZM one */) {
+        pl.buf = 0; pl.resolve_prev = 0; pl.n_win = NG; pl.pos = St.pos; pl.prev_n = 0; pl.zmode = zreq ? 1 : 0;
         if (!St.done) (void)w2_pre_step(St, job, rec_cap, sps);
         if (St.done) { pl.mode = kPlanExit; return; }
         if (St.fin_pending) { pl.mode = kPlanFinalize; return; }
@@ -1389,6 +1439,7 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
         const uint64_t pl_pp = (uint64_t)pl_in.pos;
         const int64_t pos = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(pl_pp >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)pl_pp));
         const int32_t plan_mode = __builtin_amdgcn_readfirstlane(pl_in.mode), plan_n_win = __builtin_amdgcn_readfirstlane(pl_in.n_win);
+        const int32_t plan_z = __builtin_amdgcn_readfirstlane(pl_in.zmode); // kPlanDecode / kPlanSfd: this round's windows by the ZM instantiations (W2Plan.zmode)
         W2Plan &next = ws.plan[(it + 1u) & 1u];
         if (plan_mode == kPlanExit) break;
         const long long t_start = clock64();
@@ -1450,7 +1501,11 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
         }
 
         if (plan_mode == kPlanSync) { // :770-783
-            const W3SyncOut so = w3_sync<SF, HV>(P.sync_a, P.sync_b, X + pos, &ws, slot, P.strict_sync ? P.up_ifreq : nullptr, reinterpret_cast<float *>(L.data));
+            W3SyncOut so = w3_sync<SF, HV>(P.sync_a, P.sync_b, X + pos, &ws, slot, P.strict_sync ? P.up_ifreq : nullptr, reinterpret_cast<float *>(L.data));
+            if (__builtin_amdgcn_readfirstlane(so.pz)) { // a sample of exactly zero in the window (the closed form's sums are NaN): once more, every ifreq value as the reference forms it
+                __syncthreads(); // (the scan's exchange area is written again)
+                so = w3_sync<SF, HV, true>(P.sync_a, P.sync_b, X + pos, &ws, slot, P.strict_sync ? P.up_ifreq : nullptr, reinterpret_cast<float *>(L.data));
+            }
             slot = __builtin_amdgcn_readfirstlane(so.slot);
             if (t0) {
                 W2State St = S;
@@ -1466,12 +1521,15 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
 
         if (plan_mode == kPlanSfd) { // :785-818
             constexpr int NQ = W3Acq<SF, HV>::NQS;
-            const W3SfdOut fo = w3_sfd_round<SF, HV>(W3SfdArgs{P.down_ifreq, P.up_ifreq_v, P.down_ifreq_avg, P.down_ifreq_sd, P.down_ifreq_dsum, P.sync_a, P.sync_b}, X + pos,
-                                                 n_in_data < NQ ? n_in_data : NQ, acq);
+            const W3SfdArgs sfa{P.down_ifreq, P.up_ifreq_v, P.down_ifreq_avg, P.down_ifreq_sd, P.down_ifreq_dsum, P.sync_a, P.sync_b};
+            const W3SfdOut fo = plan_z ? w3_sfd_round<SF, HV, true>(sfa, X + pos, n_in_data < NQ ? n_in_data : NQ, acq)
+                                       : w3_sfd_round<SF, HV>(sfa, X + pos, n_in_data < NQ ? n_in_data : NQ, acq);
             if (t0) {
                 W2State St = S;
+                bool zreq = false;
                 for (int g = 0; g < NQ; g++) {
                     if (g > 0 && (St.state != kFindSfd || !w2_pre_step(St, job, rec_cap, sps))) break;
+                    if ((fo.pz >> g) & 1u) { zreq = true; break; } // a sample of exactly zero in this window: it opens a round of ZM evaluations
                     // a tail probe with Job.tail_stop_sfd has seen enough once it stands at the start of its SECOND FIND_SFD step: the first
                     // one's fine_sync(-1, 4 D) (:801-803) has pulled it onto the chirp boundary its successor's own attempt passes through,
                     // and (position, d_corr_fails) is all that :785-818 read - the stitch matches it against that attempt's record
@@ -1507,7 +1565,7 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                     w2_end_step<true>(St, job, C, recs, trace, kPause, consumed, -1, 0, 0.0f, t_start);
                 }
                 W2Plan np;
-                plan_from(St, np);
+                plan_from(St, np, zreq);
                 next = np; S = St;
             }
             continue;
@@ -1555,9 +1613,18 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
             uint32_t sq[NG];
             int32_t fq[NG];
             float eq[NG];
-            if constexpr (GRAD) w3_demod_round_grad<SF, HV>(DA, L, xg, dvalid, P.implicit != 0u, slot, sq, fq, eq); // sq = bin_idx itself
+            if (plan_z) { // (uniform) a round of ZM evaluations: a window of the previous round holds a sample of exactly zero
+                const W3DemodOut zo = w3_demod_round_zm<SF, GRAD, HV>(DA, L, xg, dvalid, P.implicit != 0u, slot);
+#pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    sq[g] = (uint32_t)__builtin_amdgcn_readfirstlane((int)zo.s[g]); fq[g] = __builtin_amdgcn_readfirstlane(zo.fine[g]); eq[g] = w3_uni(zo.en[g]);
+                }
+                slot = __builtin_amdgcn_readfirstlane(zo.slot);
+            } else
+            if constexpr (GRAD) w3_demod_round_grad<SF, HV>(DA, L, xg, dvalid, P.implicit != 0u, slot, sq, fq, eq); // sq = bin_idx itself; fq = kFinePoison: see W2Plan.zmode
             else w3_demod_round<SF, HV>(DA, L, xg, dvalid, P.implicit != 0u, slot, sq, fq, eq);
             if (t0) {
+                bool zreq = false;
 #if LORA_W3_REPLAY_STATS
                 const long long tr0 = clock64(); // (LORA_HIP_DEBUG accounting: ctl[0] = the demodulation, ctl[1] = thread 0's replay, of the decode rounds)
                 ws.stats.ctl[0] += (uint32_t)((tr0 - t_start) >> 6);
@@ -1601,6 +1668,7 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                     float eg = eq[0];
 #pragma unroll
                     for (int q = 1; q < NG; q++) if (g == q) { sg = sq[q]; fg = fq[q]; eg = eq[q]; }
+                    if (fg == kFinePoison) { zreq = true; break; } // a sample of exactly zero in this window: it opens a round of ZM evaluations
                     const bool is_first = St.state == kDecodeHeader;
                     const int32_t st_w = St.state;
                     bool do_demod = true;
@@ -1641,7 +1709,7 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                 ws.stats.ctl[3] += (uint32_t)((clock64() - tr1) >> 6);
 #endif
                 W2Plan np;
-                plan_from(St, np);
+                plan_from(St, np, zreq);
                 next = np; S = St;
 #if LORA_W3_REPLAY_STATS
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1772,6 +1840,22 @@ __global__ __launch_bounds__((W3Geom<SF, HV>::T), (W3Geom<SF, HV>::T512 ? 2 : 4)
             }
         }
         __syncthreads();
+        { // a window with a sample of exactly zero comes back as kFinePoison: the round once more, by the ZM instantiations (every ifreq value as the reference forms it)
+            bool pz = false;
+#pragma unroll
+            for (int g = 0; g < G::NG; g++) pz = pz || __builtin_amdgcn_readfirstlane(fs_all[g]) == kFinePoison;
+            if (pz) { // (uniform over the workgroup)
+                if constexpr (GRAD) w3_demod_round_grad<SF, HV, true>(DA, L, iq + offsets[valid ? s0 + grp : s0], valid, false, slot, b, fs, en);
+                else w3_demod_round<SF, HV, true>(DA, L, iq + offsets[valid ? s0 + grp : s0], valid, false, slot, b, fs, en, nullptr);
+                if (threadIdx.x == 0) {
+                    for (int g = 0; g < G::NG; g++) {
+                        if (s0 + (uint32_t)g < n) { bins[s0 + g] = b[g]; if (fine) fine[s0 + g] = fs[g]; }
+                        fs_all[g] = fs[g];
+                    }
+                }
+                __syncthreads();
+            }
+        }
         if (alt.shift) { // second reads (DemodAlt): the successors of the symbols that moved the symbol clock, that far further on
 #pragma unroll
             for (int g = 0; g < G::NG; g++) fs[g] = __builtin_amdgcn_readfirstlane(fs_all[g]);
@@ -1797,6 +1881,7 @@ __global__ __launch_bounds__((W3Geom<SF, HV>::T), (W3Geom<SF, HV>::T512 ? 2 : 4)
                         const int64_t o0 = offsets[s0 + g], o1 = offsets[s0 + g + 1];
                         const int64_t a = o1 + (int64_t)fs[g];
                         if (o1 != o0 + (int64_t)G::SPS || a < 0 || a > alt.max_start) continue;
+                        if (f2[g] == kFinePoison) continue; // (a zero sample in the second window: no second read on offer - the walk asks for this shift as a read of its own)
                         alt.bins[s0 + g + 1] = b2[g]; alt.fine[s0 + g + 1] = f2[g]; alt.shift[s0 + g + 1] = fs[g];
                     }
                 }

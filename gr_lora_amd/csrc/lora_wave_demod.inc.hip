@@ -182,10 +182,14 @@ __device__ __host__ constexpr int wave_layout_bin(int J, int logj, int g, int la
 __device__ __forceinline__ v2f lean_atan2_pk(v2f y, v2f x)
 {
     const float ax0 = fabsf(x.x), ay0 = fabsf(y.x), ax1 = fabsf(x.y), ay1 = fabsf(y.y);
-    const float mx0 = fmaxf(fmaxf(ax0, ay0), 1.0e-37f), mx1 = fmaxf(fmaxf(ax1, ay1), 1.0e-37f); // atan2(0, 0) = 0
+    // atan2(0, 0) = NaN (0 * rcp(0)): a zero PRODUCT x[n] conj(x[n-1]) means a SAMPLE of exactly zero, next to which the reference's value is not the
+    // product's argument at all (std::arg(0) = 0: lora_kernels.hip, ifreq_prod_z).  The NaN poisons the sums the value feeds; every consumer checks its
+    // (uniform) sum once per window and has a poisoned window evaluated again, sample by sample, in a round of its own (kPoisonBin / ZM below).
     v2f a;
-    // (written out: behind inline-asm producers the compiler canonicalises both fminf operands with a v_max x, x each)
-    float mn0, mn1;
+    // (written out: behind inline-asm producers the compiler canonicalises both fminf / fmaxf operands with a v_max x, x each)
+    float mn0, mn1, mx0, mx1;
+    asm("v_max_f32_e64 %0, |%1|, |%2|" : "=v"(mx0) : "v"(x.x), "v"(y.x));
+    asm("v_max_f32_e64 %0, |%1|, |%2|" : "=v"(mx1) : "v"(x.y), "v"(y.y));
     asm("v_min_f32_e64 %0, |%1|, |%2|" : "=v"(mn0) : "v"(x.x), "v"(y.x));
     asm("v_min_f32_e64 %0, |%1|, |%2|" : "=v"(mn1) : "v"(x.y), "v"(y.y));
     a.x = mn0 * __builtin_amdgcn_rcpf(mx0);
@@ -225,6 +229,16 @@ __device__ __forceinline__ v2f ifreq_prod_pk(v2f p0, v2f c0, v2f p1, v2f c1)
     return lean_atan2_pk((v2f){y0, y1}, (v2f){x0, x1});
 }
 
+// ... and with the reference's convention next to a sample that is exactly zero (ZM paths; ifreq_prod_z is out of line)
+__device__ __forceinline__ v2f ifreq_prod_pk_z(v2f p0, v2f c0, v2f p1, v2f c1)
+{
+    return (v2f){ifreq_prod_z(make_float2(p0.x, p0.y), make_float2(c0.x, c0.y)), ifreq_prod_z(make_float2(p1.x, p1.y), make_float2(c1.x, c1.y))};
+}
+__device__ __forceinline__ bool poisoned3(float a, float b, float c) { return poisoned(a + b + c); }
+// what a demodulator returns in place of the bin for a POISONED window (a sample of exactly zero: its fine_sync sums are NaN): the caller has the
+// window evaluated again by the ZM = true instantiation, which forms every ifreq value as the reference does (walkers: a round of its own)
+constexpr uint32_t kPoisonBin = 0xfffffffeu;
+
 // Demodulates the symbol window x[0 .. sps): s_out = get_shift_fft's return value, fine_out = d_fine_sync after
 // fine_sync(bin_idx, 2) (0 when drift correction is disabled).  Must be called by a whole wavefront.
 // FMODE: where fine_sync's instantaneous frequency comes from - 0: a second, cache-hot read of the window behind the FFT; 1: the registers
@@ -248,12 +262,13 @@ __device__ __forceinline__ v2f ifreq_prod_pk(v2f p0, v2f c0, v2f p1, v2f c1)
 // windows: clean, noisy down to -6 dB, interferers, carrier offsets, partial windows); tests/test_gpu_ffs.py holds the kernel to the oracle.
 template <int SF> constexpr int kWaveFfsEntries = (8 << SF) / 4 + 4;
 template <int SF> constexpr int kWaveFmode = ((LORA_W2_FFS >> (SF - 7)) & 1) ? 2 : ((SF == 7) || LORA_W2_EARLY_F_SF8) ? 1 : 0;
-template <int SF, int FMODE>
+template <int SF, int FMODE_, bool ZM = false>
 __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const WaveTabs &T, const float2 *__restrict__ x, uint32_t &s_out, int32_t &fine_out,
                                                   float *en_out = nullptr /* implicit header: the window's energy (determine_energy, :368-375) */,
                                                   v2f *zs = nullptr /* FMODE 2: LDS scratch of this wavefront */,
                                                   long long *stamps = nullptr /* tools/probe_phases.hip */)
 {
+    constexpr int FMODE = ZM ? 3 : FMODE_; // ZM: fine_sync's ifreq sample by sample with std::arg(0) = 0, in a rolled loop behind the arg-max (mode 3)
     constexpr bool EARLY_F = FMODE == 1;
 #define LORA_WSTAMP(i) do { if (stamps) stamps[i] = clock64(); } while (0)
     LORA_WSTAMP(0);
@@ -487,6 +502,15 @@ __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const Wave
     // immediate offsets.  (Lane 0, j = 0 has no k: its f is 0 and it reads the finite table entries in front of v.)
     const float *__restrict__ vp = v + (nl - 2);
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    if constexpr (ZM) { // the window again from memory, every ifreq value as the reference forms it (ifreq_prod_z); rolled: this path is rare
+#pragma unroll 1
+        for (int j = 0; j < J; j++) {
+            const int n = 64 * j + nl;
+            const float fj = n >= 1 ? ifreq_prod_z(x[n - 1], x[n]) : 0.0f; // ifreq[n - 1]
+            c0 += fj * vp[64 * j]; c1 += fj * vp[64 * j + 1]; c2 += fj * vp[64 * j + 2];
+            if (j == J - 1 && nl == 63) { c0 += fj * vp[64 * j + 1]; c1 += fj * vp[64 * j + 2]; c2 += fj * vp[64 * j + 3]; } // ifreq[sps-1] = ifreq[sps-2] (:243)
+        }
+    } else {
 #pragma unroll
     for (int j = 0; j < J; j++) {
         const float fj = f[j];
@@ -496,7 +520,9 @@ __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const Wave
             c0 += fl * vp[64 * j + 1]; c1 += fl * vp[64 * j + 2]; c2 += fl * vp[64 * j + 3];
         }
     }
+    }
     c0 = wave_sum_u(c0); c1 = wave_sum_u(c1); c2 = wave_sum_u(c2);
+    if (!ZM && poisoned3(c0, c1, c2)) { s_out = kPoisonBin; return; } // (uniform) a sample of the window is exactly zero
     float mx = 0.0f;
     int32_t lag = 0;
     if (c0 > mx) { mx = c0; lag = -1; }
@@ -515,7 +541,9 @@ __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const Wave
 // group of eight lanes of register j: the bin average is three v_add with a DPP operand, its left neighbour one lane permute.
 // ifreq[sps-1] = ifreq[sps-2] (:243).  bin_out is demodulate()'s bin_idx itself (the FFT path's (s - 1) mod N); en_out the
 // window's energy (determine_energy, :368-375) when want_energy.
-template <int SF>
+// ZM = true: the evaluation of a window that holds a sample of exactly zero (see kPoisonBin) - the same estimator from memory, every ifreq value formed as
+// the reference forms it (ifreq_prod_z), rolled.
+template <int SF, bool ZM = false>
 __device__ __forceinline__ void wave_demod_symbol_grad(const DevParams &P, const float *__restrict__ Tv, const float2 *__restrict__ x, bool want_energy,
                                                        uint32_t &bin_out, int32_t &fine_out, float &en_out)
 {
@@ -523,6 +551,62 @@ __device__ __forceinline__ void wave_demod_symbol_grad(const DevParams &P, const
     constexpr int N = G::N, J = G::J, SPS = G::SPS;
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane)); // (as in wave_demod_symbol: keeps per-lane addresses out of the caller's loop-invariant set)
+    if constexpr (ZM) {
+        en_out = 0.0f;
+        if (want_energy) { // (the same sums in the same order as below)
+            const auto xe = (const __attribute__((address_space(1))) v2f *)x;
+            v2f e2 = (v2f){0.0f, 0.0f};
+#pragma unroll 1
+            for (int j = 0; j < J; j++) { const v2f aj = xe[j * 64 + lane]; e2 = __builtin_elementwise_fma(aj, aj, e2); }
+            en_out = wave_sum_u(e2.x + e2.y);
+        }
+        auto fz = [&](int j) { // ifreq[n], n = 64 j + lane; ifreq[sps-1] = ifreq[sps-2] (:243)
+            int n = 64 * j + lane;
+            n = n == SPS - 1 ? SPS - 2 : n;
+            return ifreq_prod_z(x[n], x[n + 1]);
+        };
+        float bv = 0.1f;
+        int bi = 0x7fffffff;
+        {
+            const int m = lane >> 3;
+            const int perm_addr = ((lane - 8) & 63) << 2;
+            float prev_perm = 0.0f;
+#pragma unroll 1
+            for (int j = 0; j < J; j++) {
+                float A = fz(j);
+                A += dpp_f<kDppQuadXor1>(A); A += dpp_f<kDppQuadXor2>(A); A += dpp_f<kDppRowHalfMirror>(A);
+                A *= 0.125f;
+                const float perm = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm_addr, __builtin_bit_cast(int, A)));
+                const float left = (m == 0) ? prev_perm : perm;
+                prev_perm = perm;
+                const float g = left - A;
+                const int i = 8 * j + m;
+                if ((j > 0 || m > 0) && g > bv) { bv = g; bi = i; }
+            }
+        }
+        const float best = wave_max_nonneg_u(bv);
+        const int first = wave_min_u((bv == best) ? bi : 0x7fffffff);
+        const uint32_t max_index = (first == 0x7fffffff) ? 0u : (uint32_t)first + 1u; // :486
+        const uint32_t bin_idx = ((uint32_t)N - max_index) % (uint32_t)N;              // :490
+        bin_out = bin_idx;
+        fine_out = 0;
+        if (P.enable_fine_sync == 0u) return;
+        const float *__restrict__ vp = Tv + ((int)(bin_idx + 1u) * 8 + SPS) + (lane - 1);
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll 1
+        for (int j = 0; j < J; j++) {
+            const float fj = fz(j);
+            c0 += fj * vp[64 * j]; c1 += fj * vp[64 * j + 1]; c2 += fj * vp[64 * j + 2];
+        }
+        c0 = wave_sum_u(c0); c1 = wave_sum_u(c1); c2 = wave_sum_u(c2);
+        float mx = 0.0f;
+        int32_t lag = 0;
+        if (c0 > mx) { mx = c0; lag = -1; }
+        if (c1 > mx) { mx = c1; lag = 0; }
+        if (c2 > mx) { mx = c2; lag = 1; }
+        fine_out = -lag;
+        return;
+    }
     const auto xv = (const __attribute__((address_space(1))) v2f *)x;
     v2f a[J];
 #pragma unroll
@@ -554,6 +638,7 @@ __device__ __forceinline__ void wave_demod_symbol_grad(const DevParams &P, const
     // bin averages (:474-477) and the largest drop (:479-488)
     float bv = 0.1f; // max_gradient = 0.1f
     int bi = 0x7fffffff;
+    float gs = 0.0f; // (carries the poison of a zero sample when there is no fine_sync sum to carry it)
     {
         const int m = lane >> 3;
         const int perm_addr = ((lane - 8) & 63) << 2;
@@ -567,6 +652,7 @@ __device__ __forceinline__ void wave_demod_symbol_grad(const DevParams &P, const
             const float left = (m == 0) ? prev_perm : perm; // bin i - 1: for m = 0 bin 7 of the previous register
             prev_perm = perm;
             const float g = left - A; // samples_ifreq_avg[i - 1] - samples_ifreq_avg[i]
+            gs += A;
             const int i = 8 * j + m;
             if ((j > 0 || m > 0) && g > bv) { bv = g; bi = i; } // i runs from 1; strict '>' keeps the first maximum
         }
@@ -577,7 +663,10 @@ __device__ __forceinline__ void wave_demod_symbol_grad(const DevParams &P, const
     const uint32_t bin_idx = ((uint32_t)N - max_index) % (uint32_t)N;              // :490
     bin_out = bin_idx;
     fine_out = 0;
-    if (P.enable_fine_sync == 0u) return;
+    if (P.enable_fine_sync == 0u) {
+        if (poisoned(wave_sum_u(gs))) bin_out = kPoisonBin; // (a sample of exactly zero in the window)
+        return;
+    }
     // fine_sync (:300-338), lags -1, 0, +1: c_lag = sum_k f[k] v[(bin_idx + 1) 8 + sps + lag + k], k = 64 j + lane
     const float *__restrict__ vp = Tv + ((int)(bin_idx + 1u) * 8 + SPS) + (lane - 1);
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
@@ -587,6 +676,7 @@ __device__ __forceinline__ void wave_demod_symbol_grad(const DevParams &P, const
         c0 += fj * vp[64 * j]; c1 += fj * vp[64 * j + 1]; c2 += fj * vp[64 * j + 2];
     }
     c0 = wave_sum_u(c0); c1 = wave_sum_u(c1); c2 = wave_sum_u(c2);
+    if (poisoned3(c0, c1, c2)) { bin_out = kPoisonBin; return; } // (uniform) a sample of the window is exactly zero: the bin averages next to it are NaN as well
     float mx = 0.0f;
     int32_t lag = 0;
     if (c0 > mx) { mx = c0; lag = -1; }
@@ -676,6 +766,7 @@ __global__ __launch_bounds__(256) void demod_symbols_wave_kernel(DevParams P, co
         uint32_t b;
         int32_t fs;
         wave_demod_symbol<SF, kWaveFmode<SF>>(P, T, iq + offsets[s], b, fs, nullptr, zs);
+        if (b == kPoisonBin) wave_demod_symbol<SF, kWaveFmode<SF>, true>(P, T, iq + offsets[s], b, fs, nullptr, zs); // (uniform) a window with a sample of exactly zero
         if ((threadIdx.x & 63u) == 0u) { bins[s] = b; if (fine) fine[s] = fs; }
     }
 }
@@ -694,6 +785,7 @@ __global__ __launch_bounds__(256) void demod_symbols_wave_grad_kernel(DevParams 
         int32_t fs;
         float en;
         wave_demod_symbol_grad<SF>(P, lds_v, iq + offsets[s], false, b, fs, en);
+        if (b == kPoisonBin) wave_demod_symbol_grad<SF, true>(P, lds_v, iq + offsets[s], false, b, fs, en); // (uniform) a window with a sample of exactly zero
         if ((threadIdx.x & 63u) == 0u) { bins[s] = b; if (fine) fine[s] = fs; }
     }
 }

@@ -15,21 +15,11 @@ of states, every position within one sample, identical frames (checked by the ca
 import numpy as np
 
 
-def windows_with_exact_zeros(otr, iq, sps):
-    """decode steps whose symbol window holds a sample that is EXACTLY zero (the silence a synthetic stream ends in): the reference's
-    arg(0) = 0 turns the instantaneous frequency next to it into -arg(x[k]), the kernels' arg(x[k+1] conj x[k]) into 0 - a deviation
-    that exists only on synthetic zeros and that only the gradient estimator can see, in the bin of that one window"""
-    import numpy as np
-    return {i for i, b in enumerate(otr) if b[0] in (4, 5) and bool(np.any(iq[b[1]:b[1] + sps + 1] == 0))}
-
-
-def assert_trace_parity(tr, otr, exact, tag=None, skip_bin=()):
+def assert_trace_parity(tr, otr, exact, tag=None):
     assert len(tr) == len(otr), (tag, len(tr), len(otr))
     off = 0
     for i, (a, b) in enumerate(zip(tr, otr)):
-        if exact and i in skip_bin:
-            assert tuple(a[:3]) == tuple(b[:3]) and a[4] == b[4], (tag, i, a, b)
-        elif exact:
+        if exact:
             assert tuple(a[:5]) == tuple(b[:5]), (tag, i, a, b)
             if np.isfinite(b[5]):
                 assert abs(a[5] - b[5]) <= 1e-3 * max(1.0, abs(b[5])), (tag, i, a, b)
