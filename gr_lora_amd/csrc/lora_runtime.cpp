@@ -337,7 +337,7 @@ lora_hip_status build_tables(lora_hip_decoder *h)
         for (uint32_t k = 0; k < n; k++) { sk += k; su += up_ifreq[k]; skk += (double)k * k; sku += (double)k * up_ifreq[k]; }
         P.sync_b = (n * sku - sk * su) / (n * skk - sk * sk);
         P.sync_a = (su - P.sync_b * sk) / n;
-        P.sync_closed_form = (sps >= 4096u && !getenv("LORA_HIP_SYNC_DIRECT")) ? 1u : 0u;
+        P.sync_closed_form = sps >= 4096u ? 1u : 0u;
         // near-tied SYNC shifts decided by the reference's own float sums (lora_strict_sync.inc.hip): on unless the caller opts out
         P.strict_sync = (c.flags & LORA_HIP_FLAG_FAST_SYNC) ? 0u : 1u;
         if (const char *e = getenv("LORA_HIP_STRICT_SYNC")) P.strict_sync = (e[0] != '0') ? 1u : 0u; // (A/B runs)
@@ -707,7 +707,8 @@ static lora_hip_status payload_launch_round(lora_hip_decoder *h, const float2 *d
     const bool no_alt = getenv("LORA_HIP_NO_SECOND_READS") != nullptr; // diagnostics / tests: every move of the symbol clock costs a round
     int64_t buf_end = 0; // the pass's streams end here at the latest: second reads stay inside the buffer (whether they stay inside their stream is the walk's check)
     for (const PayloadReq &q : reqs) buf_end = std::max<int64_t>(buf_end, (int64_t)(q.stream_off + q.stream_len));
-    const DemodAlt alt{no_alt ? nullptr : h->d_alt_shift.p, h->d_alt_bins.p, h->d_alt_fine.p, buf_end - 2 * sps};
+    const bool has_alt = walker3_covers(h->P.sf); // (second reads are the workgroup-per-symbol kernels'; with the wave-per-symbol ones, SF7 / SF8, every move of the symbol clock costs a round)
+    const DemodAlt alt{(no_alt || !has_alt) ? nullptr : h->d_alt_shift.p, h->d_alt_bins.p, h->d_alt_fine.p, buf_end - 2 * sps};
     // this round's reads: for every active packet the symbols from `at` on, `shift` behind their zero-drift positions
     size_t n_sym = 0;
     for (uint32_t i : ps.active) {
@@ -729,7 +730,7 @@ static lora_hip_status payload_launch_round(lora_hip_decoder *h, const float2 *d
         HIP_TRY(h, hipMemcpyAsync(h->d_offsets.p, h->p_pay_off.p, n_sym * sizeof(int64_t), hipMemcpyHostToDevice, st));
         DemodAlt ar{alt.shift ? alt.shift + ps.used : nullptr, alt.bins + ps.used, alt.fine + ps.used, alt.max_start};
         if (ar.shift) HIP_TRY(h, hipMemsetAsync(ar.shift, 0, n_sym * sizeof(int32_t), st));
-        if (launch_demod_symbols(h->P, d_iq, h->d_offsets.p, (uint32_t)n_sym, (int)h->P.demod_mode, h->d_bins.p + ps.used, h->d_fine.p + ps.used, nullptr, st, &ar) != 0)
+        if (launch_demod_symbols(h->P, d_iq, h->d_offsets.p, (uint32_t)n_sym, (int)h->P.demod_mode, h->d_bins.p + ps.used, h->d_fine.p + ps.used, nullptr, st, has_alt ? &ar : nullptr) != 0)
             return fail(h, LORA_HIP_ERR_HIP, "payload pass: symbol launch failed: %s", hipGetErrorString(hipGetLastError()));
     }
     // (launch entry a writes PayloadOut[a]; payload_pass_end spreads them to the packets' own slots)
@@ -860,7 +861,7 @@ struct DeviceEnv {
         if (h->decoupled_policy == 1) return true;
         if (h->dec_backoff) return false; // (counted down once per pass: count_jobs)
         const uint32_t full = resident_slots_alt() ? resident_slots_alt() : resident_slots();
-        static const uint32_t fill = getenv("LORA_HIP_DEC_MAX_FILL") ? (uint32_t)atoi(getenv("LORA_HIP_DEC_MAX_FILL")) : 100u; // percent of the workgroup slots (config 4, 8 s per pass: 54.5 Gsamples/s ordinary, 76.0 decoupled with ~200 jobs)
+        constexpr uint32_t fill = 100u; // percent of the workgroup slots (config 4, 8 s per pass: 54.5 Gsamples/s ordinary, 76.0 decoupled with ~200 jobs)
         return 100u * (uint32_t)n_jobs <= fill * full;
     }
     void set_skip_payload(bool on) { h->launch_skip = on; }

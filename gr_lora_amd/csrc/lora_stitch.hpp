@@ -304,7 +304,7 @@ int decode_begin(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
                     size_t n_segs = 0;
                     for (size_t i = 0; i < streams.size(); i++) {
                         int64_t prev = 0;
-                        static const uint64_t dsym = getenv("LORA_HIP_DEC_SEG_SYMBOLS") ? (uint64_t)atoi(getenv("LORA_HIP_DEC_SEG_SYMBOLS")) : 24u; // (config 4 at 2 s per pass: 24 symbols 48.0 Gsamples/s, 32: 46.1, 16: 38.3 - the scan for preambles is what a header-only job spends most of its time on, and short segments spread it over the idle CUs)
+                        constexpr uint64_t dsym = 24u; // (config 4 at 2 s per pass: 24 symbols 48.0 Gsamples/s, 32: 46.1, 16: 38.3 - the scan for preambles is what a header-only job spends most of its time on, and short segments spread it over the idle CUs)
                         const uint64_t dseg = std::max<uint64_t>(dsym, 8u) * sps;
                         auto grid_to = [&](int64_t b) {
                             if (2u * (uint64_t)(b - prev) > 3u * dseg) {

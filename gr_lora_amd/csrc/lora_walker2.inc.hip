@@ -26,9 +26,6 @@ constexpr int kW2DetectK = 4;   // DETECT windows per worker and round
 #ifndef LORA_W2_SFD_K
 #define LORA_W2_SFD_K 2 // FIND_SFD windows per worker and round
 #endif
-#ifndef LORA_W2_SFD_UNROLL
-#define LORA_W2_SFD_UNROLL 1 // both evaluations inlined: the second window's loads are issued under the first one's arithmetic (+1 %)
-#endif
 #ifndef LORA_W2_EU_SF8
 #define LORA_W2_EU_SF8 2 // wavefronts per SIMD the SF8 kernel's register budget is set for
 #endif
@@ -528,7 +525,10 @@ __device__ LORA_W2_ZM_ATTR W2DemodZ w2_demod_zm(uint32_t enable_fine_sync, uint3
 // ---- the kernel -----------------------------------------------------------------------------------------
 // GRAD: the reference's shipped demodulator (max_frequency_gradient_idx, :466-491, :499) in the decode rounds instead of the
 // dechirp + FFT: wave_demod_symbol_grad.  The FFT twiddle block is then not needed in LDS.
-template <int SF, int WAVES, bool GRAD>
+// SKIP: the header-only variant of a decoupled pass (LaunchCfg.skip_payload; DESIGN 4.13, as walker3's): behind the header parse (:831-847) the attempt is
+// closed as kAttemptHeaderOnly - the record carries d_phdr, the header block's spare codewords and d_payload_symbols - and the job goes on in DETECT where
+// DECODE_PAYLOAD would end if no symbol moved the symbol clock; the payload pass (launch_demod_symbols + payload_chain_kernel) does the rest.
+template <int SF, int WAVES, bool GRAD, bool SKIP = false>
 __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg &C)
 {
     constexpr int N = 1 << SF, SPS = 8 * N;
@@ -824,11 +824,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             // second window's lines behind the first one's loads: nothing.)
             constexpr int kSfdWin = kW2SfdK * kW2Workers;
             static_assert(kW2SfdK <= 2 && kSfdWin <= 64, "results go to specf[w][k] / speci[k][w]");
-#if LORA_W2_SFD_UNROLL
-#pragma unroll
-#else
-#pragma nounroll
-#endif
+#pragma unroll // (both evaluations inlined: the second window's loads are issued under the first one's arithmetic, +1 %)
             for (int k = 0; k < kW2SfdK; k++) {
                 const int64_t kpos = wpos + (int64_t)k * kW2Workers * sps;
                 const bool kvalid = !is_ctl && wave < plan_n_win && kpos + 2 * (int64_t)sps <= n_items;
@@ -985,6 +981,24 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                         break;
                     }
                     w2_end_step(L, job, C, recs, trace, st_w, (int32_t)sps + fw, step_bin, fw, 0.0f, t_start, t0);
+                    if constexpr (SKIP) {
+                        if (is_first && L.state == kDecodePayload && !L.done) { // header parsed (:831-847): the payload is the payload pass's
+                            AttemptRec &r = recs[L.n_att];
+                            if (t0) {
+                                SkippedPayload sk;
+                                sk.phdr[0] = L.phdr[0]; sk.phdr[1] = L.phdr[1]; sk.phdr[2] = L.phdr[2];
+                                sk.n_left = (uint8_t)(L.n_cw < 8u ? L.n_cw : 8u);
+                                for (uint32_t i = 0; i < 8u; i++) sk.left[i] = i < L.n_cw ? sh.cw[i] : (uint8_t)0;
+                                sk.payload_symbols = L.payload_symbols;
+                                *reinterpret_cast<SkippedPayload *>(r.frame) = sk;
+                            }
+                            const int32_t n_walk = L.payload_symbols > 0 ? L.payload_symbols : 1; // (:866-870 are reached behind the first symbol at the earliest)
+                            L.state = kDetect; L.frame_ok = 0; L.n_words = 0; L.n_cw = 0;
+                            w2_end_step(L, job, C, recs, nullptr, kDecodePayload, n_walk * (int32_t)sps, -1, 0, 0.0f, t_start, t0); // (the attempt is closed: status, positions, pushes)
+                            if (t0) { r.status = kAttemptHeaderOnly; r.frame_len = (uint32_t)sizeof(SkippedPayload); }
+                            break;
+                        }
+                    }
                     if (L.done || fw != 0) break; // later windows started at the wrong sample
                 }
                 // is the round the workers are computing right now the true continuation?
@@ -1094,6 +1108,11 @@ __global__ __launch_bounds__(64 * kW2WavesSf8, LORA_W2_EU_SF8) void walker2_kern
 #endif
 __global__ __launch_bounds__(64 * kW2WavesSf7, LORA_W2_EU_GRAD_SF7) void walker2_kernel_sf7_grad(DevParams P, LaunchCfg C) { walker2_body<7, kW2WavesSf7, true>(P, C); }
 __global__ __launch_bounds__(64 * kW2WavesSf8, LORA_W2_EU_GRAD_SF8) void walker2_kernel_sf8_grad(DevParams P, LaunchCfg C) { walker2_body<8, kW2WavesSf8, true>(P, C); }
+// the header-only variants of a decoupled pass (SKIP)
+__global__ __launch_bounds__(64 * kW2WavesSf7, 4) void walker2_kernel_sf7_skip(DevParams P, LaunchCfg C) { walker2_body<7, kW2WavesSf7, false, true>(P, C); }
+__global__ __launch_bounds__(64 * kW2WavesSf8, LORA_W2_EU_SF8) void walker2_kernel_sf8_skip(DevParams P, LaunchCfg C) { walker2_body<8, kW2WavesSf8, false, true>(P, C); }
+__global__ __launch_bounds__(64 * kW2WavesSf7, LORA_W2_EU_GRAD_SF7) void walker2_kernel_sf7_grad_skip(DevParams P, LaunchCfg C) { walker2_body<7, kW2WavesSf7, true, true>(P, C); }
+__global__ __launch_bounds__(64 * kW2WavesSf8, LORA_W2_EU_GRAD_SF8) void walker2_kernel_sf8_grad_skip(DevParams P, LaunchCfg C) { walker2_body<8, kW2WavesSf8, true, true>(P, C); }
 
 static uint32_t walker2_threads(uint32_t sf) { return 64u * (uint32_t)(sf == 7u ? kW2WavesSf7 : kW2WavesSf8); }
 

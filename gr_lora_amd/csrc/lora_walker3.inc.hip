@@ -37,46 +37,18 @@
 // rounds of the same loop; a job that reaches its scan limit carries on as the next segment's tail probe (second phase,
 // as in walker2).
 
-// build-time options (defaults = what ships; the others are kept for same-box A/B runs, tools/build_variant.sh + tools/ab.sh)
-#ifndef LORA_W3_LATE_F_MASK
-#define LORA_W3_LATE_F_MASK 0   // bit (SF - 9): that SF's walker computes fine_sync's ifreq from a second read of the window
-#endif
-// The next two change nothing the kernels compute, only how much the register allocator has to juggle - and at 128 VGPRs with
-// 40-190 of them spilled that decides where the spill reloads land.  A reload is a round trip to memory (the scratch lines do not
-// survive in L2 beside the IQ stream: ~1-2 us each), and one that lands in front of a round's first loads, or inside thread 0's
-// replay, is paid by the whole workgroup every round.  Same-box grids (tools/ab.sh), of HBM peak at 256 packets:
-// job record in scalar registers SF9 15.0 -> 15.4 %, SF10 15.8 -> 16.9 %, SF11 17.5 -> 18.4 %, SF12 14.1 -> 14.8 %.  (Before the
-// library was built with -greedy-reverse-local-assignment the same two switches moved SF11 between 14.1 % and 18.2 %.)
-#ifndef LORA_W3_UJ_MASK
-#define LORA_W3_UJ_MASK 15      // bit (SF - 9): the job record through readfirstlane (uniform_job): the stream base and the limits in scalar registers
-#endif
-#ifndef LORA_W3_MOD_MASK
-#define LORA_W3_MOD_MASK 15     // bit (SF - 9): the replay's power-of-two reductions as masks instead of 64-bit / runtime modulo
-#endif
-#ifndef LORA_W3_FAST_REPLAY
-#define LORA_W3_FAST_REPLAY 1   // the replay's short path for a full round of unmoved payload symbols
-#endif
+// Geometry decisions that were build-time switches while they were being measured (same-box A/B grids: profiles/r02_*, r03_ab_*, docs/LAB_NOTEBOOK.md) and
+// are now fixed: 512-thread workgroups at a 256-register budget (every thread does the work of two: +4 ... 28 % against 1024 x 128); the job record in
+// scalar registers (uniform_job); the replay's power-of-two reductions as masks; the replay's short path for a full round of unmoved payload symbols;
+// fine_sync's ifreq kept from pass 1 except at SF12 (LATE_F: its eight held rows leave no registers for it).  Dropped after measurement: a register
+// prefetch of the next pair in pass 1, pass 1 as a load pipeline, acquisition rounds over several windows at K > 1 (kept only for the header-only variants).
 #ifndef LORA_W3_REPLAY_STATS
-#define LORA_W3_REPLAY_STATS 1  // LORA_HIP_DEBUG accounting of thread 0's replay inside the decode rounds
-#endif
-#ifndef LORA_W3_T512_MASK
-#define LORA_W3_T512_MASK 15    // bit (SF - 9): that SF's kernels as 512-thread workgroups at a 256-register budget - every thread does the work of two
-                                // (2 / 2 / 2 / 4 sample chunks in pass 1, two units of passes 2 and 3): 8 wavefronts per CU instead of 16 and no spill
-                                // left in the demodulator (tools/scratch_where.py).  Same-box A/B against 1024 x 128 (256 packets, round 3):
-                                // SF9 +7 %, SF10 +5 ... 9 %, SF11 +4 %, SF12 +22 ... 28 % (its eight held rows now ARE registers)
-#endif
-#ifndef LORA_W3_EARLY_F_MASK
-#define LORA_W3_EARLY_F_MASK 0  // bit 3: SF12 keeps fine_sync's ifreq from pass 1 (needs the T512 register budget)
-#endif
-#ifndef LORA_W3_P1_PIPE
-#define LORA_W3_P1_PIPE 0       // bit (SF - 9), 512-thread geometry only: pass 1 requests a pair's predecessors and dechirp factors together with its
-                                // samples, and the NEXT pair's samples before it computes on this one (pass 1 is half of a round and was a chain of
-                                // dependent load -> use stages: 2 x (samples, 2 x predecessors, 2 x dechirp factors))
+#define LORA_W3_REPLAY_STATS 1  // LORA_HIP_DEBUG accounting of thread 0's replay inside the decode rounds (2: finer)
 #endif
 
 template <int SF, int HV = 0> struct W3Geom {
     static constexpr int N = 1 << SF, SPS = 8 * N;
-    static constexpr bool T512 = (LORA_W3_T512_MASK >> (SF - 9)) & 1;
+    static constexpr bool T512 = true;                  // 512 threads x 256 registers (the 1024 x 128 geometry of round 2 is what T512 = false still describes)
     // HV = 1 (SF9 / SF10 only): HALF the workgroup - half the groups, half the threads, the same work per thread and the same geometry per group - so
     // that TWO workgroups share a CU (79 / 78 KB of LDS each) and one's rounds fill the other's waits (+12 % at SF9, +4.5 % at SF10 when a
     // launch holds at least two jobs per CU; with one job per CU it would walk its packet at half the width - the launcher picks by job count)
@@ -96,9 +68,9 @@ template <int SF, int HV = 0> struct W3Geom {
     static constexpr int CH = SPS / 16;                 // samples between a thread's consecutive loads
     static constexpr int NWL = VT / (8 * AR), NB = 16 / NWL; // pass 3: butterflies per unit
     static constexpr int LEN = SPS / T;                 // SYNC: shifts per thread (all groups together)
-    static constexpr bool LATE_F = (SF == 12 && !((LORA_W3_EARLY_F_MASK >> 3) & 1)) || ((LORA_W3_LATE_F_MASK >> (SF - 9)) & 1); // fine_sync's ifreq from a second read of the window (SF12: 64 more live registers otherwise)
-    static constexpr bool UNIFORM_JOB = (LORA_W3_UJ_MASK >> (SF - 9)) & 1;  // the job record through readfirstlane (uniform_job)
-    static constexpr bool FAST_MOD = (LORA_W3_MOD_MASK >> (SF - 9)) & 1;    // power-of-two reductions of the replay as masks
+    static constexpr bool LATE_F = SF == 12;            // fine_sync's ifreq from a second read of the window (SF12: 64 more live registers otherwise)
+    static constexpr bool UNIFORM_JOB = true;           // the job record through readfirstlane (uniform_job)
+    static constexpr bool FAST_MOD = true;              // power-of-two reductions of the replay as masks
     static constexpr uint32_t data_entries = (uint32_t)AR * SA; // per group
     static_assert(NB * M2 == 16, "pass 3 covers 16 values per unit");
     static_assert(AR * M2 * 8 == VT, "pass 2 uses every unit of the group once per round");
@@ -381,88 +353,14 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
     float en = 0.0f;
 
     // ---- pass 1 ----
-    constexpr bool P1_PIPE = G::T512 && ((LORA_W3_P1_PIPE >> (SF - 9)) & 1);
-    if constexpr (P1_PIPE) {
-    if (valid) {
-        v2f nxt[16];
-#pragma unroll
-        for (int c = 0; c < 16; c++) nxt[c] = w3_ld2(xb, 8u * tu, (uint32_t)(c * CH * 8));
-#pragma unroll
-        for (int p = 0; p < PAIRS; p++) {
-            const int base = p * TG + t;
-            const uint32_t ob = 8u * ((uint32_t)(p * TG) + tu);
-            v2f a[16], ap[LATE_F ? 1 : 16], d[16];
-#pragma unroll
-            for (int c = 0; c < 16; c++) a[c] = nxt[c];
-            if (p + 1 < PAIRS) { // the next pair's samples: in flight under this pair's arithmetic
-                const uint32_t obn = 8u * ((uint32_t)((p + 1) * TG) + tu);
-#pragma unroll
-                for (int c = 0; c < 16; c++) nxt[c] = w3_ld2(xb, obn, (uint32_t)(c * CH * 8));
-            }
-            if constexpr (!LATE_F) {
-                if (want_fine) {
-                    ap[0] = w3_ld2(xb, (p == 0) ? (ob >= 8u ? ob - 8u : 0u) : ob - 8u, 0u);
-#pragma unroll
-                    for (int c = 1; c < 16; c++) ap[c] = w3_ld2(xb, ob, (uint32_t)(c * CH * 8 - 8));
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 16; c++) d[c] = w3_ld2(db, ob, (uint32_t)(c * CH * 8));
-            __builtin_amdgcn_sched_barrier(0); // every request of this pair (and the next pair's samples) is out before the first use
-            if (want_energy) {
-#pragma unroll
-                for (int c = 0; c < 16; c++) en += a[c].x * a[c].x + a[c].y * a[c].y;
-            }
-            if constexpr (!LATE_F) {
-                if (want_fine) {
-#pragma unroll
-                    for (int q = 0; q < 16; q += 4) {
-                        v2f im0, re0, im1, re1, o0, o1;
-                        im0 = (v2f){a[q].y * ap[q].x - a[q].x * ap[q].y, a[q + 1].y * ap[q + 1].x - a[q + 1].x * ap[q + 1].y};
-                        re0 = (v2f){a[q].x * ap[q].x + a[q].y * ap[q].y, a[q + 1].x * ap[q + 1].x + a[q + 1].y * ap[q + 1].y};
-                        im1 = (v2f){a[q + 2].y * ap[q + 2].x - a[q + 2].x * ap[q + 2].y, a[q + 3].y * ap[q + 3].x - a[q + 3].x * ap[q + 3].y};
-                        re1 = (v2f){a[q + 2].x * ap[q + 2].x + a[q + 2].y * ap[q + 2].y, a[q + 3].x * ap[q + 3].x + a[q + 3].y * ap[q + 3].y};
-                        w3_atan2_x4(im0, re0, im1, re1, o0, o1);
-                        f[LATE_F ? 0 : p][q] = (p == 0 && q == 0 && t == 0) ? 0.0f : o0.x; // n = 0 has no predecessor in the window
-                        f[LATE_F ? 0 : p][q + 1] = o0.y; f[LATE_F ? 0 : p][q + 2] = o1.x; f[LATE_F ? 0 : p][q + 3] = o1.y;
-                    }
-                }
-            }
-            cmul_batch<8>(a, d); // dechirp (:437)
-            cmul_batch<8>(a + 8, d + 8);
-            fft_inlane_dif_pk<16>(a);
-            const int q0 = base >> 3;
-            {
-                v2f w[8];
-#pragma unroll
-                for (int m = 1; m < 8; m++) w[m] = w3_tw<SF, HV>(L, (uint32_t)(q0 * brev_bits(m, 4)));
-                cmul_batch<7>(a + 1, w + 1);
-#pragma unroll
-                for (int m = 8; m < 16; m++) w[m - 8] = w3_tw<SF, HV>(L, (uint32_t)(q0 * brev_bits(m, 4)));
-                cmul_batch<8>(a + 8, w);
-            }
-#pragma unroll
-            for (int m = 0; m < AR; m++) data[m * SA + q0 * 8 + r] = a[m];
-            if constexpr (ROUNDS > 1) {
-#pragma unroll
-                for (int i = 0; i < 8; i++) hold[p][i] = a[8 + i];
-            }
-        }
-    }
-    } else
     if (valid) {
 #pragma unroll
         for (int p = 0; p < PAIRS; p++) {
             const int base = p * TG + t;
             const uint32_t ob = 8u * ((uint32_t)(p * TG) + tu); // byte offset of this thread's sample inside a chunk
             v2f a[16];
-#ifdef LORA_W3_SYNTH_X // experiment: no HBM read
-#pragma unroll
-            for (int c = 0; c < 16; c++) a[c] = (v2f){(float)(t + c), (float)(t ^ c)};
-#else
 #pragma unroll
             for (int c = 0; c < 16; c++) a[c] = w3_ld2(xb, ob, (uint32_t)(c * CH * 8));
-#endif
             if (want_energy) {
 #pragma unroll
                 for (int c = 0; c < 16; c++) en += a[c].x * a[c].x + a[c].y * a[c].y;
@@ -484,11 +382,7 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
                             re0 = (v2f){a[q].x * ap[c].x + a[q].y * ap[c].y, a[q + 1].x * ap[c + 1].x + a[q + 1].y * ap[c + 1].y};
                             im1 = (v2f){a[q + 2].y * ap[c + 2].x - a[q + 2].x * ap[c + 2].y, a[q + 3].y * ap[c + 3].x - a[q + 3].x * ap[c + 3].y};
                             re1 = (v2f){a[q + 2].x * ap[c + 2].x + a[q + 2].y * ap[c + 2].y, a[q + 3].x * ap[c + 3].x + a[q + 3].y * ap[c + 3].y};
-#ifdef LORA_W3_DBG_ATAN
-                            o0 = lean_atan2_pk(im0, re0); o1 = lean_atan2_pk(im1, re1);
-#else
                             w3_atan2_x4(im0, re0, im1, re1, o0, o1);
-#endif
                             f[LATE_F ? 0 : p][q] = (p == 0 && q == 0 && t == 0) ? 0.0f : o0.x; // n = 0 has no predecessor in the window
                             f[LATE_F ? 0 : p][q + 1] = o0.y; f[LATE_F ? 0 : p][q + 2] = o1.x; f[LATE_F ? 0 : p][q + 3] = o1.y;
                         }
@@ -1640,7 +1534,7 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                 // three counters, but as one loop over every case (header, implicit mode, traces, limits, a break per outcome) the
                 // compiler carries the whole state through ~300 instructions per symbol: 1.7 k clocks each on the one thread
                 // that runs them, with the workgroup waiting (LORA_W3_REPLAY_STATS: 6.7 k of a 50 k round at SF9).
-                bool fast = LORA_W3_FAST_REPLAY && !trace && P.implicit == 0u && St.state == kDecodePayload && plan_n_win == NG &&
+                bool fast = !trace && P.implicit == 0u && St.state == kDecodePayload && plan_n_win == NG &&
                             pos + (int64_t)(NG + 1) * (int64_t)sps <= n_items; // (every window passes the loop-top check, :91)
 #pragma unroll
                 for (int q = 0; q < NG; q++) fast = fast && fq[q] == 0;

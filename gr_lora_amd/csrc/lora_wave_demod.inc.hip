@@ -104,11 +104,6 @@ __device__ __forceinline__ int wave_min_u(int v)
 // a * w with the twiddle given as (w, wr = (-w.y, w.x)): two packed instructions
 __device__ __forceinline__ v2f cmulw(v2f a, v2f w, v2f wr) { return __builtin_elementwise_fma(a.xx, w, a.yy * wr); }
 __device__ __forceinline__ v2f cmulw(v2f a, v4f t) { return cmulw(a, t.xy, t.zw); }
-#ifdef LORA_WD_NO_LDS // experiment (tools/probe_phases.hip): twiddles from registers instead of LDS
-#define LORA_WD_TAB(expr, lane) ((v4f){1.0f, 0.001f * (float)(lane), -0.001f * (float)(lane), 1.0f})
-#else
-#define LORA_WD_TAB(expr, lane) (expr)
-#endif
 
 // in-register radix-2 DIF, natural input order, bit-reversed output
 template <int J>
@@ -285,13 +280,8 @@ __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const Wave
 
     v2f a[J];
     float f[J]; // ifreq[n - 1] of this lane's samples
-#ifdef LORA_WD_NO_GLOBAL // experiment: synthetic samples instead of the HBM read
-#pragma unroll
-    for (int j = 0; j < J; j++) a[j] = (v2f){(float)(lane + j), (float)(lane ^ j)};
-#else
 #pragma unroll
     for (int j = 0; j < J; j++) a[j] = xv[j * 64 + nl];
-#endif
     if (en_out) { // (a uniform branch: only implicit-header decoders ask)
         v2f e2 = (v2f){0.0f, 0.0f};
 #pragma unroll
@@ -346,11 +336,11 @@ __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const Wave
     }
     LORA_WSTAMP(1);
 #pragma unroll
-    for (int j = 0; j < J; j++) a[j] = cmulw(a[j], LORA_WD_TAB(T.down4[j * 64 + nl], lane)); // dechirp (:437)
+    for (int j = 0; j < J; j++) a[j] = cmulw(a[j], T.down4[j * 64 + nl]); // dechirp (:437)
     fft_inlane_dif_pk<J>(a);
     LORA_WSTAMP(2);
 #pragma unroll
-    for (int m = 1; m < J; m++) a[m] = cmulw(a[m], LORA_WD_TAB(T.twn4[m * 8 + lq], lane)); // W_N^{lq k1}
+    for (int m = 1; m < J; m++) a[m] = cmulw(a[m], T.twn4[m * 8 + lq]); // W_N^{lq k1}
     LORA_WSTAMP(3);
     { // 8-point DIF over lq
         const v4f w1 = T.xst4[lane], w2 = T.xst4[64 + lane]; // W_8^{lq & 3}, W_4^{lq & 1}: the same on both lanes of a pair
@@ -384,7 +374,7 @@ __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const Wave
     }
     LORA_WSTAMP(4);
 #pragma unroll
-    for (int m = 0; m < J; m++) a[m] = cmulw(a[m], LORA_WD_TAB(T.tws4[m * 64 + lane], lane)); // W_sps^{k r} (+ fold)
+    for (int m = 0; m < J; m++) a[m] = cmulw(a[m], T.tws4[m * 64 + lane]); // W_sps^{k r} (+ fold)
     // reduce-scatter over r = lane bits 2, 1, 0: lanes with the bit clear keep the first half of the registers
     // (Measured and dropped: the same steps as v_add_f32 with a DPP operand written out in asm - fewer issue slots on paper,
     // 13 % slower in the walker: the volatile sequence no longer interleaves with the table loads around it.)
