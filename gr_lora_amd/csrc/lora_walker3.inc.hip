@@ -300,11 +300,6 @@ __device__ __forceinline__ void w3_atan2_x4(v2f y0, v2f x0, v2f y1, v2f x1, v2f 
 template <bool FIRST, bool ZM = false>
 __device__ __forceinline__ void w3_ifreq16(const v2f (&a)[16], const v2f (&ap)[16], bool n0_thread, float (&f)[16])
 {
-    if constexpr (ZM) { // every value as the reference forms it next to a sample of exactly zero (ifreq_prod_z, out of line)
-#pragma unroll
-        for (int c = 0; c < 16; c++) f[c] = (FIRST && c == 0 && n0_thread) ? 0.0f : ifreq_prod_z(make_float2(ap[c].x, ap[c].y), make_float2(a[c].x, a[c].y));
-        return;
-    }
 #pragma unroll
     for (int c = 0; c < 16; c += 4) {
         if (c == 8) __builtin_amdgcn_sched_barrier(0);
@@ -316,6 +311,12 @@ __device__ __forceinline__ void w3_ifreq16(const v2f (&a)[16], const v2f (&ap)[1
         w3_atan2_x4(im0, re0, im1, re1, o0, o1);
         f[c] = (FIRST && c == 0 && n0_thread) ? 0.0f : o0.x; // n = 0 has no predecessor in the window
         f[c + 1] = o0.y; f[c + 2] = o1.x; f[c + 3] = o1.y;
+    }
+    if constexpr (ZM) { // the values next to a sample of exactly zero came out NaN: those as the reference forms them (ifreq_prod_z, out of line; rare)
+#pragma unroll
+        for (int c = 0; c < 16; c++)
+            if (__builtin_amdgcn_ballot_w64(poisoned(f[c])) != 0ull) // (wave-uniform)
+                if (poisoned(f[c])) f[c] = ifreq_prod_z(make_float2(ap[c].x, ap[c].y), make_float2(a[c].x, a[c].y));
     }
 }
 
@@ -528,7 +529,13 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
     if (!want_fine) return;
     // fine_sync (:300-338) with search = max(D/4, 2) = 2 -> lags -1, 0, +1
     float cs[3] = {0.f, 0.f, 0.f};
-    if (valid) {
+    // this thread's taps.  LATE: the window's ifreq from a second read of the window (SF12, and every ZM evaluation); Z: the values next to a sample of exactly
+    // zero as the reference forms them (w3_ifreq16 ZM).  (Re-evaluating a poisoned window's taps inside the wavefront, ahead of the group sums, instead of in a ZM
+    // round was measured as well: the same to +-1 %, profiles/r05_ab_zero_samples.txt.)
+    auto tap_sums = [&](auto late_t, auto z_t) {
+        constexpr bool LATE = decltype(late_t)::value, Z = decltype(z_t)::value;
+        cs[0] = 0.f; cs[1] = 0.f; cs[2] = 0.f;
+        if (!valid) return;
         uint32_t s = s_out[0];
 #pragma unroll
         for (int g = 1; g < NG; g++) s = (grp == g) ? s_out[g] : s;
@@ -546,7 +553,7 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
                 v0[c] = w3_ld1(vb, 4u * nb, (uint32_t)(c * CH * 4 - 4)); v1[c] = w3_ld1(vb, 4u * nb, (uint32_t)(c * CH * 4)); v2[c] = w3_ld1(vb, 4u * nb, (uint32_t)(c * CH * 4 + 4));
             }
             float fl[16];
-            if constexpr (LATE_F) { // second read of the window
+            if constexpr (LATE) { // second read of the window
                 const uint32_t ob = 8u * nb;
                 v2f a[16], ap[16];
 #pragma unroll
@@ -554,21 +561,22 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
                 ap[0] = w3_ld2(xb, (p == 0) ? (ob >= 8u ? ob - 8u : 0u) : ob - 8u, 0u);
 #pragma unroll
                 for (int c = 1; c < 16; c++) ap[c] = w3_ld2(xb, ob, (uint32_t)(c * CH * 8 - 8));
-                if (p == 0) w3_ifreq16<true, ZM>(a, ap, t == 0, fl);
-                else w3_ifreq16<false, ZM>(a, ap, false, fl);
+                if (p == 0) w3_ifreq16<true, Z>(a, ap, t == 0, fl);
+                else w3_ifreq16<false, Z>(a, ap, false, fl);
             }
 #pragma unroll
             for (int c = 0; c < 16; c++) {
-                const float fk = LATE_F ? fl[c] : f[LATE_F ? 0 : p][c];
+                const float fk = LATE ? fl[c] : f[LATE_F ? 0 : p][c];
                 cs[0] += fk * v0[c]; cs[1] += fk * v1[c]; cs[2] += fk * v2[c];
             }
             if (p == PAIRS - 1 && t == TG - 1) { // ifreq[sps-1] = ifreq[sps-2] (:243): the duplicated tap at k = sps-1
-                const float flast = LATE_F ? fl[15] : f[LATE_F ? 0 : p][15];
+                const float flast = LATE ? fl[15] : f[LATE_F ? 0 : p][15];
                 const uint32_t ko = 4u * (uint32_t)(SPS - 1);
                 cs[0] += flast * w3_ld1(vb, ko, 0u); cs[1] += flast * w3_ld1(vb, ko, 4u); cs[2] += flast * w3_ld1(vb, ko, 8u);
             }
         }
-    }
+    };
+    tap_sums(std::integral_constant<bool, LATE_F>{}, std::integral_constant<bool, ZM>{});
     LORA_W3STAMP(7);
     float co[NG][3];
     w3_group_sums<SF, 3, HV>(cs, ws, slot, grp, gwave, co, all);
@@ -631,10 +639,6 @@ __device__ __forceinline__ void w3_demod_round_grad(const W3DemodArgs &P, const 
                 const uint32_t obn = (p == PAIRS - 1 && t == TG - 1) ? ob - 8u : ob;
 #pragma unroll
                 for (int c = 0; c < 8; c++) an[c] = w3_ld2(xb, (8 * h + c == 15) ? obn : ob, (uint32_t)((8 * h + c) * CH * 8 + 8));
-                if constexpr (ZM) {
-#pragma unroll
-                    for (int c = 0; c < 8; c++) f[p][8 * h + c] = ifreq_prod_z(make_float2(a[8 * h + c].x, a[8 * h + c].y), make_float2(an[c].x, an[c].y));
-                } else
 #pragma unroll
                 for (int c = 0; c < 8; c += 4) {
                     const int q = 8 * h + c;
@@ -645,6 +649,12 @@ __device__ __forceinline__ void w3_demod_round_grad(const W3DemodArgs &P, const 
                     re1 = (v2f){an[c + 2].x * a[q + 2].x + an[c + 2].y * a[q + 2].y, an[c + 3].x * a[q + 3].x + an[c + 3].y * a[q + 3].y};
                     w3_atan2_x4(im0, re0, im1, re1, o0, o1);
                     f[p][q] = o0.x; f[p][q + 1] = o0.y; f[p][q + 2] = o1.x; f[p][q + 3] = o1.y;
+                }
+                if constexpr (ZM) { // the values next to a sample of exactly zero came out NaN: those as the reference forms them (rare)
+#pragma unroll
+                    for (int c = 0; c < 8; c++)
+                        if (__builtin_amdgcn_ballot_w64(poisoned(f[p][8 * h + c])) != 0ull)
+                            if (poisoned(f[p][8 * h + c])) f[p][8 * h + c] = ifreq_prod_z(make_float2(a[8 * h + c].x, a[8 * h + c].y), make_float2(an[c].x, an[c].y));
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
