@@ -82,6 +82,7 @@ struct alignas(16) W3Shared {
     double   dred[2][72];          // block scans / sums of doubles (SYNC; FIND_SFD at [group * 18 + ..])
     float    sfd[4][72];           // FIND_SFD: head / tail samples of the window's ifreq, per group
     int32_t  ibc[8];               // broadcasts (FIND_SFD lag per group)
+    int32_t  wres[16][4];          // gradient decode rounds: (bin, d_fine_sync, energy, valid) of the window each wavefront demodulated
     W2Plan   plan[2];              // the round plan, double-buffered
     W2State  st;                   // decoder state: thread 0 only
     strict::Cands sc;              // SYNC: near-tied shifts for the exact re-evaluation
@@ -594,163 +595,116 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
     }
 }
 
-// ---- the reference's SHIPPED demodulator, one window per group: max_frequency_gradient_idx (:466-491) + fine_sync -------
-// No FFT and no LDS array: thread t of the group owns the samples n = c CH + p TG + t as in pass 1 above and computes
-// f = ifreq[n] = arg(x[n+1] conj(x[n])) (successors by a second buffer load one item up: the same cache lines;
-// ifreq[sps-1] = ifreq[sps-2], :243).  The eight samples of bin i = n >> 3 sit in eight adjacent lanes: the bin average
-// (volk_32f_accumulator_s32f / D, :475-476) is three DPP adds, its left neighbour one lane permute - across wavefront and
-// chunk boundaries through a small LDS array (one value per wavefront, chunk and pair) - and the largest drop above 0.1
-// (:479-488) a first-maximum reduction over the group.  s_out[g] is demodulate()'s bin_idx itself.
-template <int SF, int HV = 0, bool ZM = false>
-__device__ __forceinline__ void w3_demod_round_grad(const W3DemodArgs &P, const W3Lds<SF, HV> &L, const float2 *__restrict__ x, bool valid, bool want_energy, int &slot,
-                                                    uint32_t (&s_out)[W3Geom<SF, HV>::NG], int32_t (&fine_out)[W3Geom<SF, HV>::NG], float (&en_out)[W3Geom<SF, HV>::NG])
+// ---- the reference's SHIPPED demodulator, one window per WAVEFRONT: max_frequency_gradient_idx (:466-491) + fine_sync (:300-338) ----------------------
+// No FFT, so nothing has to cross a workgroup: the estimator is a reduction over the window - ifreq, means of D = 8 samples, the largest drop between
+// neighbouring means (:474-488) - and the window's three fine_sync correlations another.  A wavefront walks its window in chunks of 1024 samples exactly as
+// wave_demod_symbol_grad (lora_wave_demod.inc.hip) handles a whole SF7 symbol: lane l owns n = 1024 q + 64 j + l, every load instruction covers 512
+// contiguous bytes, x[n + 1] comes from the neighbouring lane (lane 63: lane 0 of the next register / the next chunk, which is already in flight: the chunks
+// are double-buffered in registers), the eight samples of bin i = 128 q + 8 j + (l >> 3) sit in eight adjacent lanes.  The bin is known only behind the
+// last chunk, so fine_sync's sums are a SECOND pass over the window (L2-hot) that forms the ifreq values again: two arctangents per sample instead of one,
+// and no barrier, no LDS, no idle wavefront - a workgroup's 8 wavefronts demodulate 8 consecutive windows per round at every spreading factor (the
+// group-per-window form of rounds 2-4 took 4 / 2 / 1 / 1 windows behind five barriers; same-box A/B: profiles/r05_ab_wave_gradient.txt).
+// bin_out is demodulate()'s bin_idx itself; fine_out = kFinePoison for a window with a sample of exactly zero (re-evaluated by ZM = true, which patches
+// the poisoned values with ifreq_prod_z).  en_out: determine_energy (:368-375) when want_energy.
+template <int SF, bool ZM = false>
+__device__ __forceinline__ void w3_wave_window_grad(const W3DemodArgs &P, const float2 *__restrict__ x, bool want_energy, uint32_t &bin_out, int32_t &fine_out, float &en_out)
 {
-    using G = W3Geom<SF, HV>;
-    constexpr int N = G::N, SPS = G::SPS, TG = G::TG, CH = G::CH, PAIRS = G::PAIRS, NG = G::NG, GW = G::GW;
-    int tt = threadIdx.x;
-    asm volatile("" : "+v"(tt));
-    const int grp = __builtin_amdgcn_readfirstlane(tt / TG), t = tt % TG;
-    const int lane = t & 63, gwave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const bool want_fine = P.enable_fine_sync != 0u;
-    const w3_buf_t xb = w3_buf(w3_uniform_ptr(x));
-    W3Shared &ws = *L.ws;
-    float *edge = reinterpret_cast<float *>(L.data + (size_t)grp * G::data_entries); // [(p 16 + c) GW + wave]: the last bin of every wavefront
-    const uint32_t tu = (uint32_t)t;
-
-    float f[PAIRS][16]; // (the bin averages are formed twice - for the boundary values before the barrier, for the differences behind it - rather
-                         // than kept: 64 more live registers per thread at SF12 were 137 spilled ones)
-    float en = 0.0f;
-    if (valid) {
+    constexpr int N = 1 << SF, SPS = 8 * N, NCH = SPS / 1024;
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane)); // (keeps per-lane addresses out of the caller's loop-invariant set)
+    const auto xv = (const __attribute__((address_space(1))) v2f *)x;
+    // one pass over the window: use(q, f) with f[j] = ifreq[1024 q + 64 j + lane]; ifreq[sps-1] = ifreq[sps-2] (:243)
+    auto pass = [&](auto &&use, bool energy) {
+        v2f nxt[16];
 #pragma unroll
-        for (int p = 0; p < PAIRS; p++) {
-            const uint32_t ob = 8u * ((uint32_t)(p * TG) + tu);
+        for (int j = 0; j < 16; j++) nxt[j] = xv[j * 64 + lane];
+        v2f e2 = (v2f){0.0f, 0.0f};
+#pragma unroll 1
+        for (int q = 0; q < NCH; q++) {
             v2f a[16];
 #pragma unroll
-            for (int c = 0; c < 16; c++) a[c] = w3_ld2(xb, ob, (uint32_t)(c * CH * 8));
-            if (want_energy) {
+            for (int j = 0; j < 16; j++) a[j] = nxt[j];
+            const bool last = q == NCH - 1;
+            if (!last) {
 #pragma unroll
-                for (int c = 0; c < 16; c++) en += a[c].x * a[c].x + a[c].y * a[c].y;
+                for (int j = 0; j < 16; j++) nxt[j] = xv[(q + 1) * 1024 + j * 64 + lane];
             }
+            if (energy) {
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                v2f an[8]; // x[n + 1]
-                // (the sample behind the window's LAST one is never used - ifreq[sps-1] is a copy of ifreq[sps-2], :243 - and need not exist: a caller-given
-                // window may end with the caller's buffer (lora_hip_demod_symbols_ex_device): that one lane reads its own sample again)
-                const uint32_t obn = (p == PAIRS - 1 && t == TG - 1) ? ob - 8u : ob;
+                for (int j = 0; j < 16; j++) e2 = __builtin_elementwise_fma(a[j], a[j], e2);
+            }
+            float f[16];
+            v2f cn = dpp2<kDppWaveRol1>(a[0]); // a[j] of lane + 1 (lane 63: of lane 0)
 #pragma unroll
-                for (int c = 0; c < 8; c++) an[c] = w3_ld2(xb, (8 * h + c == 15) ? obn : ob, (uint32_t)((8 * h + c) * CH * 8 + 8));
-#pragma unroll
-                for (int c = 0; c < 8; c += 4) {
-                    const int q = 8 * h + c;
-                    v2f im0, re0, im1, re1, o0, o1; // x[n+1] conj(x[n])
-                    im0 = (v2f){an[c].y * a[q].x - an[c].x * a[q].y, an[c + 1].y * a[q + 1].x - an[c + 1].x * a[q + 1].y};
-                    re0 = (v2f){an[c].x * a[q].x + an[c].y * a[q].y, an[c + 1].x * a[q + 1].x + an[c + 1].y * a[q + 1].y};
-                    im1 = (v2f){an[c + 2].y * a[q + 2].x - an[c + 2].x * a[q + 2].y, an[c + 3].y * a[q + 3].x - an[c + 3].x * a[q + 3].y};
-                    re1 = (v2f){an[c + 2].x * a[q + 2].x + an[c + 2].y * a[q + 2].y, an[c + 3].x * a[q + 3].x + an[c + 3].y * a[q + 3].y};
-                    w3_atan2_x4(im0, re0, im1, re1, o0, o1);
-                    f[p][q] = o0.x; f[p][q + 1] = o0.y; f[p][q + 2] = o1.x; f[p][q + 3] = o1.y;
-                }
+            for (int j = 0; j < 16; j += 2) {
+                const v2f c0 = cn, c1 = dpp2<kDppWaveRol1>(a[j + 1]);
+                const v2f c2 = (j + 2 < 16) ? dpp2<kDppWaveRol1>(a[j + 2]) : dpp2<kDppWaveRol1>(nxt[0]); // (behind the last chunk: never used, see below)
+                cn = c2;
+                const v2f s0 = (lane == 63) ? c1 : c0, s1 = (lane == 63) ? c2 : c1; // x[n + 1]
+                const v2f fp = ifreq_prod_pk(a[j], s0, a[j + 1], s1);
+                f[j] = fp.x; f[j + 1] = fp.y;
                 if constexpr (ZM) { // the values next to a sample of exactly zero came out NaN: those as the reference forms them (rare)
-#pragma unroll
-                    for (int c = 0; c < 8; c++)
-                        if (__builtin_amdgcn_ballot_w64(poisoned(f[p][8 * h + c])) != 0ull)
-                            if (poisoned(f[p][8 * h + c])) f[p][8 * h + c] = ifreq_prod_z(make_float2(a[8 * h + c].x, a[8 * h + c].y), make_float2(an[c].x, an[c].y));
+                    if (__builtin_amdgcn_ballot_w64(poisoned(f[j]) || poisoned(f[j + 1])) != 0ull) {
+                        if (poisoned(f[j])) f[j] = ifreq_prod_z(make_float2(a[j].x, a[j].y), make_float2(s0.x, s0.y));
+                        if (poisoned(f[j + 1])) f[j + 1] = ifreq_prod_z(make_float2(a[j + 1].x, a[j + 1].y), make_float2(s1.x, s1.y));
+                    }
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
-        }
-        { // ifreq[sps-1] = ifreq[sps-2] (:243): the group's last thread takes its neighbour's value
-            const float dup = dpp_f<kDppWaveRor1>(f[PAIRS - 1][15]);
-            f[PAIRS - 1][15] = (t == TG - 1) ? dup : f[PAIRS - 1][15];
-        }
-#pragma unroll
-        for (int p = 0; p < PAIRS; p++)
-#pragma unroll
-            for (int c = 0; c < 16; c++) {
-                float v = f[p][c];
-                v += dpp_f<kDppQuadXor1>(v); v += dpp_f<kDppQuadXor2>(v); v += dpp_f<kDppRowHalfMirror>(v); // the 8 samples of the bin (:475)
-                if (lane == 63) edge[(p * 16 + c) * GW + gwave] = v * 0.125f; // / d_decim_factor (:476)
+            if (last) { // ifreq[sps-1] = ifreq[sps-2] (:243): the sample behind the window's last one is never looked at (it need not exist)
+                const float dup = dpp_f<kDppWaveRor1>(f[15]);
+                f[15] = (lane == 63) ? dup : f[15];
             }
-    }
-    __syncthreads();
-    float bv = 0.1f; // max_gradient = 0.1f (:479)
+            use(q, f);
+        }
+        return e2.x + e2.y;
+    };
+    // pass A: bin averages (:474-477) and the largest drop (:479-488)
+    float bv = 0.1f; // max_gradient = 0.1f
     int bi = 0x7fffffff;
-    float gsum = 0.0f; // (carries the poison of a zero sample when there is no fine_sync sum to carry it)
-    if (valid) {
-        const int perm_addr = ((lane - 8) & 63) << 2;
+    float gs = 0.0f, prev_perm = 0.0f; // gs carries the poison of a zero sample when there is no fine_sync sum to carry it
+    const int m = lane >> 3, perm_addr = ((lane - 8) & 63) << 2;
+    const float e = pass([&](int q, const float (&f)[16]) {
 #pragma unroll
-        for (int c = 0; c < 16; c++)
-#pragma unroll
-            for (int p = 0; p < PAIRS; p++) { // (c, p) ascending = bin index ascending
-                float Apc = f[p][c];
-                Apc += dpp_f<kDppQuadXor1>(Apc); Apc += dpp_f<kDppQuadXor2>(Apc); Apc += dpp_f<kDppRowHalfMirror>(Apc);
-                Apc *= 0.125f;
-                const float perm = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm_addr, __builtin_bit_cast(int, Apc)));
-                float left = perm;
-                if (lane < 8) { // the bin to the left lives in the previous wavefront / pair / chunk
-                    const int pp = (gwave > 0) ? p : (p > 0 ? p - 1 : PAIRS - 1), cc = (gwave > 0 || p > 0) ? c : c - 1;
-                    const int ww = (gwave > 0) ? gwave - 1 : GW - 1;
-                    left = (cc >= 0) ? edge[(pp * 16 + cc) * GW + ww] : 0.0f;
-                }
-                const float g = left - Apc; // samples_ifreq_avg[i - 1] - samples_ifreq_avg[i] (:482)
-                gsum += Apc;
-                const int i = (c * CH + p * TG + t) >> 3;
-                if (i >= 1 && g > bv) { bv = g; bi = i; } // strict '>' and ascending i: the first maximum
-            }
-    }
-    const bool all = grp == 0 && gwave == 0;
-    float bvs[NG];
-    int bis[NG];
-    w3_group_argmax_first<SF, HV>(bv, bi, ws, slot, grp, gwave, bvs, bis, all);
-#pragma unroll
-    for (int g = 0; g < NG; g++) {
-        const uint32_t max_index = (bis[g] == 0x7fffffff) ? 0u : (uint32_t)bis[g] + 1u; // :486
-        s_out[g] = ((uint32_t)N - max_index) % (uint32_t)N;                              // :490
-        fine_out[g] = 0; en_out[g] = 0.0f;
-    }
-    if (want_energy) {
-        float e1[1] = {en}, eo[NG][1];
-        w3_group_sums<SF, 1, HV>(e1, ws, slot, grp, gwave, eo, all);
-#pragma unroll
-        for (int g = 0; g < NG; g++) en_out[g] = eo[g][0];
-    }
-    if (!want_fine) {
-        if constexpr (!ZM) { // (no fine_sync sums: the bin averages themselves say whether a window was poisoned - one more exchange, in this configuration only)
-            float g1[1] = {gsum}, go[NG][1];
-            w3_group_sums<SF, 1, HV>(g1, ws, slot, grp, gwave, go, all);
-#pragma unroll
-            for (int g = 0; g < NG; g++) fine_out[g] = poisoned(go[g][0]) ? kFinePoison : 0;
+        for (int j = 0; j < 16; j++) {
+            float A = f[j];
+            A += dpp_f<kDppQuadXor1>(A); A += dpp_f<kDppQuadXor2>(A); A += dpp_f<kDppRowHalfMirror>(A); // sum over the 8 lanes of the bin
+            A *= 0.125f; // / d_decim_factor
+            const float perm = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm_addr, __builtin_bit_cast(int, A))); // bin (m - 1) mod 8 of this register
+            const float left = (m == 0) ? prev_perm : perm; // bin i - 1: for m = 0 bin 7 of the previous register
+            prev_perm = perm;
+            const float g = left - A; // samples_ifreq_avg[i - 1] - samples_ifreq_avg[i]
+            gs += A;
+            const int i = 128 * q + 8 * j + m;
+            if (i >= 1 && g > bv) { bv = g; bi = i; } // i runs from 1; strict '>' keeps the first maximum
         }
+    }, want_energy);
+    en_out = want_energy ? wave_sum_u(e) : 0.0f;
+    const float best = wave_max_nonneg_u(bv);
+    const int first = wave_min_u((bv == best) ? bi : 0x7fffffff);
+    const uint32_t max_index = (first == 0x7fffffff) ? 0u : (uint32_t)first + 1u; // :486
+    const uint32_t bin_idx = ((uint32_t)N - max_index) % (uint32_t)N;              // :490
+    bin_out = bin_idx;
+    fine_out = 0;
+    if (P.enable_fine_sync == 0u) {
+        if (!ZM && poisoned(wave_sum_u(gs))) fine_out = kFinePoison;
         return;
     }
-    float cs[3] = {0.f, 0.f, 0.f};
-    if (valid) { // fine_sync (:300-338), lags -1, 0, +1: c_lag = sum_k f[k] v[(bin_idx + 1) 8 + sps + lag + k]
-        uint32_t bin_idx = s_out[0];
+    // pass B: fine_sync (:300-338), lags -1, 0, +1: c_lag = sum_k f[k] v[(bin_idx + 1) 8 + sps + lag + k]
+    const float *__restrict__ vp = P.up_ifreq_v + ((int)(bin_idx + 1u) * 8 + SPS) + (lane - 1);
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    (void)pass([&](int q, const float (&f)[16]) {
+        const float *__restrict__ vq = vp + 1024 * q;
 #pragma unroll
-        for (int g = 1; g < NG; g++) bin_idx = (grp == g) ? s_out[g] : bin_idx;
-        const w3_buf_t vb = w3_buf(w3_uniform_ptr(P.up_ifreq_v + ((int)(bin_idx + 1u) * 8 + SPS - 1))); // origin one element early: lag -1 at k = 0
-#pragma unroll
-        for (int p = 0; p < PAIRS; p++) {
-            const uint32_t nb = 4u * ((uint32_t)(p * TG) + tu);
-#pragma unroll
-            for (int c = 0; c < 16; c++) {
-                const float v0 = w3_ld1(vb, nb, (uint32_t)(c * CH * 4)), v1 = w3_ld1(vb, nb, (uint32_t)(c * CH * 4 + 4)), v2 = w3_ld1(vb, nb, (uint32_t)(c * CH * 4 + 8));
-                cs[0] += f[p][c] * v0; cs[1] += f[p][c] * v1; cs[2] += f[p][c] * v2;
-            }
-        }
-    }
-    float co[NG][3];
-    w3_group_sums<SF, 3, HV>(cs, ws, slot, grp, gwave, co, all);
-#pragma unroll
-    for (int g = 0; g < NG; g++) {
-        float mx = 0.0f;
-        int32_t lag = 0;
-        if (co[g][0] > mx) { mx = co[g][0]; lag = -1; }
-        if (co[g][1] > mx) { mx = co[g][1]; lag = 0; }
-        if (co[g][2] > mx) { mx = co[g][2]; lag = 1; }
-        if (!ZM && poisoned(co[g][0] + co[g][1] + co[g][2])) lag = -kFinePoison; // (the bin averages next to the zero sample are NaN as well: the round is evaluated again)
-        fine_out[g] = __builtin_amdgcn_readfirstlane(-lag);
-    }
+        for (int j = 0; j < 16; j++) { c0 += f[j] * vq[64 * j]; c1 += f[j] * vq[64 * j + 1]; c2 += f[j] * vq[64 * j + 2]; }
+    }, false);
+    c0 = wave_sum_u(c0); c1 = wave_sum_u(c1); c2 = wave_sum_u(c2);
+    if (!ZM && poisoned3(c0, c1, c2)) { fine_out = kFinePoison; return; } // (uniform) a sample of the window is exactly zero: the bin averages next to it are NaN as well
+    float mx = 0.0f;
+    int32_t lag = 0;
+    if (c0 > mx) { mx = c0; lag = -1; }
+    if (c1 > mx) { mx = c1; lag = 0; }
+    if (c2 > mx) { mx = c2; lag = 1; }
+    fine_out = -lag;
 }
 
 // copies W_N^t into LDS; all threads; the caller synchronises
@@ -1257,15 +1211,14 @@ __device__ __forceinline__ void w3_touch(const float2 *X, int64_t first_item, in
 #ifndef LORA_W3_ZM_ATTR
 #define LORA_W3_ZM_ATTR __attribute__((noinline)) // (inlined into the round loop it cost SF9-SF12 another 1.5-4 %: profiles/r05_ab_zero_samples.txt)
 #endif
-template <int SF, bool GRAD, int HV>
+template <int SF, int HV>
 __device__ LORA_W3_ZM_ATTR W3DemodOut w3_demod_round_zm(W3DemodArgs DA, W3Lds<SF, HV> L, const float2 *xg, bool dvalid, bool want_energy, int slot)
 {
     constexpr int NG = W3Geom<SF, HV>::NG;
     uint32_t sq[NG];
     int32_t fq[NG];
     float eq[NG];
-    if constexpr (GRAD) w3_demod_round_grad<SF, HV, true>(DA, L, xg, dvalid, want_energy, slot, sq, fq, eq);
-    else w3_demod_round<SF, HV, true>(DA, L, xg, dvalid, want_energy, slot, sq, fq, eq);
+    w3_demod_round<SF, HV, true>(DA, L, xg, dvalid, want_energy, slot, sq, fq, eq);
     W3DemodOut o{};
 #pragma unroll
     for (int g = 0; g < NG; g++) { o.s[g] = sq[g]; o.fine[g] = fq[g]; o.en[g] = eq[g]; }
@@ -1279,6 +1232,10 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
     using G = W3Geom<SF, HV>;
     constexpr uint32_t sps = G::SPS;
     constexpr int T = G::T, NG = G::NG;
+    // windows a decode round evaluates: one per GROUP with the FFT demodulators (the pruned DFT needs the group's LDS array), one per WAVEFRONT with the
+    // gradient demodulator (w3_wave_window_grad: no FFT, nothing crosses a wavefront) - 8 at every spreading factor (4 in the half-size workgroups)
+    constexpr int NWIN = GRAD ? T / 64 : NG;
+    static_assert(NWIN <= 16, "W3Shared::wres");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const W3Lds<SF, HV> L = w3_carve<SF, HV>(smem);
     W3Shared &ws = *L.ws;
@@ -1313,10 +1270,10 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
         case kFindSfd: pl.mode = kPlanSfd; break;
         case kPause: pl.mode = kPlanPause; break;
         default:
-            pl.mode = kPlanDecode;
+            pl.mode = kPlanDecode; pl.n_win = NWIN;
             if (St.state == kDecodePayload && !P.implicit) { // symbols left in the packet (:866-870)
                 const int32_t rem = St.payload_symbols - (int32_t)St.n_words;
-                pl.n_win = rem < NG ? (rem > 0 ? rem : 1) : NG;
+                pl.n_win = rem < NWIN ? (rem > 0 ? rem : 1) : NWIN;
             }
             break;
         }
@@ -1513,20 +1470,42 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
 
         // ---- kPlanDecode: DECODE_HEADER / DECODE_PAYLOAD rounds (:826-886, demodulate :493-529) ----
         {
+            uint32_t sq[NWIN];
+            int32_t fq[NWIN];
+            float eq[NWIN];
+            if constexpr (GRAD) { // one window per wavefront: no barrier until the results are in LDS
+                const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+                const int64_t wpos = pos + (int64_t)wave * sps;
+                const bool wvalid = wave < plan_n_win && wpos + 2 * (int64_t)sps <= n_items;
+                uint32_t wb = 0u;
+                int32_t wf = 0;
+                float we = 0.0f;
+                if (wvalid) {
+                    if (plan_z) w3_wave_window_grad<SF, true>(DA, X + wpos, P.implicit != 0u, wb, wf, we); // (uniform) a round of ZM evaluations (W2Plan.zmode)
+                    else w3_wave_window_grad<SF>(DA, X + wpos, P.implicit != 0u, wb, wf, we);            // wf = kFinePoison: a sample of exactly zero in the window
+                }
+                if ((threadIdx.x & 63u) == 0u) { ws.wres[wave][0] = (int32_t)wb; ws.wres[wave][1] = wf; ws.wres[wave][2] = __builtin_bit_cast(int32_t, we); ws.wres[wave][3] = wvalid ? 1 : 0; }
+                __syncthreads();
+                if (t0) {
+#pragma unroll
+                    for (int g = 0; g < NWIN; g++) { sq[g] = (uint32_t)ws.wres[g][0]; fq[g] = ws.wres[g][1]; eq[g] = __builtin_bit_cast(float, ws.wres[g][2]); }
+#pragma unroll
+                    for (int g = 0; g < NWIN; g++) { // (thread 0's replay lives in scalar registers)
+                        sq[g] = (uint32_t)__builtin_amdgcn_readfirstlane((int)sq[g]); fq[g] = __builtin_amdgcn_readfirstlane(fq[g]); eq[g] = w3_uni(eq[g]);
+                    }
+                }
+            } else {
             const bool dvalid = gvalid && grp < plan_n_win;
-            uint32_t sq[NG];
-            int32_t fq[NG];
-            float eq[NG];
             if (plan_z) { // (uniform) a round of ZM evaluations: a window of the previous round holds a sample of exactly zero
-                const W3DemodOut zo = w3_demod_round_zm<SF, GRAD, HV>(DA, L, xg, dvalid, P.implicit != 0u, slot);
+                const W3DemodOut zo = w3_demod_round_zm<SF, HV>(DA, L, xg, dvalid, P.implicit != 0u, slot);
 #pragma unroll
                 for (int g = 0; g < NG; g++) {
                     sq[g] = (uint32_t)__builtin_amdgcn_readfirstlane((int)zo.s[g]); fq[g] = __builtin_amdgcn_readfirstlane(zo.fine[g]); eq[g] = w3_uni(zo.en[g]);
                 }
                 slot = __builtin_amdgcn_readfirstlane(zo.slot);
             } else
-            if constexpr (GRAD) w3_demod_round_grad<SF, HV>(DA, L, xg, dvalid, P.implicit != 0u, slot, sq, fq, eq); // sq = bin_idx itself; fq = kFinePoison: see W2Plan.zmode
-            else w3_demod_round<SF, HV>(DA, L, xg, dvalid, P.implicit != 0u, slot, sq, fq, eq);
+            w3_demod_round<SF, HV>(DA, L, xg, dvalid, P.implicit != 0u, slot, sq, fq, eq); // fq = kFinePoison: see W2Plan.zmode
+            }
             if (t0) {
                 bool zreq = false;
 #if LORA_W3_REPLAY_STATS
@@ -1544,13 +1523,13 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                 // three counters, but as one loop over every case (header, implicit mode, traces, limits, a break per outcome) the
                 // compiler carries the whole state through ~300 instructions per symbol: 1.7 k clocks each on the one thread
                 // that runs them, with the workgroup waiting (LORA_W3_REPLAY_STATS: 6.7 k of a 50 k round at SF9).
-                bool fast = !trace && P.implicit == 0u && St.state == kDecodePayload && plan_n_win == NG &&
-                            pos + (int64_t)(NG + 1) * (int64_t)sps <= n_items; // (every window passes the loop-top check, :91)
+                bool fast = !trace && P.implicit == 0u && St.state == kDecodePayload && plan_n_win == NWIN &&
+                            pos + (int64_t)(NWIN + 1) * (int64_t)sps <= n_items; // (every window passes the loop-top check, :91)
 #pragma unroll
-                for (int q = 0; q < NG; q++) fast = fast && fq[q] == 0;
+                for (int q = 0; q < NWIN; q++) fast = fast && fq[q] == 0;
                 if (fast) {
 #pragma unroll
-                    for (int g = 0; g < NG; g++) {
+                    for (int g = 0; g < NWIN; g++) {
                         const uint32_t sg = sq[g];
                         uint32_t bin_idx;
                         if constexpr (GRAD) bin_idx = sg;
@@ -1564,14 +1543,14 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                         St.pos += (int64_t)sps;
                     }
                 } else
-                for (int g = 0; g < NG; g++) {
+                for (int g = 0; g < NWIN; g++) {
                     if (g >= plan_n_win) break;
                     if (g > 0 && (!(St.state == kDecodeHeader || St.state == kDecodePayload) || !w2_pre_step(St, job, rec_cap, sps))) break;
                     uint32_t sg = sq[0];
                     int32_t fg = fq[0];
                     float eg = eq[0];
 #pragma unroll
-                    for (int q = 1; q < NG; q++) if (g == q) { sg = sq[q]; fg = fq[q]; eg = eq[q]; }
+                    for (int q = 1; q < NWIN; q++) if (g == q) { sg = sq[q]; fg = fq[q]; eg = eq[q]; }
                     if (fg == kFinePoison) { zreq = true; break; } // a sample of exactly zero in this window: it opens a round of ZM evaluations
                     const bool is_first = St.state == kDecodeHeader;
                     const int32_t st_w = St.state;
@@ -1732,8 +1711,8 @@ __global__ __launch_bounds__((W3Geom<SF, HV>::T), (W3Geom<SF, HV>::T512 ? 2 : 4)
         int32_t fs[G::NG];
         float en[G::NG];
         long long stamps[9];
-        if constexpr (GRAD) w3_demod_round_grad<SF, HV>(DA, L, iq + offsets[valid ? s0 + grp : s0], valid, false, slot, b, fs, en);
-        else w3_demod_round<SF, HV>(DA, L, iq + offsets[valid ? s0 + grp : s0], valid, false, slot, b, fs, en, stamps_out ? stamps : nullptr);
+        static_assert(!GRAD, "the gradient demodulator has a kernel of its own: demod_symbols_w3_grad_kernel");
+        w3_demod_round<SF, HV>(DA, L, iq + offsets[valid ? s0 + grp : s0], valid, false, slot, b, fs, en, stamps_out ? stamps : nullptr);
         if (stamps_out && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && s0 == blockIdx.x * G::NG + gridDim.x * G::NG) // (second round of block 0: every wavefront's stamps)
             for (int i = 0; i < 9; i++) stamps_out[(threadIdx.x >> 6) * 9 + i] = stamps[i];
         int32_t *fs_all = L.ws->sh.ibuf; // every group's d_fine_sync (the demodulator hands all groups' results to thread 0's wavefront only)
@@ -1749,8 +1728,7 @@ __global__ __launch_bounds__((W3Geom<SF, HV>::T), (W3Geom<SF, HV>::T512 ? 2 : 4)
 #pragma unroll
             for (int g = 0; g < G::NG; g++) pz = pz || __builtin_amdgcn_readfirstlane(fs_all[g]) == kFinePoison;
             if (pz) { // (uniform over the workgroup)
-                if constexpr (GRAD) w3_demod_round_grad<SF, HV, true>(DA, L, iq + offsets[valid ? s0 + grp : s0], valid, false, slot, b, fs, en);
-                else w3_demod_round<SF, HV, true>(DA, L, iq + offsets[valid ? s0 + grp : s0], valid, false, slot, b, fs, en, nullptr);
+                w3_demod_round<SF, HV, true>(DA, L, iq + offsets[valid ? s0 + grp : s0], valid, false, slot, b, fs, en, nullptr);
                 if (threadIdx.x == 0) {
                     for (int g = 0; g < G::NG; g++) {
                         if (s0 + (uint32_t)g < n) { bins[s0 + g] = b[g]; if (fine) fine[s0 + g] = fs[g]; }
@@ -1777,8 +1755,7 @@ __global__ __launch_bounds__((W3Geom<SF, HV>::T), (W3Geom<SF, HV>::T512 ? 2 : 4)
             if (any) {
                 uint32_t b2[G::NG];
                 int32_t f2[G::NG];
-                if constexpr (GRAD) w3_demod_round_grad<SF, HV>(DA, L, iq + (mine >= 0 ? mine : offsets[s0]), mine >= 0, false, slot, b2, f2, en);
-                else w3_demod_round<SF, HV>(DA, L, iq + (mine >= 0 ? mine : offsets[s0]), mine >= 0, false, slot, b2, f2, en, nullptr);
+                w3_demod_round<SF, HV>(DA, L, iq + (mine >= 0 ? mine : offsets[s0]), mine >= 0, false, slot, b2, f2, en, nullptr);
                 if (threadIdx.x == 0) {
                     for (int g = 0; g < G::NG; g++) {
                         if (s0 + (uint32_t)g + 1u >= n || fs[g] == 0) continue;
@@ -1798,6 +1775,36 @@ __global__ __launch_bounds__((W3Geom<SF, HV>::T), (W3Geom<SF, HV>::T512 ? 2 : 4)
 // ---- host side: tables -----------------------------------------------------------------------------------------
 // w3_tw: W_N^t, t < NTW.  w3_ctab: the combine coefficient of value i of thread t3 in round g at [(g 16 + i) T + t3]:
 // W_sps^{k r} for the signed bin k of k1 = a + 16 a2 + 256 b2 (+ the fold at k1 = N/2, :450).
+// The gradient demodulator on caller-given windows (lora_hip_demod_symbols_device, the payload pass of a decoupled pass): one WAVEFRONT per symbol
+// (w3_wave_window_grad), no LDS, no barrier; a poisoned window (a sample of exactly zero) is evaluated again in place by the ZM instantiation.  Second
+// reads (DemodAlt): the wavefront whose symbol moved the symbol clock reads that symbol's successor again, that far on - wavefront-local as well.
+template <int SF>
+__global__ __launch_bounds__(512, 2) void demod_symbols_w3_grad_kernel(DevParams P, const float2 *iq, const int64_t *offsets, uint32_t n, uint32_t *bins, int32_t *fine, DemodAlt alt)
+{
+    constexpr int SPS = 8 << SF;
+    const W3DemodArgs DA{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode};
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t s = blockIdx.x * 8u + wave; s < n; s += gridDim.x * 8u) {
+        const int64_t o0 = offsets[s];
+        uint32_t b;
+        int32_t fs;
+        float en;
+        w3_wave_window_grad<SF>(DA, iq + o0, false, b, fs, en);
+        if (fs == kFinePoison) w3_wave_window_grad<SF, true>(DA, iq + o0, false, b, fs, en); // (uniform over the wavefront)
+        if (lane == 0u) { bins[s] = b; if (fine) fine[s] = fs; }
+        if (alt.shift && fs != 0 && s + 1u < n) {
+            const int64_t o1 = offsets[s + 1u], a = o1 + (int64_t)fs;
+            if (o1 == o0 + (int64_t)SPS && a >= 0 && a <= alt.max_start) {
+                uint32_t b2;
+                int32_t f2;
+                w3_wave_window_grad<SF>(DA, iq + a, false, b2, f2, en);
+                if (f2 == kFinePoison) w3_wave_window_grad<SF, true>(DA, iq + a, false, b2, f2, en);
+                if (lane == 0u) { alt.bins[s + 1u] = b2; alt.fine[s + 1u] = f2; alt.shift[s + 1u] = fs; }
+            }
+        }
+    }
+}
+
 template <int SF, int HV = 0>
 static void build_w3_tables_sf(float2 *tw, float2 *ctab)
 {
