@@ -270,7 +270,7 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=0.5, help="the K-step block (--steps) is timed repeatedly, each block bracketed by barrier + synchronize on both sides, "
                     "until the timed blocks add up to this many seconds; value / ms_per_step are the MEDIAN block's (0: one block)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-grad-line", action="store_true", help="skip the second measurement (the reference's shipped gradient demodulator on the same workload; --no-cpu-baseline, the tools' quick mode, skips it too)")
+    ap.add_argument("--no-grad-line", action="store_true", help="skip the second measurement (the reference's shipped gradient demodulator on the same workload)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -481,7 +481,7 @@ def main():
     # makes it the headline): its own kernels (walker2/3_*_grad), verified against what the compiled reference published on this IQ
     # (tests/golden/fullsize_ref.json).  A second, shorter measurement after the timed region of the headline; single process only.
     grad_line = None
-    if rank == 0 and world == 1 and args.config in (2, 3) and args.demod != 0 and not (args.no_grad_line or args.no_cpu_baseline) and split_ranges is None:
+    if rank == 0 and world == 1 and args.config in (2, 3) and args.demod != 0 and not args.no_grad_line and split_ranges is None:
         try:
             fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_ref.json")))
             wantk = dict(sf=sf, cr=args.cr, packets=packets, payload=args.payload, streams=min(args.streams, packets), seed=(2 if args.config == 2 else 100 * sf + 4))

@@ -58,7 +58,7 @@ typedef enum lora_hip_demod {
                                       decides these ties its own way; no reference build agrees with another one there (tests/test_ref_pin.py::
                                       test_sync_shift_depends_on_volk_summation_order). */
 #define LORA_HIP_FLAG_NO_DECOUPLED 8u /* never run a pass decoupled.  A decoupled pass (chosen per pass when its jobs would leave most CUs idle - a gateway's short
-                                       * pass, a few packets per channel; SF9-12 at decimation 8, explicit header): the state-machine jobs stop behind every header
+                                       * pass, a few packets per channel; SF7-12 at decimation 8, explicit header): the state-machine jobs stop behind every header
                                        * and skip the payload, all payload symbols are demodulated at once at their zero-drift positions, and a packet whose symbols
                                        * moved the symbol clock is decoded again by the complete kernels.  Same frames either way (decoder_impl.cc:838-886).
                                        * LORA_HIP_DECOUPLED=0|1 in the environment overrides the per-pass choice (1: every pass the kernels allow). */

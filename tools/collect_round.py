@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Collects what tools/r04_final.sh (profile_all.sh) left under gpurun_out/ into profiles/<round>_* (after tools/profile_summary.py <tag> <round> for every
+"""Collects what tools/final_round.sh (profile_all.sh) left under gpurun_out/ into profiles/<round>_* (after tools/profile_summary.py <tag> <round> for every
 tag) and prints the table.  usage: tools/collect_round.py r04"""
 import json, os, shutil, sys
 RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
@@ -27,7 +27,7 @@ for tag in ["sf7","sf8","sf9","sf10","sf11","sf12","sf9_1024","sf7_grad","sf9_gr
     line=json.load(open("profiles/%s_%s_bench_line.json"%(RND,tag))); pmc=json.load(open("profiles/%s_%s_pmc_traffic.json"%(RND,tag)))
     assert pmc["source_hash"]==bench.source_hash(), tag
     r=line["roofline"]; n=line["config"]["items_per_gpu"]; rp=pmc["rocprof_walker_avg_ms_per_pass"]
-    print("%-10s %-26s value %7.1f Gs/s  kernel %.4f ms frac %.4f | rocprof %.4f ms frac %.4f | traffic %.2fx write %.3f GB | cpu %.1f (ref %.1f) | grad2 %s"%(tag, r["kernel"], line["value"]/1e3, r["kernel_ms_per_pass"], r["frac"], rp, 8*n/(rp*1e-3)/1e9/8000, pmc["traffic_over_algorithmic"], pmc["write_bytes_per_pass_raw"]/1e9, line["cpu_baseline"]["value"], (line["cpu_baseline"].get("reference_build") or {}).get("value",0), (line.get("reference_default_demodulator") or {}).get("frac")))
+    print("%-10s %-26s value %7.1f Gs/s  kernel %.4f ms frac %.4f | rocprof %.4f ms frac %.4f | traffic %.2fx write %.3f GB | cpu %.1f (ref %.1f) | grad2 %s"%(tag, r["kernel"], line["value"]/1e3, r["kernel_ms_per_pass"], r["frac"], rp, 8*n/(rp*1e-3)/1e9/8000, pmc["traffic_over_algorithmic"], pmc["write_bytes_per_pass_raw"]/1e9, (line.get("cpu_baseline") or {}).get("value",0), ((line.get("cpu_baseline") or {}).get("reference_build") or {}).get("value",0), (line.get("reference_default_demodulator") or {}).get("frac")))
 for f in ["default_line","default_fast_sync_line","default_grad_line","work_line","cfg4_line","cfg4_8s_line","cfg4_2s_line","torchrun1_line","streams1_line","mux_cfg4_2s_line","split1_line"]:
     d=json.load(open("gpurun_out/%s.json"%f)); print(f, d["value"], d.get("roofline",{}).get("frac"), d.get("roofline",{}).get("frac_rocprof"), d["config"].get("bit_exact_vs_expected"), d["config"].get("process_group"), (d.get("reference_default_demodulator") or {}).get("frac"), (d.get("one_handle_per_channel") or {}).get("value"))
 for k,v in out["kernels"].items(): print(k, list(v["derived"].values())[:4])

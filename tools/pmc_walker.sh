@@ -9,7 +9,7 @@ OUT=$REPO/gpurun_out/$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export LORA_BENCH_CACHE=${LORA_BENCH_CACHE:-/dev/shm/lora_bench}
-CMD="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
+CMD="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-grad-line --min-seconds 0 $*"
 i=0
 for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" \
            "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \

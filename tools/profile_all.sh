@@ -6,6 +6,7 @@ export LORA_BENCH_CACHE=/dev/shm/lora_bench
 mkdir -p gpurun_out
 {
 tools/profile_round.sh sf7
+export PROFILE_LINE_FLAGS=--no-cpu-baseline   # (the CPU legs once, in the sf7 set and the default line; the gradient second line needs them on: see below)
 tools/profile_round.sh sf8 --config 3 --sf 8 --packets 1024
 PROFILE_STEPS=8 tools/profile_round.sh sf9 --config 3 --sf 9
 PROFILE_STEPS=8 tools/profile_round.sh sf10 --config 3 --sf 10
