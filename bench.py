@@ -255,7 +255,7 @@ def main():
     ap.add_argument("--packets", type=int, default=None)
     ap.add_argument("--payload", type=int, default=32)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("LORA_BENCH_STREAMS", "8")))
-    ap.add_argument("--seconds", type=float, default=32.0, help="config 4: signal per channel per pass (BASELINE: continuous, at least 2 s; a pass of 8 s leaves the device half empty: 244 jobs of ~1 packet, DESIGN 5.2)")
+    ap.add_argument("--seconds", type=float, default=32.0, help="config 4: signal per channel per pass (BASELINE: continuous, at least 2 s; a pass of 8 s leaves the device half empty: 244 jobs of ~1 packet, docs/LAB_NOTEBOOK.md 5.2)")
     ap.add_argument("--demod", type=int, default=2, help="0 grad, 1 fft, 2 fft_compat")
     ap.add_argument("--depth", type=int, default=3, help="pipeline depth: 1 = strictly one pass after the other; 2 = while the device runs "
                     "step k+1 the host stitches step k (decoder handles alternating on one stream; walker kernels never overlap); "
@@ -565,11 +565,11 @@ def main():
         }
         pp = hs[0].payload_pass()
         if pp["packets"]:
-            # a decoupled pass: `kernel` is the header-only walker variant, `kernel_ms_per_pass` the SUM over the pass's kernels - header-only
+            # a decoupled pass (docs/LAB_NOTEBOOK.md 4.13): `kernel` is the header-only walker variant, `kernel_ms_per_pass` the SUM over the pass's kernels - header-only
             # jobs, the payload pass's symbol and chain kernels, the explicit probes - which overlap (two streams, and the passes of the pipeline among
             # themselves): the job's own fraction of the roofline is value x 8 B / peak
             res["roofline"]["decoupled_pass"] = {"last_pass": pp, "job_frac_of_hbm_peak": round(value * 1e6 * 8.0 / 1e9 / HBM_PEAK_GBS, 5),
-                                                 "note": "kernel_ms_per_pass sums kernels that overlap; see DESIGN 4.13 / 5.5"}
+                                                 "note": "kernel_ms_per_pass sums kernels that overlap; see docs/LAB_NOTEBOOK.md 4.13 / 5.5"}
         if grad_line is not None:
             res["reference_default_demodulator"] = grad_line
         if world == 1 and not args.no_cpu_baseline:

@@ -32,7 +32,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return LIB
     # -greedy-reverse-local-assignment: the walker kernels run at the 128-VGPR limit with 40-180 registers spilled; where the
-    # reloads land decides their speed, and this order measured +2.5 % at SF9, +0.5 % at SF11, neutral elsewhere
+    # reloads land decides their speed (docs/LAB_NOTEBOOK.md 5.2), and this order measured +2.5 % at SF9, +0.5 % at SF11, neutral elsewhere
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
            "-Wall", "-Wno-unused-function"] + CODEGEN_FLAGS + os.environ.get("LORA_HIP_EXTRA_FLAGS", "").split() + ["-I", CSRC, "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:

@@ -525,7 +525,7 @@ __device__ LORA_W2_ZM_ATTR W2DemodZ w2_demod_zm(uint32_t enable_fine_sync, uint3
 // ---- the kernel -----------------------------------------------------------------------------------------
 // GRAD: the reference's shipped demodulator (max_frequency_gradient_idx, :466-491, :499) in the decode rounds instead of the
 // dechirp + FFT: wave_demod_symbol_grad.  The FFT twiddle block is then not needed in LDS.
-// SKIP: the header-only variant of a decoupled pass (LaunchCfg.skip_payload; DESIGN 4.13, as walker3's): behind the header parse (:831-847) the attempt is
+// SKIP: the header-only variant of a decoupled pass (LaunchCfg.skip_payload; docs/LAB_NOTEBOOK.md 4.13, as walker3's): behind the header parse (:831-847) the attempt is
 // closed as kAttemptHeaderOnly - the record carries d_phdr, the header block's spare codewords and d_payload_symbols - and the job goes on in DETECT where
 // DECODE_PAYLOAD would end if no symbol moved the symbol clock; the payload pass (launch_demod_symbols + payload_chain_kernel) does the rest.
 template <int SF, int WAVES, bool GRAD, bool SKIP = false>
@@ -534,7 +534,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     constexpr int N = 1 << SF, SPS = 8 * N;
     constexpr int kW2 = 64 * WAVES, kW2Workers = WAVES - 1; // the last wavefront is the control wavefront
     // Decode rounds look at kW2Win windows: one per worker.  (A second window for the worker that shares its SIMD with the mostly waiting control
-    // wavefront was built and measured 13 % slower - the SIMD time-slices its wavefronts evenly, DESIGN 5.2 - and is gone from the sources.)
+    // wavefront was built and measured 13 % slower - the SIMD time-slices its wavefronts evenly, docs/LAB_NOTEBOOK.md 5.2 - and is gone from the sources.)
     constexpr int kW2Win = kW2Workers;
     static_assert(kW2Win <= kW2MaxWaves, "speci is sized for kW2MaxWaves windows");
     static_assert(WAVES <= kW2MaxWaves, "W2Shared is sized for kW2MaxWaves wavefronts");

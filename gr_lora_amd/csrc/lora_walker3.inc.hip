@@ -50,7 +50,7 @@ template <int SF, int HV = 0> struct W3Geom {
     static constexpr int N = 1 << SF, SPS = 8 * N;
     static constexpr bool T512 = true;                  // 512 threads x 256 registers (the 1024 x 128 geometry of round 2 is what T512 = false still describes)
     // HV = 1 (SF9 / SF10 only): HALF the workgroup - half the groups, half the threads, the same work per thread and the same geometry per group - so
-    // that TWO workgroups share a CU (79 / 78 KB of LDS each) and one's rounds fill the other's waits (+12 % at SF9, +4.5 % at SF10 when a
+    // that TWO workgroups share a CU (79 / 78 KB of LDS each) and one's rounds fill the other's waits (docs/LAB_NOTEBOOK.md 5.4: +12 % at SF9, +4.5 % at SF10 when a
     // launch holds at least two jobs per CU; with one job per CU it would walk its packet at half the width - the launcher picks by job count)
     static_assert(HV == 0 || (HV == 1 && SF <= 10), "half-size workgroups exist for SF9 and SF10");
     static constexpr int T = (T512 ? 512 : 1024) >> HV; // threads per workgroup (16 or 8 wavefronts, one workgroup per CU; HV: 4, two per CU)

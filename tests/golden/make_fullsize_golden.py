@@ -71,7 +71,7 @@ def run_case(tag, sf, cr, packets, payload, streams, seed):
              "n_items": int(iq.size), "source": "reference (oracle/_ref/libref_decoder.so, gradient demodulator)",
              "per_stream": [{"frames": len(f), "sha256": digest(f), "header_pos": [int(p) for p in pos],
                              "frame_sha": [hashlib.sha256(fr).hexdigest()[:10] for fr in f],
-                             # (the gradient estimator is not the transmitter's inverse on every symbol - DESIGN section 2,
+                             # (the gradient estimator is not the transmitter's inverse on every symbol - docs/LAB_NOTEBOOK.md section 2,
                              # tests/test_gpu_parity.py::test_gradient_vs_fft_divergence: the reference itself gets some payloads wrong)
                              "payloads_as_sent": sum(1 for a, b in zip([fr[15:] for fr in f], expect[k]) if a == b)} for k, (f, pos) in enumerate(res)]}
     print("%-20s %4d frames  %6.1f s  payloads as sent: %d" % (tag, sum(e["frames"] for e in entry["per_stream"]), time.time() - t0,

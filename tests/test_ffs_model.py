@@ -1,4 +1,4 @@
-"""The closed-form fine_sync rule (tools/ffs_model.py = wave_demod_symbol FMODE 2) against the oracle's fine_sync on CPU: wherever the rule
+"""The closed-form fine_sync rule (tools/ffs_model.py = wave_demod_symbol FMODE 2, docs/LAB_NOTEBOOK.md 5.4) against the oracle's fine_sync on CPU: wherever the rule
 claims a decision it is the reference's; the table constants are those lora_hip_create derives."""
 import os
 import sys

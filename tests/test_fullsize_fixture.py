@@ -35,7 +35,7 @@ def test_oracle_grad_equals_reference_fixture(oracle_mod, tag):
         assert len(f) == want["frames"] and _digest(f) == want["sha256"] and o.frame_positions() == want["header_pos"], (tag, k)
         total_as_sent += want["payloads_as_sent"]
     # the gradient estimator is not the transmitter's inverse on every symbol: the reference itself loses a few payloads on
-    # clean input; what is pinned is that everyone loses the SAME ones
+    # clean input (docs/LAB_NOTEBOOK.md section 2); what is pinned is that everyone loses the SAME ones
     assert 0.9 * fx["packets"] < total_as_sent <= fx["packets"]
 
 

@@ -164,7 +164,7 @@ def test_uint32_offset_compat_mode(torch_cuda):
     tuned frequency wraps (868.0 MHz tuned, 867.9 MHz wanted: -100032 -> 4294867264 Hz, an alias at 1 Msps) and apply_cfo adds in float
     (:70).  With the flag the device reproduces that arithmetic (same tolerance against the float64 restatement as everything else in
     this file); without it the offset keeps its sign.  No reference-held vector exists for this block: parity stays UNPINNED at sample
-    level - the oracle is a restatement of GNU Radio's published algorithm, not of its output."""
+    level (docs/LAB_NOTEBOOK.md 4.6) - the oracle is a restatement of GNU Radio's published algorithm, not of its output."""
     from gr_lora_amd import capi
     from oracle import channelizer_oracle as co
     rng = np.random.default_rng(5)

@@ -1,4 +1,4 @@
-"""Decoupled passes (gr_lora_amd/csrc/lora_stitch.hpp payload_begin / payload_end; include/lora_hip.h LORA_HIP_FLAG_NO_DECOUPLED): the
+"""Decoupled passes (gr_lora_amd/csrc/lora_stitch.hpp payload_begin / payload_end; include/lora_hip.h LORA_HIP_FLAG_NO_DECOUPLED; docs/LAB_NOTEBOOK.md 4.13): the
 state-machine jobs run the header-only kernel variant (walker3_kernel_sf*_skip, and since round 5 walker2_kernel_sf7/8*_skip; LaunchCfg.skip_payload) - a packet's attempt ends behind its header, the job
 goes on where the payload would end had no symbol moved the symbol clock - and the payload pass demodulates every payload symbol of every packet at once
 (demod_symbols_w3_kernel, second reads behind symbols that move the clock) and walks each packet's symbols through the integer chain

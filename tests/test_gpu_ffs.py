@@ -1,4 +1,4 @@
-"""d_fine_sync of the SF7 / SF8 wave demodulator on hostile windows - and the closed-form fine_sync behind LORA_W2_FFS (wave_demod_symbol FMODE 2, DESIGN 5.4:
+"""d_fine_sync of the SF7 / SF8 wave demodulator on hostile windows - and the closed-form fine_sync behind LORA_W2_FFS (wave_demod_symbol FMODE 2, docs/LAB_NOTEBOOK.md 5.4:
 built, green, measured slower, off by default; this test is what a build with the switch on has to pass).  d_fine_sync per window against the oracle's fine_sync
 (lib/decoder_impl.cc:300-338) on every kind of window tools/ffs_model.py knows - clean and noisy symbols cut early / late, noise,
 downchirps, tones, interferers, carrier offsets, partial windows, bursts, clipping - i.e. on windows that take the closed form AND on

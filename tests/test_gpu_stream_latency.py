@@ -1,4 +1,4 @@
-"""Streaming latency of lora_hip_work.
+"""Streaming latency of lora_hip_work (docs/LAB_NOTEBOOK.md 4.8).
 
 The reference publishes a frame inside the work() call that completes the packet (decoder_impl.cc:870-881).  The library decodes
 in device passes; lora_hip_set_stream_latency bounds how long a delivered sample may wait for its pass (wall clock), and a

@@ -90,7 +90,7 @@ def test_sync_decision_is_the_reference_s(oracle_mod, sf, demod):
 @pytest.mark.parametrize("sf", [11, 12])
 def test_fast_sync_flag_keeps_the_closed_form(oracle_mod, sf):
     """LORA_HIP_FLAG_FAST_SYNC: the double-precision maximum stands - one sample beside the reference's float sums on a clean
-    SF11 / SF12 preamble, same frames from the FFT demodulators"""
+    SF11 / SF12 preamble (docs/LAB_NOTEBOOK.md 2), same frames from the FFT demodulators"""
     from gr_lora_amd import capi
     from parity_util import assert_trace_parity
     cfg = synth.TxConfig(sf=sf, cr=4, reduced_rate=True)
