@@ -606,21 +606,26 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
 // group-per-window form of rounds 2-4 took 4 / 2 / 1 / 1 windows behind five barriers; same-box A/B: profiles/r05_ab_wave_gradient.txt).
 // bin_out is demodulate()'s bin_idx itself; fine_out = kFinePoison for a window with a sample of exactly zero (re-evaluated by ZM = true, which patches
 // the poisoned values with ifreq_prod_z).  en_out: determine_energy (:368-375) when want_energy.
+// fcache: this wavefront's kW3GradCacheChunks x 1024 floats of LDS - pass A leaves the ifreq of the window's first chunks there and pass B reads them back
+// instead of forming them again (the whole window at SF9, half of it at SF10, ...): fewer arctangents and no second read for those chunks.
+constexpr int kW3GradCacheChunks = 4;
 template <int SF, bool ZM = false>
-__device__ __forceinline__ void w3_wave_window_grad(const W3DemodArgs &P, const float2 *__restrict__ x, bool want_energy, uint32_t &bin_out, int32_t &fine_out, float &en_out)
+__device__ __forceinline__ void w3_wave_window_grad(const W3DemodArgs &P, const float2 *__restrict__ x, bool want_energy, uint32_t &bin_out, int32_t &fine_out, float &en_out, float *fcache)
 {
-    constexpr int N = 1 << SF, SPS = 8 * N, NCH = SPS / 1024;
+    constexpr int N = 1 << SF, SPS = 8 * N, NCH = SPS / 1024, NCC = NCH < kW3GradCacheChunks ? NCH : kW3GradCacheChunks;
+    typedef __attribute__((address_space(3))) float lds_f;
+    lds_f *fc = (lds_f *)fcache;
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane)); // (keeps per-lane addresses out of the caller's loop-invariant set)
     const auto xv = (const __attribute__((address_space(1))) v2f *)x;
     // one pass over the window: use(q, f) with f[j] = ifreq[1024 q + 64 j + lane]; ifreq[sps-1] = ifreq[sps-2] (:243)
-    auto pass = [&](auto &&use, bool energy) {
+    auto pass = [&](auto &&use, bool energy, int q_first) {
         v2f nxt[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) nxt[j] = xv[j * 64 + lane];
+        for (int j = 0; j < 16; j++) nxt[j] = xv[q_first * 1024 + j * 64 + lane];
         v2f e2 = (v2f){0.0f, 0.0f};
 #pragma unroll 1
-        for (int q = 0; q < NCH; q++) {
+        for (int q = q_first; q < NCH; q++) {
             v2f a[16];
 #pragma unroll
             for (int j = 0; j < 16; j++) a[j] = nxt[j];
@@ -664,6 +669,10 @@ __device__ __forceinline__ void w3_wave_window_grad(const W3DemodArgs &P, const 
     float gs = 0.0f, prev_perm = 0.0f; // gs carries the poison of a zero sample when there is no fine_sync sum to carry it
     const int m = lane >> 3, perm_addr = ((lane - 8) & 63) << 2;
     const float e = pass([&](int q, const float (&f)[16]) {
+        if (q < NCC) { // (uniform) kept for pass B
+#pragma unroll
+            for (int j = 0; j < 16; j++) fc[(q * 16 + j) * 64 + lane] = f[j];
+        }
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             float A = f[j];
@@ -677,7 +686,7 @@ __device__ __forceinline__ void w3_wave_window_grad(const W3DemodArgs &P, const 
             const int i = 128 * q + 8 * j + m;
             if (i >= 1 && g > bv) { bv = g; bi = i; } // i runs from 1; strict '>' keeps the first maximum
         }
-    }, want_energy);
+    }, want_energy, 0);
     en_out = want_energy ? wave_sum_u(e) : 0.0f;
     const float best = wave_max_nonneg_u(bv);
     const int first = wave_min_u((bv == best) ? bi : 0x7fffffff);
@@ -692,11 +701,19 @@ __device__ __forceinline__ void w3_wave_window_grad(const W3DemodArgs &P, const 
     // pass B: fine_sync (:300-338), lags -1, 0, +1: c_lag = sum_k f[k] v[(bin_idx + 1) 8 + sps + lag + k]
     const float *__restrict__ vp = P.up_ifreq_v + ((int)(bin_idx + 1u) * 8 + SPS) + (lane - 1);
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-    (void)pass([&](int q, const float (&f)[16]) {
+    auto taps = [&](int q, const float (&f)[16]) {
         const float *__restrict__ vq = vp + 1024 * q;
 #pragma unroll
         for (int j = 0; j < 16; j++) { c0 += f[j] * vq[64 * j]; c1 += f[j] * vq[64 * j + 1]; c2 += f[j] * vq[64 * j + 2]; }
-    }, false);
+    };
+#pragma unroll 1
+    for (int q = 0; q < NCC; q++) { // the chunks pass A kept (this lane's own values: no synchronisation needed)
+        float f[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) f[j] = fc[(q * 16 + j) * 64 + lane];
+        taps(q, f);
+    }
+    if constexpr (NCC < NCH) (void)pass(taps, false, NCC);
     c0 = wave_sum_u(c0); c1 = wave_sum_u(c1); c2 = wave_sum_u(c2);
     if (!ZM && poisoned3(c0, c1, c2)) { fine_out = kFinePoison; return; } // (uniform) a sample of the window is exactly zero: the bin averages next to it are NaN as well
     float mx = 0.0f;
@@ -1481,8 +1498,9 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                 int32_t wf = 0;
                 float we = 0.0f;
                 if (wvalid) {
-                    if (plan_z) w3_wave_window_grad<SF, true>(DA, X + wpos, P.implicit != 0u, wb, wf, we); // (uniform) a round of ZM evaluations (W2Plan.zmode)
-                    else w3_wave_window_grad<SF>(DA, X + wpos, P.implicit != 0u, wb, wf, we);            // wf = kFinePoison: a sample of exactly zero in the window
+                    float *fcache = reinterpret_cast<float *>(L.data) + wave * (kW3GradCacheChunks * 1024); // (the FFT demodulators' LDS array, idle in these kernels)
+                    if (plan_z) w3_wave_window_grad<SF, true>(DA, X + wpos, P.implicit != 0u, wb, wf, we, fcache); // (uniform) a round of ZM evaluations (W2Plan.zmode)
+                    else w3_wave_window_grad<SF>(DA, X + wpos, P.implicit != 0u, wb, wf, we, fcache);            // wf = kFinePoison: a sample of exactly zero in the window
                 }
                 if ((threadIdx.x & 63u) == 0u) { ws.wres[wave][0] = (int32_t)wb; ws.wres[wave][1] = wf; ws.wres[wave][2] = __builtin_bit_cast(int32_t, we); ws.wres[wave][3] = wvalid ? 1 : 0; }
                 __syncthreads();
@@ -1784,21 +1802,23 @@ __global__ __launch_bounds__(512, 2) void demod_symbols_w3_grad_kernel(DevParams
     constexpr int SPS = 8 << SF;
     const W3DemodArgs DA{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode};
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *fcache = reinterpret_cast<float *>(smem) + wave * (kW3GradCacheChunks * 1024);
     for (uint32_t s = blockIdx.x * 8u + wave; s < n; s += gridDim.x * 8u) {
         const int64_t o0 = offsets[s];
         uint32_t b;
         int32_t fs;
         float en;
-        w3_wave_window_grad<SF>(DA, iq + o0, false, b, fs, en);
-        if (fs == kFinePoison) w3_wave_window_grad<SF, true>(DA, iq + o0, false, b, fs, en); // (uniform over the wavefront)
+        w3_wave_window_grad<SF>(DA, iq + o0, false, b, fs, en, fcache);
+        if (fs == kFinePoison) w3_wave_window_grad<SF, true>(DA, iq + o0, false, b, fs, en, fcache); // (uniform over the wavefront)
         if (lane == 0u) { bins[s] = b; if (fine) fine[s] = fs; }
         if (alt.shift && fs != 0 && s + 1u < n) {
             const int64_t o1 = offsets[s + 1u], a = o1 + (int64_t)fs;
             if (o1 == o0 + (int64_t)SPS && a >= 0 && a <= alt.max_start) {
                 uint32_t b2;
                 int32_t f2;
-                w3_wave_window_grad<SF>(DA, iq + a, false, b2, f2, en);
-                if (f2 == kFinePoison) w3_wave_window_grad<SF, true>(DA, iq + a, false, b2, f2, en);
+                w3_wave_window_grad<SF>(DA, iq + a, false, b2, f2, en, fcache);
+                if (f2 == kFinePoison) w3_wave_window_grad<SF, true>(DA, iq + a, false, b2, f2, en, fcache);
                 if (lane == 0u) { alt.bins[s + 1u] = b2; alt.fine[s + 1u] = f2; alt.shift[s + 1u] = fs; }
             }
         }
