@@ -33,6 +33,9 @@ for _sf in (7, 8, 9, 10, 11, 12):
         CASES.append(("config3-sf%d-cr%d" % (_sf, _cr), _sf, _cr, 256, 32, 8, 100 * _sf + _cr))
 
 
+# the default bench workload as the ranks 1 .. 7 of a multi-GPU run synthesise it (bench.py: seed 2 + 1000 rank): `bench.py --demod 0 --gpus N` then has a yardstick on every rank
+for _r in range(1, 8):
+    CASES.append(("config2-8streams-rank%d" % _r, 7, 4, 1024, 32, 8, 2 + 1000 * _r))
 CASES.append(("config3-sf8-cr4-1024packets", 8, 4, 1024, 32, 8, 804))  # the SF8 profile workload (tools/profile_all.sh: 1024 packets fill the device)
 
 

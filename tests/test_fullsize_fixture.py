@@ -62,3 +62,12 @@ def test_oracle_fft_reproduces_its_fixture_cell(oracle_mod):
         o.run(iq[offs[k]:offs[k] + lens[k]])
         f = o.frames()
         assert len(f) == want["frames"] and _digest(f) == want["sha256"] and o.frame_positions() == want["header_pos"], k
+
+
+def test_reference_fixture_has_every_rank_of_the_default_workload():
+    """bench.py --demod 0 --gpus N: rank r decodes the default workload synthesised with seed 2 + 1000 r and needs the compiled reference's frames for it"""
+    fx = json.load(open(_FIX))
+    for r in range(1, 8):
+        e = fx["config2-8streams-rank%d" % r]
+        assert e["seed"] == 2 + 1000 * r and e["packets"] == 1024 and e["streams"] == 8 and e["source"].startswith("reference")
+        assert sum(s["frames"] for s in e["per_stream"]) == 1024

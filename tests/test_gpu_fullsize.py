@@ -109,6 +109,13 @@ def test_config3_full_size_grad_vs_reference_fixture(sf, cr):
     _against_reference_fixture("config3-sf%d-cr%d" % (sf, cr))
 
 
+@pytest.mark.parametrize("r", [3, 7])
+def test_config2_other_ranks_workload_grad_vs_reference_fixture(r):
+    """the default workload as rank r of a multi-GPU run synthesises it (bench.py: seed 2 + 1000 r): `bench.py --demod 0 --gpus N` verifies every rank against
+    what the compiled reference published on that rank's IQ (round 5: fixtures for ranks 1 .. 7)"""
+    _against_reference_fixture("config2-8streams-rank%d" % r)
+
+
 def test_sf8_profile_workload_grad_vs_reference_fixture():
     """the SF8 workload of the profile set (1024 packets: tools/profile_all.sh) in the reference's shipped mode"""
     _against_reference_fixture("config3-sf8-cr4-1024packets")

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Issue-cycle model of a device function: its ISA listing (tools/w3_asm.sh writes /tmp/w3/k.s) weighted with the measured
+"""Issue-cycle model of a device function: its ISA listing (LISTING=<file>, default /tmp/w3/k.s: `hipcc --offload-arch=gfx950 -O3 -S --cuda-device-only -o /tmp/w3/k.s
+gr_lora_amd/csrc/lora_kernels.hip`) weighted with the measured
 cycles per wave64 instruction (tools/ubench_valu.hip): packed fp32 4.3, plain fp32 fma / mul / add 2.6, DPP / select / compare /
 min / max / integer 4.3, v_rcp and v_permlane*_swap 8.2, s_nop N = N + 1.   usage: tools/cycle_model.py <substring of the symbol>"""
-import re,sys
+import os,re,sys
 from collections import Counter
-lines=open('/tmp/w3/k.s').read().split('\n')
+lines=open(os.environ.get('LISTING','/tmp/w3/k.s')).read().split('\n')
 labels=[(i,l.split(':')[0]) for i,l in enumerate(lines) if re.match(r'^_Z\w+:',l)]
 for idx,(i,name) in enumerate(labels):
     if sys.argv[1] not in name: continue
