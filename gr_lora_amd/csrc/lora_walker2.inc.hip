@@ -27,7 +27,7 @@ constexpr int kW2DetectK = 4;   // DETECT windows per worker and round
 #define LORA_W2_SFD_K 2 // FIND_SFD windows per worker and round
 #endif
 #ifndef LORA_W2_EU_SF8
-#define LORA_W2_EU_SF8 2 // wavefronts per SIMD the SF8 kernel's register budget is set for
+#define LORA_W2_EU_SF8 4 // wavefronts per SIMD the SF8 kernel's register budget is set for (round 5: 128 registers and 73 KB of LDS, two workgroups per CU as at SF7: +19 % - until then 2: 256 registers, one)
 #endif
 // wavefronts per workgroup the shared structures are sized for (SF7: 16-wave workgroups, one per CU, were measured slower:
 // all 15 workers hit their load and VALU phases together)
@@ -510,6 +510,7 @@ __device__ LORA_W2_ZM_ATTR W2SfdOut w2_sfd_window_zm(const float2 *p, const floa
 {
     return w2_sfd_window<SF, true>(p, Tv, Tdd, scr, down_ifreq_sd, down_ifreq_dsum, sync_a, sync_b);
 }
+template <int SF> constexpr bool kW2Alias = SF == 8; // SYNC's work areas inside the FFT table block (walker2_body ALIAS)
 struct W2DemodZ { uint32_t s; int32_t fine; float en; };
 template <int SF, bool GRAD>
 __device__ LORA_W2_ZM_ATTR W2DemodZ w2_demod_zm(uint32_t enable_fine_sync, uint32_t demod_mode, bool want_energy, WaveTabs T, const float2 *x)
@@ -545,12 +546,18 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     Shared &sh = W.sh;
     // LDS carve-up after W2Shared: f2[2 sps] | v[3 sps + 40 (padded to 4)] | dd[sps] | twiddle block of the wave
     // demodulator | chunk prefix sums of the SYNC correlation
-    float *f2 = reinterpret_cast<float *>(smem + ((sizeof(W2Shared) + 15) & ~(size_t)15));
-    float *vl = f2 + 2 * SPS;
+    // ALIAS (SF8): SYNC's two work areas lie IN the twiddle block - which only decode rounds read - and every SYNC round ends by copying the
+    // block in again (36 KB from L2, once per acquisition): 73 KB instead of 94 KB, two workgroups per CU
+    constexpr bool ALIAS = kW2Alias<SF> && !GRAD;
     constexpr uint32_t NV = (3u * SPS + 40u + 3u) & ~3u;
+    float *lds0 = reinterpret_cast<float *>(smem + ((sizeof(W2Shared) + 15) & ~(size_t)15));
+    float *vl = ALIAS ? lds0 : lds0 + 2 * SPS;
     float *ddl = vl + NV;
-    v4f *tab4 = reinterpret_cast<v4f *>(ddl + SPS);
-    double *pre = reinterpret_cast<double *>(tab4 + (GRAD ? 0u : WaveGeom<SF>::n_v4f)); // SYNC: chunk prefix sums (2 x 256) + per-wavefront totals
+    v2f *tab2 = reinterpret_cast<v2f *>(ddl + SPS);
+    float *f2 = ALIAS ? reinterpret_cast<float *>(tab2) : lds0;
+    double *pre = ALIAS ? reinterpret_cast<double *>(f2 + 2 * SPS)
+                        : reinterpret_cast<double *>(tab2 + (GRAD ? 0u : WaveGeom<SF>::n_ent)); // SYNC: chunk prefix sums (2 x 256) + per-wavefront totals
+    static_assert(!ALIAS || (2u * SPS * 4u + (2u * 256u + 8u) * 8u <= WaveGeom<SF>::n_ent * 8u && kWaveFmode<SF> != 2), "SYNC's work areas fit the table block; no closed-form scratch in them");
     // closed-form fine_sync (wave_demod_symbol FMODE 2): one scratch area per worker.  SYNC's two work areas (f2, pre) are idle in decode rounds
     // and take the first workers; the others get an area behind `pre`.  (All seven behind `pre` made the SF7 workgroup 80.4 KB: one per CU.)
     constexpr int kZsN = kWaveFfsEntries<SF>, kZsF2 = (2 * SPS * 4) / (kZsN * 8), kZsPre = ((2 * 256 + 8) * 8) / (kZsN * 8);
@@ -578,7 +585,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         for (uint32_t i = threadIdx.x; i < 3u * sps + 40u; i += kW2) vl[i] = P.up_ifreq_v[i];
         FT.v = vl;
     } else {
-        FT = wave_tabs_to_lds<SF>(P, tab4, vl, kW2);
+        FT = wave_tabs_to_lds<SF>(P, tab2, vl, kW2);
     }
     for (uint32_t i = threadIdx.x; i < sps; i += kW2) ddl[i] = P.down_ifreq[i] - P.down_ifreq_avg;
 
@@ -813,6 +820,11 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 W2Plan np;
                 plan_from(L, np);
                 next = np; S = L;
+            }
+            if constexpr (ALIAS) { // the twiddle block back over SYNC's work areas (visible behind the next round's barrier)
+                __syncthreads();
+                const v2f *__restrict__ src = reinterpret_cast<const v2f *>(P.wave_tabs);
+                for (uint32_t i = threadIdx.x; i < WaveGeom<SF>::n_ent; i += kW2) tab2[i] = src[i];
             }
             continue;
         }
@@ -1099,6 +1111,9 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
 constexpr int kW2WavesSf7 = LORA_W2_WAVES_SF7, kW2WavesSf8 = LORA_W2_WAVES_SF8;
 __global__ __launch_bounds__(64 * kW2WavesSf7, 4) void walker2_kernel_sf7(DevParams P, LaunchCfg C) { walker2_body<7, kW2WavesSf7, false>(P, C); }
 __global__ __launch_bounds__(64 * kW2WavesSf8, LORA_W2_EU_SF8) void walker2_kernel_sf8(DevParams P, LaunchCfg C) { walker2_body<8, kW2WavesSf8, false>(P, C); }
+// the same body at the 256-register budget (one workgroup per CU by registers): what launch_walker picks for a launch with no more jobs than CUs, where a
+// workgroup has its CU to itself anyway - 0.161 against 0.138 of HBM peak at 256 packets; with more jobs the two-per-CU build above wins, 0.251 against 0.211 at 1024
+__global__ __launch_bounds__(64 * kW2WavesSf8, 2) void walker2_kernel_sf8_wide(DevParams P, LaunchCfg C) { walker2_body<8, kW2WavesSf8, false>(P, C); }
 // the gradient demodulator (demod_mode 0, the reference's default): no FFT tables, fewer live registers
 #ifndef LORA_W2_EU_GRAD_SF7
 #define LORA_W2_EU_GRAD_SF7 4
@@ -1108,9 +1123,9 @@ __global__ __launch_bounds__(64 * kW2WavesSf8, LORA_W2_EU_SF8) void walker2_kern
 #endif
 __global__ __launch_bounds__(64 * kW2WavesSf7, LORA_W2_EU_GRAD_SF7) void walker2_kernel_sf7_grad(DevParams P, LaunchCfg C) { walker2_body<7, kW2WavesSf7, true>(P, C); }
 __global__ __launch_bounds__(64 * kW2WavesSf8, LORA_W2_EU_GRAD_SF8) void walker2_kernel_sf8_grad(DevParams P, LaunchCfg C) { walker2_body<8, kW2WavesSf8, true>(P, C); }
-// the header-only variants of a decoupled pass (SKIP)
+// the header-only variants of a decoupled pass (SKIP); a decoupled pass has no more jobs than CUs: SF8 at the 256-register budget
 __global__ __launch_bounds__(64 * kW2WavesSf7, 4) void walker2_kernel_sf7_skip(DevParams P, LaunchCfg C) { walker2_body<7, kW2WavesSf7, false, true>(P, C); }
-__global__ __launch_bounds__(64 * kW2WavesSf8, LORA_W2_EU_SF8) void walker2_kernel_sf8_skip(DevParams P, LaunchCfg C) { walker2_body<8, kW2WavesSf8, false, true>(P, C); }
+__global__ __launch_bounds__(64 * kW2WavesSf8, 2) void walker2_kernel_sf8_skip(DevParams P, LaunchCfg C) { walker2_body<8, kW2WavesSf8, false, true>(P, C); }
 __global__ __launch_bounds__(64 * kW2WavesSf7, LORA_W2_EU_GRAD_SF7) void walker2_kernel_sf7_grad_skip(DevParams P, LaunchCfg C) { walker2_body<7, kW2WavesSf7, true, true>(P, C); }
 __global__ __launch_bounds__(64 * kW2WavesSf8, LORA_W2_EU_GRAD_SF8) void walker2_kernel_sf8_grad_skip(DevParams P, LaunchCfg C) { walker2_body<8, kW2WavesSf8, true, true>(P, C); }
 
@@ -1127,6 +1142,8 @@ static uint32_t walker2_lds_bytes(uint32_t sf, bool grad = false)
 {
     const uint32_t sps = 8u << sf;
     const uint32_t nv = (3u * sps + 40u + 3u) & ~3u;
+    if (!grad && sf == 8u && kW2Alias<8>) // (SYNC's work areas inside the table block)
+        return (uint32_t)((sizeof(W2Shared) + 15) & ~(size_t)15) + (nv + sps) * (uint32_t)sizeof(float) + wave_tables_floats(sf) * (uint32_t)sizeof(float);
     return (uint32_t)((sizeof(W2Shared) + 15) & ~(size_t)15) + (2u * sps + nv + sps) * (uint32_t)sizeof(float) +
            (grad ? 0u : wave_tables_floats(sf) * (uint32_t)sizeof(float)) + (2u * 256u + 8u) * (uint32_t)sizeof(double) +
            (grad ? 0u : w2_ffs_extra_workers(sps) * (sps / 4u + 4u) * (uint32_t)sizeof(float2)); // (+ closed-form fine_sync scratch of the workers that do not fit SYNC's idle areas)

@@ -64,14 +64,20 @@ template <int SF, int HV = 0> struct W3Geom {
     static constexpr int AR = 16 / ROUNDS;              // rows resident in LDS per round
     static constexpr int M = N / 16, M2 = M / 16, LOGM2 = ilog2(M2);
     static constexpr int SA = 8 * M + 8;                // entries per row
-    static constexpr int NTW = (N > 2048 || (HV && SF == 10)) ? N / 2 : N; // W_N^t entries kept in LDS (SF12, and SF10's half-size workgroup - 82 080 -> 77 984 B -: half, the rest by sign)
+    // SF9, full-size workgroup (round 5): the FFT demodulator is wave_demod_symbol<9> - one window per WAVEFRONT, everything in registers (lora_wave_demod.inc.hip) -
+    // and the LDS array holds [16 KB of acquisition scratch | its tables]; passes 1-3 below are then SF10-SF12's (and the half-size SF9 workgroup's)
+    static constexpr bool WFFT = SF == 9 && HV == 0;
+    static constexpr int NTW = WFFT ? 0 : (N > 2048 || (HV && SF == 10)) ? N / 2 : N; // W_N^t entries kept in LDS (SF12, and SF10's half-size workgroup - 82 080 -> 77 984 B -: half, the rest by sign)
+    static constexpr int STRICT_CH = WFFT ? 512 : 2048; // strict SYNC's chunk unit (strict::resolve; two buffers of kK x CH floats at the head of the LDS array: 16 KB / 64 KB)
     static constexpr int CH = SPS / 16;                 // samples between a thread's consecutive loads
     static constexpr int NWL = VT / (8 * AR), NB = 16 / NWL; // pass 3: butterflies per unit
     static constexpr int LEN = SPS / T;                 // SYNC: shifts per thread (all groups together)
     static constexpr bool LATE_F = SF == 12;            // fine_sync's ifreq from a second read of the window (SF12: 64 more live registers otherwise)
     static constexpr bool UNIFORM_JOB = true;           // the job record through readfirstlane (uniform_job)
     static constexpr bool FAST_MOD = true;              // power-of-two reductions of the replay as masks
-    static constexpr uint32_t data_entries = (uint32_t)AR * SA; // per group
+    static constexpr uint32_t kWfftScratch = 16384u;
+    static constexpr uint32_t data_entries = WFFT ? (kWfftScratch + kWaveLdsBytes<9>) / 8u / (uint32_t)NG : (uint32_t)AR * SA; // per group
+    static_assert(!WFFT || (kWfftScratch + kWaveLdsBytes<9>) % (8u * (uint32_t)NG) == 0u, "the SF9 table block in whole entries");
     static_assert(NB * M2 == 16, "pass 3 covers 16 values per unit");
     static_assert(AR * M2 * 8 == VT, "pass 2 uses every unit of the group once per round");
     static_assert(U * TG == VT && U == PAIRS / (SF == 12 ? 2 : 1) && TG % 64 == 0, "geometry");
@@ -125,15 +131,6 @@ __device__ __forceinline__ v2f w3_tw(const W3Lds<SF, HV> &L, uint32_t idx)
     }
 }
 
-// a * w in two packed instructions: t = a.yy * (-w.y, w.x) through op_sel / neg_lo, then a.xx * w + t (written out: from
-// vector code the compiler builds (-w.y, w.x) with a v_xor and a v_mov first)
-__device__ __forceinline__ v2f cmul2(v2f a, v2f w)
-{
-    v2f t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "v"(w));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
-    return r;
-}
 // K complex multiplies a[i] *= w[i], the multiplies first and the multiply-adds after them (a v_pk_fma_f32 directly behind
 // the v_pk_mul_f32 it depends on costs a wait state)
 template <int K>
@@ -989,7 +986,7 @@ __device__ __attribute__((noinline)) W3SyncOut w3_sync(double sync_a, double syn
         const int nc = ws.sc.n;
         if (nc >= 2 && nc <= strict::kK) {
             float ev;
-            bi = strict::resolve<G::T, 2048, true>(x, SPS, strict_u, &ws.sc, strict_buf, &ev);
+            bi = strict::resolve<G::T, G::STRICT_CH, true>(x, SPS, strict_u, &ws.sc, strict_buf, &ev);
             bv = ev;
         }
     }
@@ -1251,7 +1248,8 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
     constexpr int T = G::T, NG = G::NG;
     // windows a decode round evaluates: one per GROUP with the FFT demodulators (the pruned DFT needs the group's LDS array), one per WAVEFRONT with the
     // gradient demodulator (w3_wave_window_grad: no FFT, nothing crosses a wavefront) - 8 at every spreading factor (4 in the half-size workgroups)
-    constexpr int NWIN = GRAD ? T / 64 : NG;
+    constexpr bool WFFT = G::WFFT && !GRAD; // SF9: the FFT demodulator one window per wavefront as well (wave_demod_symbol<9>)
+    constexpr int NWIN = (GRAD || WFFT) ? T / 64 : NG;
     static_assert(NWIN <= 16, "W3Shared::wres");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const W3Lds<SF, HV> L = w3_carve<SF, HV>(smem);
@@ -1273,7 +1271,9 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
     int slot = 0;
     const W3DemodArgs DA{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode};
 
-    w3_tables_to_lds<SF, HV>(P, L);
+    WaveTabs WT{};
+    if constexpr (WFFT) WT = wave_tabs_to_lds<SF>(P, smem + G::kWfftScratch, (uint32_t)T); // (visible behind the round loop's first barrier)
+    else w3_tables_to_lds<SF, HV>(P, L);
 
     // plan for the next round from the TRUE state (thread 0 only)
     auto plan_from = [&](W2State &St, W2Plan &pl, bool zreq = false /* a window of this round came back poisoned (a sample of exactly zero): the next round is a ZM one */) {
@@ -1490,17 +1490,26 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
             uint32_t sq[NWIN];
             int32_t fq[NWIN];
             float eq[NWIN];
-            if constexpr (GRAD) { // one window per wavefront: no barrier until the results are in LDS
+            if constexpr (GRAD || WFFT) { // one window per wavefront: no barrier until the results are in LDS
                 const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
                 const int64_t wpos = pos + (int64_t)wave * sps;
                 const bool wvalid = wave < plan_n_win && wpos + 2 * (int64_t)sps <= n_items;
                 uint32_t wb = 0u;
                 int32_t wf = 0;
                 float we = 0.0f;
+                if constexpr (GRAD) {
                 if (wvalid) {
                     float *fcache = reinterpret_cast<float *>(L.data) + wave * (kW3GradCacheChunks * 1024); // (the FFT demodulators' LDS array, idle in these kernels)
                     if (plan_z) w3_wave_window_grad<SF, true>(DA, X + wpos, P.implicit != 0u, wb, wf, we, fcache); // (uniform) a round of ZM evaluations (W2Plan.zmode)
                     else w3_wave_window_grad<SF>(DA, X + wpos, P.implicit != 0u, wb, wf, we, fcache);            // wf = kFinePoison: a sample of exactly zero in the window
+                }
+                } else {
+                if (wvalid) {
+                    float *en_p = P.implicit != 0u ? &we : nullptr;
+                    if (plan_z) wave_demod_symbol<SF, 1, true>(P, WT, X + wpos, wb, wf, en_p);
+                    else wave_demod_symbol<SF, 1>(P, WT, X + wpos, wb, wf, en_p);
+                    if (wb == kPoisonBin) wf = kFinePoison; // a sample of exactly zero in the window: the replay asks for a ZM round
+                }
                 }
                 if ((threadIdx.x & 63u) == 0u) { ws.wres[wave][0] = (int32_t)wb; ws.wres[wave][1] = wf; ws.wres[wave][2] = __builtin_bit_cast(int32_t, we); ws.wres[wave][3] = wvalid ? 1 : 0; }
                 __syncthreads();
@@ -1691,7 +1700,6 @@ __global__ __launch_bounds__(W3Geom<10>::T, W3Geom<10>::T512 ? 2 : 4) void walke
 __global__ __launch_bounds__(W3Geom<11>::T, W3Geom<11>::T512 ? 2 : 4) void walker3_kernel_sf11(DevParams P, LaunchCfg C) { walker3_body<11, false>(P, C); }
 __global__ __launch_bounds__(W3Geom<12>::T, W3Geom<12>::T512 ? 2 : 4) void walker3_kernel_sf12(DevParams P, LaunchCfg C) { walker3_body<12, false>(P, C); }
 // half-size workgroups, two per CU (W3Geom HV = 1): launched when a pass holds more jobs than full-size workgroups fit at once
-__global__ __launch_bounds__((W3Geom<9, 1>::T), 2) void walker3_kernel_sf9_half(DevParams P, LaunchCfg C) { walker3_body<9, false, 1>(P, C); }
 __global__ __launch_bounds__((W3Geom<10, 1>::T), 2) void walker3_kernel_sf10_half(DevParams P, LaunchCfg C) { walker3_body<10, false, 1>(P, C); }
 __global__ __launch_bounds__((W3Geom<9, 1>::T), 2) void walker3_kernel_sf9_grad_half(DevParams P, LaunchCfg C) { walker3_body<9, true, 1>(P, C); }
 __global__ __launch_bounds__((W3Geom<10, 1>::T), 2) void walker3_kernel_sf10_grad_half(DevParams P, LaunchCfg C) { walker3_body<10, true, 1>(P, C); }
@@ -1830,7 +1838,8 @@ static void build_w3_tables_sf(float2 *tw, float2 *ctab)
 {
     using G = W3Geom<SF, HV>;
     constexpr int N = G::N, SPS = G::SPS, T = G::VT;
-    for (int t = 0; t < G::NTW; t++) {
+    constexpr int NTWB = G::WFFT ? N : G::NTW; // (SF9: the full-size workgroup keeps none in LDS, the half-size one all N)
+    for (int t = 0; t < NTWB; t++) {
         const double a = -2.0 * M_PI * (double)t / (double)N;
         tw[t] = make_float2((float)std::cos(a), (float)std::sin(a));
     }
@@ -1858,7 +1867,7 @@ static void build_w3_tables_sf(float2 *tw, float2 *ctab)
 }
 
 bool walker3_covers(uint32_t sf) { return sf >= 9u && sf <= 12u; }
-uint32_t w3_tw_entries(uint32_t sf) { return sf == 9u ? W3Geom<9>::NTW : sf == 10u ? W3Geom<10>::NTW : sf == 11u ? W3Geom<11>::NTW : sf == 12u ? W3Geom<12>::NTW : 0u; }
+uint32_t w3_tw_entries(uint32_t sf) { return sf == 9u ? W3Geom<9, 1>::NTW : sf == 10u ? W3Geom<10>::NTW : sf == 11u ? W3Geom<11>::NTW : sf == 12u ? W3Geom<12>::NTW : 0u; }
 void build_w3_tables(uint32_t sf, float2 *tw, float2 *ctab /* sps entries */)
 {
     if (sf == 9u) build_w3_tables_sf<9>(tw, ctab);

@@ -1,12 +1,14 @@
-// lora_wave_demod.inc.hip -- one wavefront demodulates one symbol (decimation 8: SF7 / SF8 at 1 Msps / 125 kHz).
+// lora_wave_demod.inc.hip -- one wavefront demodulates one symbol (decimation 8: SF7 / SF8 / SF9 at 1 Msps / 125 kHz).
 // Included by lora_kernels.hip.
 //
 // get_shift_fft (lib/decoder_impl.cc:430-464) + the per-symbol fine_sync (:300-338, :514-518) for the
 // decode rounds of walker2 and for lora_hip_demod_symbols_device.  Written for the VALU, which is what
 // bounds the walker: complex arithmetic in packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, two
 // flops per lane per instruction), lane exchanges as single DPP moves (bound_ctrl: no `old` operand to
-// materialise) or v_permlane{16,32}_swap, every twiddle a 16-byte LDS entry (w.x, w.y, -w.y, w.x) so that a
-// complex multiply is two packed instructions: a*w = a.xx*(w.x,w.y) + a.yy*(-w.y,w.x).
+// materialise) or v_permlane{16,32}_swap, every twiddle an 8-byte LDS entry (w.x, w.y) and a complex multiply
+// two packed instructions: a.yy * (-w.y, w.x) through op_sel / neg_lo, then a.xx * (w.x, w.y) + that (cmul2).
+// (Until round 5 the entries were 16 bytes - (w.x, w.y, -w.y, w.x) - for the same two instructions from vector
+// code; at half the size the SF8 walker's workgroup fits a CU twice and SF9 fits at all: profiles/r05_ab_sf9_wave_fft.txt.)
 //
 // Work split.  sps = 8 N samples, lane = 8 lq + r.  A lane owns the samples n = 64 j + lane, j < J = N / 8:
 // every load instruction covers 512 contiguous bytes (the earlier layout with the 8 lanes of a polyphase
@@ -41,7 +43,6 @@
 #endif
 
 typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int kDppQuadXor1 = 0xB1, kDppQuadXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140, kDppRor8 = 0x128,
               kDppBcast15 = 0x142, kDppBcast31 = 0x143,
@@ -103,8 +104,16 @@ __device__ __forceinline__ int wave_min_u(int v)
 
 // a * w with the twiddle given as (w, wr = (-w.y, w.x)): two packed instructions
 __device__ __forceinline__ v2f cmulw(v2f a, v2f w, v2f wr) { return __builtin_elementwise_fma(a.xx, w, a.yy * wr); }
-__device__ __forceinline__ v2f cmulw(v2f a, v4f t) { return cmulw(a, t.xy, t.zw); }
 
+// a * w in two packed instructions: t = a.yy * (-w.y, w.x) through op_sel / neg_lo, then a.xx * w + t (written out: from
+// vector code the compiler builds (-w.y, w.x) with a v_xor and a v_mov first)
+__device__ __forceinline__ v2f cmul2(v2f a, v2f w)
+{
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
 // in-register radix-2 DIF, natural input order, bit-reversed output
 template <int J>
 __device__ __forceinline__ void fft_inlane_dif_pk(v2f (&a)[J])
@@ -129,16 +138,7 @@ __device__ __forceinline__ void fft_inlane_dif_pk(v2f (&a)[J])
     }
 }
 
-// one DIF butterfly stage across lanes: a' = (sg * a + partner) * w   (upper lane: sg = +1, w = 1; lower: sg = -1)
-template <int CTRL, int J>
-__device__ __forceinline__ void xstage_pk(v2f (&a)[J], v2f sg, v4f w)
-{
-#pragma unroll
-    for (int m = 0; m < J; m++) {
-        const v2f p = dpp2<CTRL>(a[m]);
-        a[m] = cmulw(__builtin_elementwise_fma(sg, a[m], p), w);
-    }
-}
+// the last DIF butterfly stage across lanes: a' = sg * a + partner   (upper lane: sg = +1; lower: sg = -1)
 template <int CTRL, int J>
 __device__ __forceinline__ void xstage_last_pk(v2f (&a)[J], v2f sg)
 {
@@ -148,17 +148,17 @@ __device__ __forceinline__ void xstage_last_pk(v2f (&a)[J], v2f sg)
 
 // LDS-resident tables of the wave demodulator (built by build_wave_tables below, copied in by the kernels)
 struct WaveTabs {
-    const v4f   *down4; // [sps]      d_downchirp[n] as (d, i d)
-    const v4f   *twn4;  // [J][8]     W_N^{lq * bitrev(m)}
-    const v4f   *tws4;  // [J][64]    polyphase twiddle of register m on each lane (incl. the N/2 fold)
-    const v4f   *xst4;  // [2][64]    lane twiddles of the first two cross-lane stages
+    const v2f   *down;  // [sps]      d_downchirp[n]
+    const v2f   *twn;   // [J][8]     W_N^{lq * bitrev(m)}
+    const v2f   *tws;   // [J][64]    polyphase twiddle of register m on each lane (incl. the N/2 fold)
+    const v2f   *xst;   // [2][64]    lane twiddles of the first two cross-lane stages
     const float *v;     // d_upchirp_ifreq_v (+ guard)
 };
 
 template <int SF> struct WaveGeom {
     static constexpr int N = 1 << SF, J = N / 8, SPS = 8 * N, LOGJ = ilog2(J);
-    static constexpr uint32_t n_down4 = SPS, n_twn4 = J * 8, n_tws4 = J * 64, n_xst4 = 2 * 64;
-    static constexpr uint32_t n_v4f = n_down4 + n_twn4 + n_tws4 + n_xst4; // v4f entries of the packed table block
+    static constexpr uint32_t n_down = SPS, n_twn = J * 8, n_tws = J * 64, n_xst = 2 * 64;
+    static constexpr uint32_t n_ent = n_down + n_twn + n_tws + n_xst; // 8-byte entries of the packed table block
 };
 
 // Bin held by register g of `lane` after the cross-lane FFT (and, with g the surviving register, after the
@@ -336,14 +336,14 @@ __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const Wave
     }
     LORA_WSTAMP(1);
 #pragma unroll
-    for (int j = 0; j < J; j++) a[j] = cmulw(a[j], T.down4[j * 64 + nl]); // dechirp (:437)
+    for (int j = 0; j < J; j++) a[j] = cmul2(a[j], T.down[j * 64 + nl]); // dechirp (:437)
     fft_inlane_dif_pk<J>(a);
     LORA_WSTAMP(2);
 #pragma unroll
-    for (int m = 1; m < J; m++) a[m] = cmulw(a[m], T.twn4[m * 8 + lq]); // W_N^{lq k1}
+    for (int m = 1; m < J; m++) a[m] = cmul2(a[m], T.twn[m * 8 + lq]); // W_N^{lq k1}
     LORA_WSTAMP(3);
     { // 8-point DIF over lq
-        const v4f w1 = T.xst4[lane], w2 = T.xst4[64 + lane]; // W_8^{lq & 3}, W_4^{lq & 1}: the same on both lanes of a pair
+        const v2f w1 = T.xst[lane], w2 = T.xst[64 + lane]; // W_8^{lq & 3}, W_4^{lq & 1}: the same on both lanes of a pair
 #pragma unroll
         for (int i = 0; i < J / 2; i++) { // lq bit 2 = lane bit 5
             const float dx = a[i].x, dy = a[i].y, sx = a[i + J / 2].x, sy = a[i + J / 2].y;
@@ -353,7 +353,7 @@ __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const Wave
             const v2f lo = (v2f){__builtin_bit_cast(float, x0), __builtin_bit_cast(float, y0)};
             const v2f hi = (v2f){__builtin_bit_cast(float, x1), __builtin_bit_cast(float, y1)};
             a[i] = lo + hi;
-            a[i + J / 2] = cmulw(lo - hi, w1);
+            a[i + J / 2] = cmul2(lo - hi, w1);
         }
 #pragma unroll
         for (int h = 0; h < 2; h++)
@@ -367,14 +367,14 @@ __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const Wave
                 const v2f lo = (v2f){__builtin_bit_cast(float, x0), __builtin_bit_cast(float, y0)};
                 const v2f hi = (v2f){__builtin_bit_cast(float, x1), __builtin_bit_cast(float, y1)};
                 a[g] = lo + hi;
-                a[g + J / 4] = cmulw(lo - hi, w2);
+                a[g + J / 4] = cmul2(lo - hi, w2);
             }
         const v2f sg3 = (lane & 8) ? (v2f){-1.f, -1.f} : (v2f){1.f, 1.f}; // lq bit 0 = lane bit 3
         xstage_last_pk<kDppRor8, J>(a, sg3);
     }
     LORA_WSTAMP(4);
 #pragma unroll
-    for (int m = 0; m < J; m++) a[m] = cmulw(a[m], T.tws4[m * 64 + lane]); // W_sps^{k r} (+ fold)
+    for (int m = 0; m < J; m++) a[m] = cmul2(a[m], T.tws[m * 64 + lane]); // W_sps^{k r} (+ fold)
     // reduce-scatter over r = lane bits 2, 1, 0: lanes with the bit clear keep the first half of the registers
     // (Measured and dropped: the same steps as v_add_f32 with a DPP operand written out in asm - fewer issue slots on paper,
     // 13 % slower in the walker: the volatile sequence no longer interleaves with the table loads around it.)
@@ -675,31 +675,37 @@ __device__ __forceinline__ void wave_demod_symbol_grad(const DevParams &P, const
     fine_out = -lag;
 }
 
-// copies the packed table block (down4 | twn4 | tws4 | xst4) and the ifreq template into LDS; all threads of the block
+// copies the packed table block (down | twn | tws | xst) and the ifreq template into LDS; all threads of the block; the caller synchronises
+template <int SF> constexpr uint32_t kWaveLdsBytes = WaveGeom<SF>::n_ent * 8u + ((3u * WaveGeom<SF>::SPS + 40u + 3u) & ~3u) * 4u; // [tables | ifreq template]
 template <int SF>
-__device__ __forceinline__ WaveTabs wave_tabs_to_lds(const DevParams &P, v4f *lds4, float *lds_v, uint32_t nthreads)
+__device__ __forceinline__ WaveTabs wave_tabs_to_lds(const DevParams &P, v2f *l2, float *lv, uint32_t nthreads)
 {
     using G = WaveGeom<SF>;
-    const v4f *__restrict__ src = reinterpret_cast<const v4f *>(P.wave_tabs);
-    for (uint32_t i = threadIdx.x; i < G::n_v4f; i += nthreads) lds4[i] = src[i];
-    for (uint32_t i = threadIdx.x; i < 3u * G::SPS + 40u; i += nthreads) lds_v[i] = P.up_ifreq_v[i];
-    WaveTabs T;
-    T.down4 = lds4; T.twn4 = lds4 + G::n_down4; T.tws4 = T.twn4 + G::n_twn4; T.xst4 = T.tws4 + G::n_tws4; T.v = lds_v;
+    const v2f *__restrict__ src = reinterpret_cast<const v2f *>(P.wave_tabs);
+    for (uint32_t i = threadIdx.x; i < G::n_ent; i += nthreads) l2[i] = src[i];
+    for (uint32_t i = threadIdx.x; i < 3u * G::SPS + 40u; i += nthreads) lv[i] = P.up_ifreq_v[i];
+    WaveTabs T{};
+    T.down = l2; T.twn = l2 + G::n_down; T.tws = T.twn + G::n_twn; T.xst = T.tws + G::n_tws; T.v = lv;
     return T;
+}
+template <int SF>
+__device__ __forceinline__ WaveTabs wave_tabs_to_lds(const DevParams &P, unsigned char *lds, uint32_t nthreads)
+{ // kWaveLdsBytes<SF> bytes
+    v2f *l2 = reinterpret_cast<v2f *>(lds);
+    return wave_tabs_to_lds<SF>(P, l2, reinterpret_cast<float *>(l2 + WaveGeom<SF>::n_ent), nthreads);
 }
 
 // host side: the table block in the layout above, from the handle's downchirp
-static void build_wave_tables_host(uint32_t sf, const float2 *down, float *out /* 4 * n_v4f floats */)
+static void build_wave_tables_host(uint32_t sf, const float2 *down, float *out /* 2 * n_ent floats */)
 {
     const int N = 1 << sf, J = N / 8, SPS = 8 * N;
     int logj = 0;
     while ((1 << logj) < J) logj++;
     auto put = [&](size_t idx, double re, double im) {
-        const float c = (float)re, s = (float)im;
-        out[4 * idx + 0] = c; out[4 * idx + 1] = s; out[4 * idx + 2] = -s; out[4 * idx + 3] = c;
+        out[2 * idx + 0] = (float)re; out[2 * idx + 1] = (float)im;
     };
     size_t o = 0;
-    for (int n = 0; n < SPS; n++) { out[4 * o + 0] = down[n].x; out[4 * o + 1] = down[n].y; out[4 * o + 2] = -down[n].y; out[4 * o + 3] = down[n].x; o++; }
+    for (int n = 0; n < SPS; n++) { out[2 * o + 0] = down[n].x; out[2 * o + 1] = down[n].y; o++; }
     for (int m = 0; m < J; m++)
         for (int lq = 0; lq < 8; lq++) {
             const int k1 = brev_bits(m, logj);
@@ -736,31 +742,10 @@ static void build_wave_tables_host(uint32_t sf, const float2 *down, float *out /
     }
 }
 
-uint32_t wave_tables_floats(uint32_t sf) { return sf == 7u ? 4u * WaveGeom<7>::n_v4f : (sf == 8u ? 4u * WaveGeom<8>::n_v4f : 0u); }
+uint32_t wave_tables_floats(uint32_t sf) { return sf == 7u ? 2u * WaveGeom<7>::n_ent : (sf == 8u ? 2u * WaveGeom<8>::n_ent : (sf == 9u ? 2u * WaveGeom<9>::n_ent : 0u)); }
 void build_wave_tables(uint32_t sf, const float2 *down, float *out) { build_wave_tables_host(sf, down, out); }
 
-// ---- symbol-level kernel: one wavefront per symbol, for lora_hip_demod_symbols_device ------------------
-template <int SF>
-__global__ __launch_bounds__(256) void demod_symbols_wave_kernel(DevParams P, const float2 *iq, const int64_t *offsets, uint32_t n,
-                                                                 uint32_t *bins, int32_t *fine)
-{
-    using G = WaveGeom<SF>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    v4f *lds4 = reinterpret_cast<v4f *>(smem);
-    float *lds_v = reinterpret_cast<float *>(lds4 + G::n_v4f);
-    const WaveTabs T = wave_tabs_to_lds<SF>(P, lds4, lds_v, 256u);
-    __syncthreads();
-    const uint32_t wave = threadIdx.x >> 6;
-    v2f *zs = reinterpret_cast<v2f *>(lds_v + ((3u * G::SPS + 40u + 3u) & ~3u)) + wave * kWaveFfsEntries<SF>;
-    for (uint32_t s = blockIdx.x * 4u + wave; s < n; s += gridDim.x * 4u) {
-        uint32_t b;
-        int32_t fs;
-        wave_demod_symbol<SF, kWaveFmode<SF>>(P, T, iq + offsets[s], b, fs, nullptr, zs);
-        if (b == kPoisonBin) wave_demod_symbol<SF, kWaveFmode<SF>, true>(P, T, iq + offsets[s], b, fs, nullptr, zs); // (uniform) a window with a sample of exactly zero
-        if ((threadIdx.x & 63u) == 0u) { bins[s] = b; if (fine) fine[s] = fs; }
-    }
-}
-
+// ---- symbol-level kernels: one wavefront per symbol, for lora_hip_demod_symbols_device and the payload pass of a decoupled pass ------------------
 template <int SF>
 __global__ __launch_bounds__(256) void demod_symbols_wave_grad_kernel(DevParams P, const float2 *iq, const int64_t *offsets, uint32_t n, uint32_t *bins, int32_t *fine)
 {
@@ -780,9 +765,34 @@ __global__ __launch_bounds__(256) void demod_symbols_wave_grad_kernel(DevParams 
     }
 }
 
-static uint32_t wave_tabs_lds_bytes(uint32_t sf)
+// The FFT demodulators.  512-thread workgroups; OCC = wavefronts per SIMD the register budget is set for: SF7 6 (80 registers, three workgroups per CU),
+// SF8 4 (128, two per CU), SF9 2 (256: 64 samples per lane and fine_sync's 64 ifreq values beside them - a second read of the window instead costs 40 %,
+// 0.268 against 0.373 of HBM peak; the cooperative w3_demod_round it replaces: 0.207).  Same-box A/B of the geometries: profiles/r05_ab_sf9_wave_fft.txt.
+// second reads (DemodAlt): the wavefront whose symbol moved the symbol clock reads that symbol's successor again, that far on (as demod_symbols_w3_grad_kernel)
+template <int SF, int OCC>
+__global__ __launch_bounds__(512, OCC) void demod_symbols_wave_kernel(DevParams P, const float2 *iq, const int64_t *offsets, uint32_t n, uint32_t *bins, int32_t *fine, DemodAlt alt)
 {
-    const uint32_t sps = 8u << sf;
-    return wave_tables_floats(sf) * (uint32_t)sizeof(float) + ((3u * sps + 40u + 3u) & ~3u) * (uint32_t)sizeof(float) +
-           (((LORA_W2_FFS >> (sps == 1024u ? 0 : 1)) & 1) ? 4u * (sps / 4u + 4u) * (uint32_t)sizeof(float2) : 0u); // + demod_symbols_wave_kernel's four closed-form scratch areas
+    constexpr int SPS = 8 << SF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const WaveTabs T = wave_tabs_to_lds<SF>(P, smem, 512u);
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t s = blockIdx.x * 8u + wave; s < n; s += gridDim.x * 8u) {
+        const int64_t o0 = offsets[s];
+        uint32_t b;
+        int32_t fs;
+        wave_demod_symbol<SF, 1>(P, T, iq + o0, b, fs);
+        if (b == kPoisonBin) wave_demod_symbol<SF, 1, true>(P, T, iq + o0, b, fs); // (uniform) a window with a sample of exactly zero
+        if (lane == 0u) { bins[s] = b; if (fine) fine[s] = fs; }
+        if (alt.shift && fs != 0 && s + 1u < n) {
+            const int64_t o1 = offsets[s + 1u], a = o1 + (int64_t)fs;
+            if (o1 == o0 + (int64_t)SPS && a >= 0 && a <= alt.max_start) {
+                uint32_t b2;
+                int32_t f2;
+                wave_demod_symbol<SF, 1>(P, T, iq + a, b2, f2);
+                if (b2 == kPoisonBin) wave_demod_symbol<SF, 1, true>(P, T, iq + a, b2, f2);
+                if (lane == 0u) { alt.bins[s + 1u] = b2; alt.fine[s + 1u] = f2; alt.shift[s + 1u] = fs; }
+            }
+        }
+    }
 }

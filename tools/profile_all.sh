@@ -12,7 +12,7 @@ PROFILE_STEPS=8 tools/profile_round.sh sf9 --config 3 --sf 9
 PROFILE_STEPS=8 tools/profile_round.sh sf10 --config 3 --sf 10
 PROFILE_STEPS=6 tools/profile_round.sh sf11 --config 3 --sf 11
 PROFILE_STEPS=4 tools/profile_round.sh sf12 --config 3 --sf 12
-PROFILE_STEPS=6 tools/profile_round.sh sf9_1024 --config 3 --sf 9 --packets 1024   # more jobs than CUs: the half-size workgroups (walker3_kernel_sf9_half)
+PROFILE_STEPS=6 tools/profile_round.sh sf9_1024 --config 3 --sf 9 --packets 1024   # more jobs than CUs (four packets per workgroup)
 # the reference's shipped demodulator (gradient, decoder_impl.cc:499) on the same workloads: its own kernels
 tools/profile_round.sh sf7_grad --demod 0
 PROFILE_STEPS=8 tools/profile_round.sh sf9_grad --config 3 --sf 9 --demod 0
@@ -24,10 +24,12 @@ python bench.py --config 4 --steps 30 --warmup 5 2>/dev/null | tail -1 > gpurun_
 python bench.py --config 4 --seconds 8 --steps 30 --warmup 5 2>/dev/null | tail -1 > gpurun_out/cfg4_8s_line.json
 python bench.py --config 4 --seconds 2 --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/cfg4_2s_line.json                               # few jobs for the device: a decoupled pass (header-only jobs + payload pass)
 LORA_HIP_DECOUPLED=0 python bench.py --config 4 --seconds 2 --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/cfg4_2s_ordinary_line.json   # ... and the same pass by the complete kernels
-PROFILE_STEPS=20 tools/profile_round.sh cfg4_2s --config 4 --seconds 2   # kernel stats of the decoupled pass: walker3_kernel_sf9_skip, demod_symbols_w3_kernel, payload_chain_kernel
+PROFILE_STEPS=20 tools/profile_round.sh cfg4_2s --config 4 --seconds 2   # kernel stats of the decoupled pass: walker3_kernel_sf9_skip, demod_symbols_wave_kernel<9, 2>, payload_chain_kernel
 python bench.py --demod 0 2>/dev/null | tail -1 > gpurun_out/default_grad_line.json
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/torchrun1_line.json
 python bench.py --streams 1 --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/streams1_line.json
+python bench.py --config 3 --sf 7 --packets 256 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/sf7_256_line.json   # config 3's own cell size at SF7 / SF8: no more jobs than CUs (the plan for one workgroup per CU; SF8: walker2_kernel_sf8_wide)
+python bench.py --config 3 --sf 8 --packets 256 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/sf8_256_line.json
 tools/pmc_walker.sh sq_sf7
 tools/pmc_walker.sh sq_sf9 --config 3 --sf 9
 tools/pmc_walker.sh sq_sf12 --config 3 --sf 12
