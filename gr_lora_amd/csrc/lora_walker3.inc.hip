@@ -1,5 +1,9 @@
-// lora_walker3.inc.hip -- the SF9 .. SF12 walker (decimation 8, FFT demodulators): one workgroup demodulates one
-// symbol window at a time, cooperatively.  Included by lora_kernels.hip.
+// lora_walker3.inc.hip -- the SF9 .. SF12 walker (decimation 8): one workgroup per job; the FFT demodulators of SF10 .. SF12 demodulate
+// a symbol window cooperatively (below), SF9's and every gradient demodulator one window per WAVEFRONT.  Included by lora_kernels.hip.
+//
+// SF9 (round 5): a 4096-sample window is 64 samples per lane - wave_demod_symbol<9> of lora_wave_demod.inc.hip holds it in registers, and a
+// decode round is eight independent wavefronts (W3Geom::WFFT: the LDS array then holds 16 KB of acquisition scratch and the wave
+// demodulator's tables).  What follows describes the cooperative form, which SF9 keeps only for its acquisition rounds' geometry.
 //
 // A symbol is 8 N samples = 32 .. 256 KB: too much for one wavefront's registers (the SF7 / SF8 scheme), and the
 // generic kernel's radix-2 stages in LDS (one barrier per stage, twiddles and tables from global memory) leave the

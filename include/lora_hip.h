@@ -50,7 +50,7 @@ typedef enum lora_hip_demod {
                                       within rounding of that maximum is re-evaluated with the reference's own arithmetic (glibc's atan2f, the unwrap of
                                       :231-240, one sequential float sum per shift as volk_32f_x2_dot_prod_32f_generic adds) and the FIRST maximum of those
                                       sums wins, as in :399-407 - on a clean preamble two adjacent shifts tie to ~6 / sps^2 of the peak and the float
-                                      arithmetic alone decides.  Costs 6-8 % of a pass at every spreading factor (measured: profiles/r04_default_fast_sync_bench_line.json,
+                                      arithmetic alone decides.  Costs 6-8 % of a pass at every spreading factor (measured: profiles/r05_default_fast_sync_bench_line.json,
                                       profiles/r05_ab_acquisition_experiments.txt); FFT demodulators publish the same bytes either way.
                                       WHAT "the reference's own arithmetic" IS PINNED TO: atan2f as glibc 2.35 computes it (fdlibm's float algorithm) and VOLK's
                                       GENERIC dot product (one sequential float sum) - the build oracle/ref_build compiles and tests/test_ref_pin.py holds.  A
