@@ -29,7 +29,7 @@ struct SimEnv {
     int decoupled_mode = 0;  // 1: every pass decoupled (header-only segment jobs + payload pass)
     bool skip = false;
     uint32_t n_payload = 0, n_rerun = 0;
-    bool decoupled(size_t n) const { return decoupled_mode == 1 || (decoupled_mode == 2 && n <= slots); }
+    bool decoupled(size_t n) const { return decoupled_mode == 1 || (decoupled_mode == 2 && n <= (two_per_cu ? slots / 2u : slots)); }
     void set_skip_payload(bool on) { skip = on; }
     uint32_t n_moved = 0, n_pending = 0;
     void count_payload(uint32_t p, uint32_t m, uint32_t r) { n_payload += p; n_moved += m; n_rerun += r; }
@@ -64,7 +64,8 @@ struct SimEnv {
     uint32_t ctor_cr() const { return ctor_cr_; }
     uint32_t segment_symbols() const { return seg_symbols; }
     uint32_t resident_slots() const { return slots; }
-    uint32_t resident_slots_alt() const { return 0; }
+    uint32_t resident_slots_alt() const { return two_per_cu ? slots / 2u : 0u; } // (the device: walker_resident_slots_full - one workgroup per CU where the kernel fits a CU twice)
+    bool two_per_cu = false;
     bool tracing() const { return false; }
     bool implicit() const { return false; }
     bool quiet_edges(const std::vector<StreamDesc> &streams, std::vector<std::vector<int64_t>> &edges)
@@ -166,6 +167,7 @@ extern "C" int stitch_sim_decode(const float *iq, size_t n_items, int sf, int ct
     env.burst_plan = (tail_probes & 2) != 0;
     env.early = (tail_probes & 4) != 0;
     env.decoupled_mode = (tail_probes & 8) ? 1 : (tail_probes & 16) ? 2 : 0; // 2: the device's per-pass rule (the jobs fit the device at once)
+    env.two_per_cu = (tail_probes & 32) != 0;
     env.payload_force_rerun = (uint32_t)(tail_probes >> 8) & 0xffu;
     std::vector<StreamDesc> sds(1);
     sds[0].off = 0; sds[0].len = n_items; sds[0].id = 0; sds[0].cr_in = (uint32_t)ctor_cr; sds[0].abs_base = 0;

@@ -28,13 +28,13 @@ def sim(oracle_mod):
     L.stitch_sim_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int,
                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
 
-    def run(iq, sf, ctor_cr=4, demod=2, reduced=False, seg=0, slots=512, tails=True, plan=False, early=False, decoupled=False, force_rerun=0, auto=False):
+    def run(iq, sf, ctor_cr=4, demod=2, reduced=False, seg=0, slots=512, tails=True, plan=False, early=False, decoupled=False, force_rerun=0, auto=False, two_per_cu=False):
         a = np.ascontiguousarray(iq, dtype=np.complex64)
         out = np.zeros(1 << 20, dtype=np.uint8)
         lens = np.zeros(4096, dtype=np.int32)
         hp = np.zeros(4096, dtype=np.int64)
         st = np.zeros(12, dtype=np.uint32)
-        mode = int(tails) | (2 if plan else 0) | (4 if early else 0) | (8 if decoupled else 0) | (16 if auto else 0) | ((force_rerun & 0xff) << 8)
+        mode = int(tails) | (2 if plan else 0) | (4 if early else 0) | (8 if decoupled else 0) | (16 if auto else 0) | (32 if two_per_cu else 0) | ((force_rerun & 0xff) << 8)
         n = L.stitch_sim_decode(a.ctypes.data, a.size, sf, ctor_cr, 1, int(reduced), demod, seg, slots, mode, out.ctypes.data, out.size,
                                 lens.ctypes.data, hp.ctypes.data, 4096, st.ctypes.data)
         assert n >= 0, n
@@ -94,6 +94,29 @@ def test_burst_aware_plan_equals_serial(sim, oracle_mod, slots, snr_db):
         print(slots, stats)
         if stats["planned"]:
             assert stats["jobs"] <= slots and stats["slow"] == 0 and stats["probes"] == 0
+
+
+@pytest.mark.parametrize("slots,auto", [(100, False), (100, True), (200, True), (60, True)])
+def test_fewer_bursts_than_slots_is_planned_for_one_workgroup_per_cu(sim, oracle_mod, slots, auto):
+    """A kernel that fits a CU twice reports twice the CUs as slots; a pass with fewer bursts than that, but at least one per CU, is planned for
+    one workgroup per CU (resident_slots_alt = walker_resident_slots_full on the device: whole packets per job, no fixed grid, no probes) and is
+    decoupled only with no more jobs than CUs (round 5: config 3's 256 packets per cell at SF7 / SF8).  Same frames as the serial decoder."""
+    cfg = synth.TxConfig(sf=7, cr=4)
+    rng = np.random.default_rng(5100 + slots)
+    payloads = [bytes(rng.integers(0, 256, int(rng.integers(4, 40)), dtype=np.uint8)) for _ in range(64)]
+    st = synth.build_stream(payloads, cfg, rng=rng, gap_symbols=(2.0, 6.0))
+    want, wpos = _serial(oracle_mod, st.iq, 7)
+    assert len(want) == len(payloads)
+    got, gpos, stats = sim(st.iq, 7, seg=0, slots=slots, plan=True, auto=auto, two_per_cu=True)
+    assert got == want and gpos == wpos
+    cap = slots if len(payloads) >= slots else slots // 2   # bursts for every slot: the ordinary plan; at least one per CU: the plan for slots / 2 jobs
+    if len(payloads) >= slots // 2 and stats["payload"] == 0:
+        assert stats["planned"] == 1 and stats["jobs"] <= cap + 1 and stats["slow"] == 0 and stats["probes"] == 0, stats
+    if auto and len(payloads) + 1 <= slots // 2:
+        assert stats["payload"] > 0, stats    # no more jobs than CUs: a decoupled pass
+    base, _, bstats = sim(st.iq, 7, seg=0, slots=slots, plan=True, auto=auto)
+    assert base == want
+    print(slots, auto, stats, bstats)
 
 
 def test_fast_path_dominates_on_regular_traffic(sim, oracle_mod):
