@@ -3,7 +3,7 @@
 //
 // Same state machine as walker_body (decoder_impl::work, lib/decoder_impl.cc:740-903), organised in
 // ROUNDS: WAVES wavefronts = WAVES-1 workers + 1 control wavefront (512 threads: 7 workers; two workgroups per CU
-// at SF7.  A 16-wavefront workgroup with 15 workers was built and measured 30 % slower).  In DETECT, FIND_SFD and DECODE_*
+// at SF7 and, since round 5, at SF8.  A 16-wavefront workgroup with 15 workers was built and measured 30 % slower).  In DETECT, FIND_SFD and DECODE_*
 // every worker evaluates upcoming symbol windows at pos + w*sps (zero drift assumed: one per round in DECODE_*, two in FIND_SFD,
 // one or four in DETECT); the control
 // thread then replays the reference's per-call logic over the results in order and stops at the first

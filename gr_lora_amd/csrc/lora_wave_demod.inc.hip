@@ -25,7 +25,7 @@
 //      part of the table) and a reduce-scatter over r = lane bits 2 (row_shl/shr:4 with bank masks), 1, 0
 //   4. |X|^2 arg-max, first maximum in bin order (:454-463)
 //   5. fine_sync over lags -1, 0, +1 against the ifreq template; the window's instantaneous frequency is
-//      computed from the registers that were loaded for the dechirp (EARLY_F: SF7, and SF8 at its 256-register budget) or
+//      computed from the registers that were loaded for the dechirp (EARLY_F: every shipped instantiation - SF7, SF8, SF9) or
 //      from a second, cache-hot read after the FFT (an SF8 build held to 128 registers, where 32 more live ones would spill).
 //
 // Instruction costs this is written against (tools/ubench_valu.hip, cycles per wave64 instruction per SIMD):
@@ -39,7 +39,7 @@
 #endif
 #ifndef LORA_W2_EARLY_F_SF8
 #define LORA_W2_EARLY_F_SF8 1 // SF8: fine_sync's ifreq from the registers loaded for the dechirp (as SF7) instead of a second, cache-hot read:
-                              // at the kernel's 256-register budget it fits without a spill (227 VGPRs) and measures +6.5 %
+                              // at a 256-register budget it fits without a spill (227 VGPRs) and measured +6.5 %; at the 128 registers of the two-per-CU walker (round 5) it spills and still wins
 #endif
 
 typedef float v2f __attribute__((ext_vector_type(2)));
