@@ -161,6 +161,28 @@ def test_config4_64_channels(oracle_mod):
     assert [[f[15:] for f in g[0]] for g in got] == expect
 
 
+def test_sf8_two_builds_of_one_body_by_job_count():
+    """walker2 at SF8 (round 5): two workgroups per CU at 128 registers when a launch has more jobs than CUs, the 256-register build of the same body
+    (walker2_kernel_sf8_wide) when every job has a CU to itself - config 3's own 256 packets per cell, planned for one workgroup per CU.  Same frames;
+    SF7 has one build and the same plan."""
+    from gr_lora_amd import capi
+    for sf, packets, want in ((8, 1024, "walker2_kernel_sf8"), (8, 256, "walker2_kernel_sf8_wide"), (7, 256, "walker2_kernel_sf7")):
+        cfg, iq, offs, lens, expect = bench.make_workload(sf, 4, packets, 32, 8, seed=100 * sf + 4)
+        dev = _dev(iq)
+        h = capi.Handle(demod=2, sf=sf, cr=4)
+        h.decode_device(dev.data_ptr(), iq.size, offs, lens, 0)
+        by = {}
+        for g, i in h.drain():
+            by.setdefault(i.stream, []).append(g[15:])
+        name, (burst_aware, segments), pp = h.kernel_name(), h.plan(), h.payload_pass()
+        h.close()
+        assert name == want, (sf, packets, name)
+        assert [by.get(s, []) for s in range(len(offs))] == expect, (sf, packets)
+        assert burst_aware and segments <= 512 and pp["packets"] == 0, (sf, packets, burst_aware, segments, pp)   # whole packets per job, not the fixed grid; not a decoupled pass
+        if packets == 256:
+            assert segments <= 256 + 8, (sf, segments)   # one workgroup per CU
+
+
 @pytest.mark.parametrize("sf,demod", [(9, 2), (9, 0), (10, 2)])
 def test_half_size_workgroups_with_more_jobs_than_cus(sf, demod):
     """walker3 SF9 (gradient) / SF10 exist in two workgroup sizes (W3Geom HV): a pass with more jobs than full-size workgroups fit at once - 1024 packets:
