@@ -302,9 +302,9 @@ lora_hip_status build_tables(lora_hip_decoder *h)
         // guard tail for bin_idx = N-1 (reference indexes past the vector there, :301,:310)
         for (size_t i = 3u * (size_t)sps; i < up3.size(); i++) up3[i] = up3[3u * (size_t)sps - 1u];
     }
-    { // closed-form fine_sync of the wave demodulator (DevParams::ffs_*): slope, step and noise bound of d_upchirp_ifreq_v as built above
+    { // closed-form fine_sync of the wave demodulators (DevParams::ffs_*): slope, step and noise bound of d_upchirp_ifreq_v as built above
         P.ffs_on = 0u; P.ffs_alpha = 0.0f; P.ffs_jump = 0.0f; P.ffs_tol = 0.0f;
-        if (D == 8u && (c.sf == 7u || c.sf == 8u) && !getenv("LORA_HIP_NO_FFS")) {
+        if (D == 8u && c.sf >= 7u && c.sf <= 12u && !getenv("LORA_HIP_NO_FFS")) {
             const size_t S = sps, lo = S + 7u, hi = 3u * S - 8u; // every dV index a lag difference can touch for bin_idx < N-1: [S+7, 3S-9]
             auto dV = [&](size_t m) { return (double)up3[m + 1u] - (double)up3[m]; };
             double sum = 0.0;
@@ -315,8 +315,17 @@ lora_hip_status build_tables(lora_hip_decoder *h)
             for (size_t m = lo; m < hi; m++) { const double e = (m == 2u * S - 1u) ? 0.0 : dV(m) - alpha; cs[m - lo + 1u] = cs[m - lo] + e * e; }
             double worst = 0.0;
             for (size_t o = lo; o + S <= hi; o++) worst = std::max(worst, cs[o + S - lo] - cs[o - lo]);
-            const double tol = 1.05 * M_PI * std::sqrt((double)S) * std::sqrt(worst) + 1.0e-4; // Cauchy-Schwarz with |ifreq| <= pi, + the evaluation's own rounding
-            if (ok && tol < 0.1) { P.ffs_on = 1u; P.ffs_alpha = (float)alpha; P.ffs_jump = (float)(dV(2u * S - 1u) - alpha); P.ffs_tol = (float)tol; }
+            // what the table's float noise e[] adds to a lag difference is sum_k ifreq[k] e[o + k].  SF7 / SF8: Cauchy-Schwarz with |ifreq| <= pi - a bound for
+            // ANY window.  SF9 and up: the kernel vouches only for windows whose every |ifreq[k]| stays below pi / 2 (SF9, SF10) or atan(1/2) (SF11, SF12;
+            // a clean chirp at decimation 8 stays below pi / 8): the same bound with that ceiling - and where even that exceeds what a decision has to spare
+            // (SF10 and up: the table's own rounding noise grows with the chirp's phase) twelve standard deviations of the sum under random signs of e[], which
+            // is what the model and the decision-flip sweeps hold to the oracle (tools/ffs_model.py, tools/decision_flip_sweep.py); + the evaluation's own rounding
+            const double enorm = std::sqrt(worst), fmax = c.sf >= 11u ? std::atan(0.5) : c.sf >= 9u ? M_PI / 2.0 : M_PI; // (kFfsClass, lora_wave_demod.inc.hip)
+            const double fnorm = c.sf >= 9u ? std::sqrt((double)S * fmax * fmax + 8.0 * M_PI * M_PI) : fmax * std::sqrt((double)S); // (the four products at either end of a window: any value)
+            double tol = 1.05 * fnorm * enorm + 1.0e-4;
+            if (c.sf >= 9u && tol > 0.15) tol = 12.0 * fmax * enorm + 1.0e-4;
+            if (ok && tol < 0.2) { P.ffs_on = 1u; P.ffs_alpha = (float)alpha; P.ffs_jump = (float)(dV(2u * S - 1u) - alpha); P.ffs_tol = (float)tol; }
+            if (getenv("LORA_HIP_DEBUG")) fprintf(stderr, "[lora_hip] closed-form fine_sync: SF%u alpha %.6g jump %.6g |e| %.4g tol %.4g -> %s\n", (unsigned)c.sf, alpha, dV(2u * S - 1u) - alpha, enorm, tol, P.ffs_on ? "on" : "off");
         }
     }
     { // chirp_avg and stddev of the ideal downchirp ifreq over sps-1 points (:287-289, :415-425)

@@ -519,7 +519,7 @@ __device__ LORA_W2_ZM_ATTR W2DemodZ w2_demod_zm(uint32_t enable_fine_sync, uint3
     Q.enable_fine_sync = enable_fine_sync; Q.demod_mode = demod_mode;
     W2DemodZ r{0u, 0, 0.0f};
     if constexpr (GRAD) wave_demod_symbol_grad<SF, true>(Q, T.v, x, want_energy, r.s, r.fine, r.en);
-    else wave_demod_symbol<SF, 0, true>(Q, T, x, r.s, r.fine, want_energy ? &r.en : nullptr, nullptr);
+    else wave_demod_symbol<SF, 0, true>(Q, T, x, r.s, r.fine, want_energy ? &r.en : nullptr);
     return r;
 }
 
@@ -557,10 +557,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     float *f2 = ALIAS ? reinterpret_cast<float *>(tab2) : lds0;
     double *pre = ALIAS ? reinterpret_cast<double *>(f2 + 2 * SPS)
                         : reinterpret_cast<double *>(tab2 + (GRAD ? 0u : WaveGeom<SF>::n_ent)); // SYNC: chunk prefix sums (2 x 256) + per-wavefront totals
-    static_assert(!ALIAS || (2u * SPS * 4u + (2u * 256u + 8u) * 8u <= WaveGeom<SF>::n_ent * 8u && kWaveFmode<SF> != 2), "SYNC's work areas fit the table block; no closed-form scratch in them");
-    // closed-form fine_sync (wave_demod_symbol FMODE 2): one scratch area per worker.  SYNC's two work areas (f2, pre) are idle in decode rounds
-    // and take the first workers; the others get an area behind `pre`.  (All seven behind `pre` made the SF7 workgroup 80.4 KB: one per CU.)
-    constexpr int kZsN = kWaveFfsEntries<SF>, kZsF2 = (2 * SPS * 4) / (kZsN * 8), kZsPre = ((2 * 256 + 8) * 8) / (kZsN * 8);
+    static_assert(!ALIAS || (2u * SPS * 4u + (2u * 256u + 8u) * 8u <= WaveGeom<SF>::n_ent * 8u), "SYNC's work areas fit the table block");
 
     const uint32_t jid = blockIdx.x;
     if (jid >= C.n_jobs) return;
@@ -572,9 +569,6 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     AttemptRec *recs = C.recs + (size_t)jid * C.recs_per_job;
     StepRec *trace = C.trace ? C.trace + (size_t)jid * C.trace_cap : nullptr;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    v2f *zs_mine = (wave < kZsF2)            ? reinterpret_cast<v2f *>(f2) + wave * kZsN
-                   : (wave < kZsF2 + kZsPre) ? reinterpret_cast<v2f *>(pre) + (wave - kZsF2) * kZsN
-                                              : reinterpret_cast<v2f *>(pre + 2 * 256 + 8) + (wave - kZsF2 - kZsPre) * kZsN;
     const bool is_ctl = wave == kW2Workers;                 // control wavefront
     const bool t0 = threadIdx.x == kW2Workers * 64;         // the control thread: sole owner of the decoder state S
     if (is_ctl) __builtin_amdgcn_s_setprio(2);              // its serial bookkeeping is on every round's critical path
@@ -955,7 +949,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                         ws = z.s; wfine = z.fine; wen = z.en;
                     } else
                     if constexpr (GRAD) wave_demod_symbol_grad<SF>(P, FT.v, X + dwpos, P.implicit != 0u, ws, wfine, wen); // ws = bin_idx itself; kPoisonBin: see W2Plan.zmode
-                    else wave_demod_symbol<SF, kWaveFmode<SF>>(P, FT, X + dwpos, ws, wfine, P.implicit != 0u ? &wen : nullptr, zs_mine);
+                    else wave_demod_symbol<SF, kWaveFmode<SF>>(P, FT, X + dwpos, ws, wfine, P.implicit != 0u ? &wen : nullptr);
                 }
                 if (lane == 0) { W.speci[plan_buf][widx][0] = dvalid ? (int32_t)ws : -1; W.speci[plan_buf][widx][1] = wfine; W.speci[plan_buf][widx][2] = __builtin_bit_cast(int32_t, wen); }
             }
@@ -1131,13 +1125,6 @@ __global__ __launch_bounds__(64 * kW2WavesSf8, LORA_W2_EU_GRAD_SF8) void walker2
 
 static uint32_t walker2_threads(uint32_t sf) { return 64u * (uint32_t)(sf == 7u ? kW2WavesSf7 : kW2WavesSf8); }
 
-static uint32_t w2_ffs_extra_workers(uint32_t sps)
-{
-    if (!((LORA_W2_FFS >> (sps == 1024u ? 0 : 1)) & 1)) return 0u;
-    const uint32_t zb = (sps / 4u + 4u) * (uint32_t)sizeof(float2), fit = (2u * sps * 4u) / zb + ((2u * 256u + 8u) * 8u) / zb, workers = (uint32_t)kW2MaxWaves - 1u;
-    return workers > fit ? workers - fit : 0u;
-}
-
 static uint32_t walker2_lds_bytes(uint32_t sf, bool grad = false)
 {
     const uint32_t sps = 8u << sf;
@@ -1145,6 +1132,5 @@ static uint32_t walker2_lds_bytes(uint32_t sf, bool grad = false)
     if (!grad && sf == 8u && kW2Alias<8>) // (SYNC's work areas inside the table block)
         return (uint32_t)((sizeof(W2Shared) + 15) & ~(size_t)15) + (nv + sps) * (uint32_t)sizeof(float) + wave_tables_floats(sf) * (uint32_t)sizeof(float);
     return (uint32_t)((sizeof(W2Shared) + 15) & ~(size_t)15) + (2u * sps + nv + sps) * (uint32_t)sizeof(float) +
-           (grad ? 0u : wave_tables_floats(sf) * (uint32_t)sizeof(float)) + (2u * 256u + 8u) * (uint32_t)sizeof(double) +
-           (grad ? 0u : w2_ffs_extra_workers(sps) * (sps / 4u + 4u) * (uint32_t)sizeof(float2)); // (+ closed-form fine_sync scratch of the workers that do not fit SYNC's idle areas)
+           (grad ? 0u : wave_tables_floats(sf) * (uint32_t)sizeof(float)) + (2u * 256u + 8u) * (uint32_t)sizeof(double);
 }

@@ -1511,7 +1511,7 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                 if (wvalid) {
                     float *en_p = P.implicit != 0u ? &we : nullptr;
                     if (plan_z) wave_demod_symbol<SF, 1, true>(P, WT, X + wpos, wb, wf, en_p);
-                    else wave_demod_symbol<SF, 1>(P, WT, X + wpos, wb, wf, en_p);
+                    else wave_demod_symbol<SF, kWaveFmode<SF>>(P, WT, X + wpos, wb, wf, en_p);
                     if (wb == kPoisonBin) wf = kFinePoison; // a sample of exactly zero in the window: the replay asks for a ZM round
                 }
                 }

@@ -33,7 +33,7 @@
 // v_rcp_f32 and v_permlane*_swap 8.2.
 
 #ifndef LORA_W2_FFS
-#define LORA_W2_FFS 0 // bit 0: SF7, bit 1: SF8: fine_sync in closed form (wave_demod_symbol FMODE 2) instead of from sps arctangents.  Built, held to the
+#define LORA_W2_FFS 7 // bit (SF - 7): fine_sync in closed form (wave_demod_symbol FMODE 2) - SF7, SF8, SF9
                       // oracle on the GPU (tests/test_gpu_ffs.py with the switch on: 221 passed) and measured: 16 % fewer VALU instructions per symbol, but the
                       // lane-mask bookkeeping is scalar work of the same wavefront - SF7 -4 %, SF8 -1 % (profiles/r03_ab_closed_form_fine_sync.txt): off
 #endif
@@ -234,33 +234,75 @@ __device__ __forceinline__ bool poisoned3(float a, float b, float c) { return po
 // window evaluated again by the ZM = true instantiation, which forms every ifreq value as the reference does (walkers: a round of its own)
 constexpr uint32_t kPoisonBin = 0xfffffffeu;
 
+// One row of the closed form's bookkeeping (wave_demod_symbol, FMODE 2) for the sample (ax, ay) = x[n] of this lane, n = 64 j + lane:
+//   z = x[n] conj x[n-1] (x[n-1]: the neighbouring lane's sample as a DPP operand; lane 0 reads lane 63: the caller drops its bits),
+//   mA <- sign Im x[n], mC <- sign Im z, zmin <- min(zmin, |Im z| [, Re z | Re z - 2 |Im z|]) (MIN; CLS 1 | 2: the class bound on |arg z|, kFfsClass).
+// Written out: left to the compiler the scalar products are re-packed into v_pk_fma_f32 with a v_mov_b32_dpp per operand and register pairs to
+// assemble, and every row's products are formed ahead of the serial mask chains (277 registers spilled at SF9).  The s_nop covers the
+// VALU -> DPP read hazard should the compiler have moved (ax, ay) with a VALU instruction directly in front.
+template <int CLS, bool MIN>
+__device__ __forceinline__ void ffs_row(float ax, float ay, uint32_t &mA, uint32_t &mC, float &zmin, float &t, float &re)
+{
+#define LORA_FFS_DPP " wave_ror:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    if constexpr (CLS == 0) { // Im z only
+        asm("v_alignbit_b32 %0, %0, %5, 31\n\t"
+            "s_nop 0\n\t"
+            "v_mul_f32_dpp %3, %4, %5" LORA_FFS_DPP
+            "v_fmac_f32_dpp %3, %5, -%4" LORA_FFS_DPP
+            "v_alignbit_b32 %1, %1, %3, 31\n\t"
+            "v_min_f32_e64 %2, |%3|, %2"
+            : "+v"(mA), "+v"(mC), "+v"(zmin), "=&v"(t) : "v"(ax), "v"(ay));
+        re = 0.0f;
+    } else {
+        float u;
+#define LORA_FFS_HEAD                                 \
+    "v_alignbit_b32 %0, %0, %7, 31\n\t"               \
+    "s_nop 0\n\t"                                     \
+    "v_mul_f32_dpp %3, %6, %7" LORA_FFS_DPP           \
+    "v_mul_f32_dpp %4, %6, %6" LORA_FFS_DPP           \
+    "v_fmac_f32_dpp %3, %7, -%6" LORA_FFS_DPP         \
+    "v_fmac_f32_dpp %4, %7, %7" LORA_FFS_DPP          \
+    "v_alignbit_b32 %1, %1, %3, 31"
+#define LORA_FFS_OPS : "+v"(mA), "+v"(mC), "+v"(zmin), "=&v"(t), "=&v"(re), "=&v"(u) : "v"(ax), "v"(ay)
+        if constexpr (!MIN) asm(LORA_FFS_HEAD LORA_FFS_OPS);
+        else if constexpr (CLS == 1) asm(LORA_FFS_HEAD "\n\tv_min3_f32 %2, %4, |%3|, %2" LORA_FFS_OPS);
+        else asm(LORA_FFS_HEAD "\n\tv_fma_f32 %5, -2.0, |%3|, %4\n\tv_min3_f32 %2, %5, |%3|, %2" LORA_FFS_OPS);
+#undef LORA_FFS_HEAD
+#undef LORA_FFS_OPS
+    }
+#undef LORA_FFS_DPP
+}
+
 // Demodulates the symbol window x[0 .. sps): s_out = get_shift_fft's return value, fine_out = d_fine_sync after
 // fine_sync(bin_idx, 2) (0 when drift correction is disabled).  Must be called by a whole wavefront.
 // FMODE: where fine_sync's instantaneous frequency comes from - 0: a second, cache-hot read of the window behind the FFT; 1: the registers
-// loaded for the dechirp (16 / 32 values per lane kept through the FFT); 2: not computed at all for most windows - the CLOSED FORM (below),
-// with mode 0 as the fall-back when the closed form cannot vouch for the reference's decision.  zs: this wavefront's LDS scratch for
-// mode 2 (kWaveFfsEntries<SF> v2f entries; unused otherwise).
+// loaded for the dechirp (16 / 32 / 64 values per lane kept through the FFT); 2: not computed at all for most windows - the CLOSED FORM (below),
+// with mode 0 as the fall-back when the closed form cannot vouch for the reference's decision.
 //
-// The closed form.  fine_sync picks the first maximum > 0 of c(i) = sum_k ifreq[k] v[o + i + k], i = -1, 0, 1 (:306-313; o = shift_ref + sps,
-// ifreq[sps-1] = ifreq[sps-2] :243).  v = d_upchirp_ifreq_v is a ramp of slope alpha with one step J at index 2 sps - 1 inside every
-// stretch fine_sync can look at for bin_idx < N - 1 (DevParams::ffs_*, checked on the table itself at lora_hip_create), so
+// The closed form (round 6: sign tests per lane; rounds 3-5 had built it on wavefront ballots and scalar popcounts, which cost more than it saved).
+// fine_sync picks the first maximum > 0 of c(i) = sum_k ifreq[k] v[o + i + k], i = -1, 0, 1 (:306-313; o = shift_ref + sps, ifreq[sps-1] =
+// ifreq[sps-2] :243).  v = d_upchirp_ifreq_v is a ramp of slope alpha with one step J at index 2 sps - 1 inside every stretch fine_sync can look
+// at for bin_idx < N - 1 (DevParams::ffs_*, checked on the table itself at lora_hip_create), so
 //     c(i+1) - c(i) = alpha F + J ifreq[2 sps - 1 - (o + i)] + (table noise, |.| <= ffs_tol),    F = sum_k ifreq[k],
 // and F telescopes: ifreq[k] = theta[k+1] - theta[k] + 2 pi w[k] (:231-240), w[k] = -1 / +1 when the step crosses the negative real axis
-// upwards / downwards - read off the signs of Im x[k], Im x[k+1] and Im(x[k+1] conj x[k]).  So the ORDER of the three correlations needs
-// the window's winding number (two v_cmp per sample and scalar popcounts), arg x[0], arg x[sps-1], ifreq[sps-2] and the ifreq at two
-// samples next to a bin boundary, instead of sps arctangents and 3 sps multiply-adds.  The differences are accepted when they exceed the
-// noise bound.  The SIGN of the maximum (a window without a matching chirp has c <= 0 and the reference then leaves lag = 0) is checked on
-// a uniform quarter of the sum's own terms - the samples n = 0, 1 (mod 8), whose x[n] conj x[n-1] go through LDS; the step sample is
-// always one of them: that partial correlation must reach half of the table's energy over the same terms, and at most sps / 128 samples
-// may turn by more than pi / 2 (noise floor).  Anything else - and bin_idx = N - 1, where the window runs into the table's tail - takes
-// the exact path.  tools/ffs_model.py holds the same rule in numpy against the oracle's fine_sync (0 differing decisions in 7 x 10^5
-// windows: clean, noisy down to -6 dB, interferers, carrier offsets, partial windows); tests/test_gpu_ffs.py holds the kernel to the oracle.
-template <int SF> constexpr int kWaveFfsEntries = (8 << SF) / 4 + 4;
+// upwards / downwards - read off the signs of Im x[k], Im x[k+1] and Im(x[k+1] conj x[k]).  Per sample that is one product (two multiplies with
+// the neighbour lane's sample as a DPP operand), two v_alignbit that collect the sign bits of a lane's rows into 32-bit words and one v_min; the
+// crossings of 32 rows are then five bitwise operations and two population counts.  arg x[0], arg x[sps-2], arg x[sps-1] come from the registers
+// the window was loaded into, the two ifreq values next to the template's step from three samples read again behind the arg-max.
+// The decision taken here is the common one only: c(0) > c(-1) and c(0) >= c(1), both by more than the noise bound - the scan then ends on lag 0
+// whatever the signs of the sums are (if c(-1) <= 0 the scan never leaves lag 0 before c(0); c(1) <= c(0) cannot displace it).  A symbol that moves
+// the clock (~1 %), a window next to the table's tail (bin_idx = N - 1), a product of exactly zero (std::arg(0): see kPoisonBin; or two collinear
+// samples, a tie of the sign tests), differences inside the noise bound and - SF9 and up, where the noise bound is computed for bounded ifreq - a window
+// with an |ifreq[k]| above atan(1/2) away from its ends take the sums themselves (the exact path).  tools/ffs_model.py holds
+// the same rule in numpy against the oracle's fine_sync (SF7 .. SF12: clean, noisy down to -15 dB, interferers, carrier offsets, partial
+// windows); tests/test_gpu_ffs.py holds the kernel to the oracle.
+// the bound on |ifreq[k]| a window has to keep (away from its ends) for the closed form to vouch for it - what DevParams::ffs_tol is computed for at
+// lora_hip_create (ffs_class_bound): 0: none (pi), 1: pi / 2 (Re > 0), 2: atan(1/2) (Re > 2 |Im|)
+template <int SF> constexpr int kFfsClass = SF <= 8 ? 0 : SF <= 10 ? 1 : 2;
 template <int SF> constexpr int kWaveFmode = ((LORA_W2_FFS >> (SF - 7)) & 1) ? 2 : ((SF == 7) || LORA_W2_EARLY_F_SF8) ? 1 : 0;
 template <int SF, int FMODE_, bool ZM = false>
 __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const WaveTabs &T, const float2 *__restrict__ x, uint32_t &s_out, int32_t &fine_out,
                                                   float *en_out = nullptr /* implicit header: the window's energy (determine_energy, :368-375) */,
-                                                  v2f *zs = nullptr /* FMODE 2: LDS scratch of this wavefront */,
                                                   long long *stamps = nullptr /* tools/probe_phases.hip */)
 {
     constexpr int FMODE = ZM ? 3 : FMODE_; // ZM: fine_sync's ifreq sample by sample with std::arg(0) = 0, in a rolled loop behind the arg-max (mode 3)
@@ -304,34 +346,67 @@ __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const Wave
             f[j + 1] = fp.y;
         }
     }
-    int ffs_w = 0, ffs_back = 0; // FMODE 2: winding number of the window, samples turning by more than pi / 2 (uniform)
+    // FMODE 2: the window's winding number and end-point angles, from sign tests - no arctangent per sample (see "The closed form" above)
+    float ffs_F = 0.0f;   // F = sum_k ifreq[k] (uniform)
+    bool ffs_ok = false;  // (uniform) the closed form may vouch for this window: no product of exactly zero (a zero SAMPLE: std::arg(0), or two collinear
+                          // samples: a tie of the sign tests) and - SF9 and up - every |ifreq[k]| inside the bound ffs_tol is computed for
     if constexpr (FMODE == 2) {
         if (want_fine && P.ffs_on != 0u) {
-            v2f bprev = (v2f){0.0f, 0.0f}, zlast = (v2f){0.0f, 0.0f};
-            unsigned long long a_prev = 0ull;
+            constexpr int CLS = kFfsClass<SF>;
+            constexpr int NM = (J + 31) / 32;
+            uint32_t mA[NM], mC[NM]; // one bit per row j of this lane's samples n = 64 j + lane: Im x[n] < 0, Im(x[n] conj x[n-1]) < 0
+#pragma unroll
+            for (int g = 0; g < NM; g++) { mA[g] = 0u; mC[g] = 0u; }
+            float zmin = 3.0e38f;
 #pragma unroll
             for (int j = 0; j < J; j++) {
-                const v2f b = dpp2<kDppWaveRor1>(a[j]);
-                const v2f p = (lane == 0) ? bprev : b; // sample n - 1 (n = 0: none, z = 0)
-                bprev = b;
-                const v2f z = cmul_conj(a[j], p);      // (re, im) of x[n] conj x[n-1]: ifreq[n-1] = arg z
-                const unsigned long long A = __builtin_amdgcn_ballot_w64(a[j].y < 0.0f), Cm = __builtin_amdgcn_ballot_w64(z.y < 0.0f),
-                                         R = __builtin_amdgcn_ballot_w64(z.x < 0.0f);
-                const unsigned long long B = (A << 1) | (a_prev >> 63); // Im x[n-1] < 0
-                const unsigned long long M = j == 0 ? ~1ull : ~0ull;    // n = 0 has no predecessor
-                ffs_w += __builtin_popcountll(A & ~B & ~Cm & M) - __builtin_popcountll(~A & B & Cm & M);
-                ffs_back += __builtin_popcountll(R & M);
-                a_prev = A;
-                if ((lane & 6) == 0) zs[j * 16 + ((lane >> 3) << 1) + (lane & 1)] = z; // n = 0, 1 (mod 8): entry (n >> 3) * 2 + (n & 1)
-                if (j == J - 1) zlast = z;
-                asm volatile("" : "+s"(ffs_w), "+s"(ffs_back)); // (the counts are needed here: left alone the popcounts sink to their use behind the FFT
-                                                                 // and 6 J scalar registers of lane masks wait for them in VGPR lanes)
+                // a window one or two samples off its symbol holds the phase step between two symbols next to one of its ends: the first and the last four
+                // products are not held to the class (ffs_tol allows for eight values up to pi), only to being non-zero
+                const bool ends = CLS != 0 && (j == 0 || j == J - 1);
+                float t, re;
+                if (ends) {
+                    ffs_row<CLS, false>(a[j].x, a[j].y, mA[j >> 5], mC[j >> 5], zmin, t, re);
+                    float u = CLS == 1 ? re : __builtin_fmaf(-2.0f, fabsf(t), re);
+                    u = (j == 0 ? lane < 4 : lane >= 60) ? 1.0f : u;
+                    asm("v_min3_f32 %0, %1, |%2|, %3" : "=v"(zmin) : "v"(u), "v"(t), "v"(zmin));
+                } else {
+                    ffs_row<CLS, true>(a[j].x, a[j].y, mA[j >> 5], mC[j >> 5], zmin, t, re);
+                }
             }
-            // arg x[0] (lane 0), arg x[sps-1] and ifreq[sps-2] = arg z[sps-1] (lane 63): one packed evaluation
-            const v2f sel = (lane == 63) ? zlast : a[0];
-            const v2f r = lean_atan2_pk((v2f){sel.y, a[J - 1].y}, (v2f){sel.x, a[J - 1].x});
-            if (lane == 0) zs[SPS / 4] = (v2f){r.x, 0.0f};
-            if (lane == 63) zs[SPS / 4 + 1] = r; // (ifreq[sps-2], arg x[sps-1])
+            zmin = lane == 0 ? 3.0e38f : zmin; // (lane 0's products were taken with the wrong neighbour)
+            int cnt = 0;
+#pragma unroll
+            for (int g = 0; g < NM; g++) {
+                const uint32_t A = mA[g], Cm = mC[g];
+                const uint32_t B = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)A, kDppWaveRor1, 0xf, 0xf, true); // Im x[n-1] < 0: the neighbour's bit of the same row
+                uint32_t q = ((Cm & B) | (~Cm & A)) & (A ^ B); // the step crosses the real axis ... the long way round: the negative half
+                q = lane == 0 ? 0u : q;
+                cnt += __builtin_popcount(q) - 2 * __builtin_popcount(q & Cm); // upwards (+1: Cm clear) / downwards (-1)
+            }
+            { // the row boundaries: lane l, 1 <= l < J, holds (x[64 l - 1], x[64 l])
+                const bool mine = lane >= 1 && lane < J;
+                typedef float f4u __attribute__((ext_vector_type(4), aligned(8))); // (8-byte aligned: x[64 l - 1] is the last item of a 16-byte pair)
+                const f4u pb = *reinterpret_cast<const __attribute__((address_space(1))) f4u *>((const __attribute__((address_space(1))) float *)x + (mine ? 128 * lane - 2 : 0));
+                const float t = pb.w * pb.x - pb.z * pb.y, re = pb.z * pb.x + pb.w * pb.y; // x[n] conj x[n-1]
+                const uint32_t A = __builtin_bit_cast(uint32_t, pb.w), B = __builtin_bit_cast(uint32_t, pb.y), Cm = __builtin_bit_cast(uint32_t, t);
+                const uint32_t q = mine ? (((Cm & B) | (~Cm & A)) & (A ^ B)) : 0u;
+                cnt += (int)(q >> 31) - 2 * (int)((q & Cm) >> 31);
+                float u = fabsf(t);
+                if constexpr (CLS != 0) u = fminf(u, CLS == 1 ? re : __builtin_fmaf(-2.0f, u, re));
+                zmin = mine ? fminf(zmin, u) : zmin;
+            }
+            const float W = wave_sum_u((float)cnt); // (exact: |W| <= sps)
+            const int zbits = wave_min_u(__builtin_bit_cast(int, zmin)); // (as integers: a negative value - out of the class - is smaller than any positive one)
+            // arg x[0] (lane 0), arg x[sps-2], arg x[sps-1] (lanes 62, 63): one evaluation; ifreq[sps-1] = ifreq[sps-2] (:243) is the sum's last term
+            const v2f sel = (lane == 0) ? a[0] : a[J - 1];
+            const float th = lean_atan2_pk((v2f){sel.y, sel.y}, (v2f){sel.x, sel.x}).x;
+            const float th0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, th), 0));
+            const float th2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, th), 62));
+            const float the = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, th), 63));
+            float last = the - th2;
+            last = last > 3.14159265358979324f ? last - 6.28318530717958648f : (last < -3.14159265358979324f ? last + 6.28318530717958648f : last);
+            ffs_F = (the - th0) + 6.28318530717958648f * W + last;
+            ffs_ok = zbits > 0 && ffs_F == ffs_F;
         }
     }
     LORA_WSTAMP(1);
@@ -440,41 +515,21 @@ __device__ __forceinline__ void wave_demod_symbol(const DevParams &P, const Wave
     const uint32_t bin_idx = (s == 0u && P.demod_mode == 2u) ? 0u : (s + (uint32_t)N - 1u) % (uint32_t)N;
     const float *__restrict__ v = T.v + ((int)(bin_idx + 1u) * 8 + SPS);
     if constexpr (FMODE == 2) {
-        bool exact = P.ffs_on == 0u || bin_idx == (uint32_t)N - 1u || ffs_back > SPS / 128;
-        if (!exact) {
-            constexpr int EPL = SPS / 4 / 64; // entries per lane (4 / 8)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the entries were written by other lanes of this wavefront
-            float fe[EPL], cs = 0.0f, es = 0.0f;
-#pragma unroll
-            for (int i = 0; i < EPL; i += 2) {
-                const int e0 = lane + 64 * i, e1 = e0 + 64;
-                const v2f z0 = zs[e0], z1 = zs[e1];
-                const v2f fp = lean_atan2_pk((v2f){z0.y, z1.y}, (v2f){z0.x, z1.x});
-                fe[i] = fp.x; fe[i + 1] = fp.y;
-                const float v0 = v[(e0 >> 1) * 8 + (e0 & 1) - 1], v1 = v[(e1 >> 1) * 8 + (e1 & 1) - 1]; // entry e <-> n = (e >> 1) 8 + (e & 1), ifreq[n-1]
-                cs += fp.x * v0 + fp.y * v1;
-                es += ((i == 0 && lane == 0) ? 0.0f : v0 * v0) + v1 * v1; // (n = 0 is not a term of the sum)
-            }
-            cs = wave_sum_u(cs); es = wave_sum_u(es);
-            const int ea = (int)((uint32_t)SPS - 8u * (bin_idx + 1u)) >> 2; // entry of n = ka = sps - 8 (bin_idx + 1): ifreq[ka-1]; its neighbour n = ka + 1: ifreq[ka]
-            float fb = 0.0f, fa = 0.0f;
-#pragma unroll
-            for (int i = 0; i < EPL; i++)
-                if (i == (ea >> 6)) {
-                    fb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fe[i]), ea & 63));
-                    fa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fe[i]), (ea & 63) + 1));
-                }
-            const v2f e0 = zs[SPS / 4], e1 = zs[SPS / 4 + 1];
-            const float F = (e1.y - e0.x) + 6.28318530717958648f * (float)ffs_w + e1.x;
-            const float D0 = P.ffs_alpha * F + P.ffs_jump * fa, D1 = P.ffs_alpha * F + P.ffs_jump * fb; // c(0) - c(-1), c(1) - c(0)
-            const float tol = P.ffs_tol;
-            int32_t lag;
-            bool sure = fabsf(D0) > tol;
-            if (D0 > 0.0f) { sure = sure && fabsf(D1) > tol; lag = D1 > 0.0f ? 1 : 0; }
-            else { sure = sure && fabsf(D0 + D1) > 2.0f * tol; lag = (D0 + D1) > 0.0f ? 1 : -1; }
-            sure = sure && cs >= 0.5f * es; // (NaN: not sure)
-            if (__builtin_amdgcn_readfirstlane(sure ? 1 : 0) != 0) {
-                fine_out = __builtin_amdgcn_readfirstlane(-lag);
+        if (ffs_ok && bin_idx != (uint32_t)N - 1u) { // (uniform)
+            // ifreq[ka - 1], ifreq[ka] next to the template's step, ka = sps - 8 (bin_idx + 1) >= 8: three samples read again (cache-hot), formed as the
+            // reference forms them - the difference of two sample arguments, unwrapped (:231-240).  (Taking the two decisions as flags while the window is
+            // in registers - nothing read again - costs four more instructions per sample and measured the same in the walkers, 14 % slower standalone at SF8.)
+            const int ka = SPS - 8 * ((int)bin_idx + 1);
+            const v2f xs = xv[ka - 1 + (lane < 2 ? lane : 2)];
+            const float th = lean_atan2_pk((v2f){xs.y, xs.y}, (v2f){xs.x, xs.x}).x;
+            float d = th - dpp_f<kDppWaveRor1>(th);
+            d = d > 3.14159265358979324f ? d - 6.28318530717958648f : (d < -3.14159265358979324f ? d + 6.28318530717958648f : d);
+            const float fb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), 1)); // ifreq[ka - 1]
+            const float fa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), 2)); // ifreq[ka]
+            const float D0 = P.ffs_alpha * ffs_F + P.ffs_jump * fa, D1 = P.ffs_alpha * ffs_F + P.ffs_jump * fb; // c(0) - c(-1), c(1) - c(0)
+            // c(0) above c(-1) and c(1) below c(0), both by more than the table's noise: the scan (:306-313) ends on lag 0 whatever the signs of the sums
+            // are.  Everything else - the ~1 % of symbols that move the clock, and the windows whose differences lie inside the noise - is decided by the sums
+            if (D0 > P.ffs_tol && D1 < -P.ffs_tol) { // (uniform; NaN: not taken)
                 LORA_WSTAMP(7);
                 return;
             }
@@ -781,7 +836,7 @@ __global__ __launch_bounds__(512, OCC) void demod_symbols_wave_kernel(DevParams 
         const int64_t o0 = offsets[s];
         uint32_t b;
         int32_t fs;
-        wave_demod_symbol<SF, 1>(P, T, iq + o0, b, fs);
+        wave_demod_symbol<SF, kWaveFmode<SF>>(P, T, iq + o0, b, fs);
         if (b == kPoisonBin) wave_demod_symbol<SF, 1, true>(P, T, iq + o0, b, fs); // (uniform) a window with a sample of exactly zero
         if (lane == 0u) { bins[s] = b; if (fine) fine[s] = fs; }
         if (alt.shift && fs != 0 && s + 1u < n) {
@@ -789,7 +844,7 @@ __global__ __launch_bounds__(512, OCC) void demod_symbols_wave_kernel(DevParams 
             if (o1 == o0 + (int64_t)SPS && a >= 0 && a <= alt.max_start) {
                 uint32_t b2;
                 int32_t f2;
-                wave_demod_symbol<SF, 1>(P, T, iq + a, b2, f2);
+                wave_demod_symbol<SF, kWaveFmode<SF>>(P, T, iq + a, b2, f2);
                 if (b2 == kPoisonBin) wave_demod_symbol<SF, 1, true>(P, T, iq + a, b2, f2);
                 if (lane == 0u) { alt.bins[s + 1u] = b2; alt.fine[s + 1u] = f2; alt.shift[s + 1u] = fs; }
             }

@@ -1,5 +1,5 @@
-"""d_fine_sync of the SF7 / SF8 wave demodulator on hostile windows - and the closed-form fine_sync behind LORA_W2_FFS (wave_demod_symbol FMODE 2, docs/LAB_NOTEBOOK.md 5.4:
-built, green, measured slower, off by default; this test is what a build with the switch on has to pass).  d_fine_sync per window against the oracle's fine_sync
+"""d_fine_sync of the FFT demodulators on hostile windows - the closed-form fine_sync of wave_demod_symbol (FMODE 2: SF7 - SF9 one wavefront per window, round 6) and
+whatever SF10 - SF12 run.  d_fine_sync per window against the oracle's fine_sync
 (lib/decoder_impl.cc:300-338) on every kind of window tools/ffs_model.py knows - clean and noisy symbols cut early / late, noise,
 downchirps, tones, interferers, carrier offsets, partial windows, bursts, clipping - i.e. on windows that take the closed form AND on
 windows that must take the exact path, and the same with the closed form switched off (LORA_HIP_NO_FFS)."""
@@ -50,10 +50,6 @@ def _check(sf, mode, wins, kinds, g, gf, oracle_mod):
         sres = o.get_shift_fft(w)
         if int(g[i]) != sres:
             continue            # (the arg-max of a noise window may differ in the last float bit: not this test's subject)
-        if kinds[i] == "halfz":
-            continue            # exact zeros: the reference's arg(0) = 0 makes ifreq next to a zero sample -arg(x[k]) where the kernels' arg(x[k+1] conj x[k])
-                                # gives 0 - every ifreq path of the product, not this rule's subject (no decoded window holds exact zeros); the GPU
-                                # still runs these windows, and on / off must agree on them (below)
         n_same_bin += 1
         bin_idx = 0 if (sres == 0 and mode == 2) else (sres + N - 1) % N
         wf = o.fine_sync(w, bin_idx, 2)
@@ -68,7 +64,7 @@ def _check(sf, mode, wins, kinds, g, gf, oracle_mod):
     return n_same_bin, n_closed
 
 
-@pytest.mark.parametrize("sf,n_per_kind", [(7, 120), (8, 60)])
+@pytest.mark.parametrize("sf,n_per_kind", [(7, 120), (8, 60), (9, 30), (10, 12), (11, 6), (12, 4)])
 def test_closed_form_fine_sync_equals_oracle(torch_cuda, oracle_mod, sf, n_per_kind):
     from gr_lora_amd import capi
     cfg, wins, kinds = _windows(sf, n_per_kind, seed=4000 + sf)
@@ -80,7 +76,7 @@ def test_closed_form_fine_sync_equals_oracle(torch_cuda, oracle_mod, sf, n_per_k
         g, gf = h.demod_symbols_ex_device(dev.data_ptr(), x.size, offs, mode)
         h.close()
         n_same, n_closed = _check(sf, mode, wins, kinds, g, gf, oracle_mod)
-        assert n_same > 0.9 * len(wins) and n_closed > 0.25 * len(wins), (n_same, n_closed, len(wins))   # both paths are exercised
+        assert n_same > 0.9 * len(wins) and n_closed > (0.15 if sf <= 8 else 0.03) * len(wins), (n_same, n_closed, len(wins))   # both paths are exercised
 
 
 _NOFFS = r'''

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The closed-form fine_sync of the wave demodulator (gr_lora_amd/csrc/lora_wave_demod.inc.hip, FMODE 2) in numpy, against the oracle's
+"""The closed-form fine_sync of the wave demodulators (gr_lora_amd/csrc/lora_wave_demod.inc.hip, FMODE 2) in numpy, against the oracle's
 fine_sync (lib/decoder_impl.cc:300-338) on synthetic windows of many kinds: what the rule is, and the evidence that it reproduces the
 reference's decision whenever it claims to (CPU only).
 
@@ -7,10 +7,12 @@ reference's decision whenever it claims to (CPU only).
 
 fine_sync picks the first maximum > 0 of c(i) = sum_k ifreq[k] v[o + i + k], i = -1, 0, 1.  v (d_upchirp_ifreq_v) is a ramp of slope
 alpha with one step J at index 2 sps - 1 in every stretch the sum can cover for bin_idx < N - 1, so
-    c(i+1) - c(i) = alpha F + J ifreq[2 sps - 1 - (o + i)] + eta,   F = sum_k ifreq[k],   |eta| <= tol  (table noise, Cauchy-Schwarz)
-and F = arg x[sps-1] - arg x[0] + 2 pi W + ifreq[sps-2] with W the window's winding number (sign tests only).  The sign of the maximum is
-checked on the terms n = 0, 1 (mod 8) of the sum (a uniform quarter): their partial correlation must reach half of the table's energy over
-the same terms, and at most sps / 128 samples may turn by more than pi / 2.  `fast` returns None where the kernel takes the exact path."""
+    c(i+1) - c(i) = alpha F + J ifreq[2 sps - 1 - (o + i)] + eta,   F = sum_k ifreq[k],   |eta| <= tol  (table noise)
+and F = arg x[sps-1] - arg x[0] + 2 pi W + ifreq[sps-2] with W the window's winding number (sign tests only).  The rule takes the common
+decision only: c(0) - c(-1) > tol and c(1) - c(0) < -tol - the reference's scan then ends on lag 0 whatever the signs of the sums are.
+Everything else is the exact path: a window whose differences say anything else, bin_idx = N - 1, a product x[k+1] conj x[k] with a zero
+imaginary part (a zero sample, or a tie of the sign tests) and - SF9 and up, where `tol` is computed for bounded ifreq - any |ifreq[k]| above
+atan(1/2).  `fast` returns None where the kernel takes the exact path."""
 import argparse
 import os
 import sys
@@ -26,6 +28,7 @@ def tables(o):
     """alpha, J, tol from the table itself - the same computation as lora_hip_create (lora_runtime.cpp, DevParams::ffs_*)"""
     V = o.table(4).astype(np.float64)
     S = o.sps
+    sf = int(round(np.log2(S))) - 3
     dV = np.diff(V)
     lo, hi = S + 7, 3 * S - 8
     reg = np.ones(hi - lo, bool)
@@ -34,7 +37,12 @@ def tables(o):
     eps = np.where(reg, dV[lo:hi] - alpha, 0.0)
     cs = np.concatenate([[0.0], np.cumsum(eps ** 2)])
     worst = max(cs[s + S] - cs[s] for s in range(0, hi - lo - S + 1))
-    tol = 1.05 * np.pi * np.sqrt(S) * np.sqrt(worst) + 1e-4
+    enorm = np.sqrt(worst)
+    fmax = np.arctan(0.5) if sf >= 11 else np.pi / 2 if sf >= 9 else np.pi   # (kFfsClass)
+    fnorm = np.sqrt(S * fmax ** 2 + 8 * np.pi ** 2) if sf >= 9 else fmax * np.sqrt(S)   # (the four products at either end of a window: any value)
+    tol = 1.05 * fnorm * enorm + 1e-4
+    if sf >= 9 and tol > 0.15:
+        tol = 12.0 * fmax * enorm + 1e-4
     return V, np.float32(alpha), np.float32(dV[2 * S - 1] - alpha), np.float32(tol)
 
 
@@ -44,36 +52,37 @@ def fast(x, bin_idx, S, N, V, alpha, J, tol):
     if bin_idx == N - 1:
         return None, "edge"
     z = (x[1:] * np.conj(x[:-1])).astype(np.complex64)  # z[k] <-> ifreq[k] = arg z[k], k = 0 .. S-2
-    if int((z.real < 0).sum()) > S // 128:
-        return None, "noise"
+    if S >= 4096:
+        u = z.real - 2 * np.abs(z.imag) if S >= 16384 else z.real.copy()
+        u[:3] = 1                      # products n = 1, 2, 3 and n = sps-4 .. sps-1 (n = 64 j + lane: row 0 lanes 1-3, the last row's lanes 60-63): non-zero only
+        u[-4:] = 1
+        if not min(u.min(), np.abs(z.imag).min()) > 0:
+            return None, "class"
+    elif not np.abs(z.imag).min() > 0:
+        return None, "zero"
     a, b, c = x.imag[1:] < 0, x.imag[:-1] < 0, z.imag < 0
     W = int((a & ~b & ~c).sum()) - int((~a & b & c).sum())
-    F = np.float32(np.angle(x[-1]) - np.angle(x[0]) + np.float32(2 * np.pi * W) + np.angle(z[S - 2]))
-    o = (bin_idx + 1) * 8 + S
-    k = np.arange(S - 1)
-    sel = k[((k % 8) == 7) | ((k % 8) == 0)]           # samples n = k + 1 = 0, 1 (mod 8)
-    f = np.angle(z[sel]).astype(np.float32)
-    vv = V[o + sel].astype(np.float32)
-    if not float(np.dot(f, vv)) >= 0.5 * float(np.dot(vv, vv)):
-        return None, "sign"
+
+    def ifr(k):  # the reference's form: the difference of two sample arguments, unwrapped
+        d = np.float32(np.angle(x[k + 1])) - np.float32(np.angle(x[k]))
+        return d - np.float32(2 * np.pi) if d > np.pi else (d + np.float32(2 * np.pi) if d < -np.pi else d)
+    F = np.float32(np.angle(x[-1]) - np.angle(x[0]) + np.float32(2 * np.pi * W) + ifr(S - 2))
     ka = S - 8 * (bin_idx + 1)
-    D0 = alpha * F + J * np.float32(np.angle(z[ka]))       # c(0) - c(-1)
-    D1 = alpha * F + J * np.float32(np.angle(z[ka - 1]))   # c(1) - c(0)
-    if abs(D0) <= tol:
-        return None, "D0"
-    if D0 > 0:
-        return (1 if D1 > 0 else 0, None) if abs(D1) > tol else (None, "D1")
-    return (1 if D0 + D1 > 0 else -1, None) if abs(D0 + D1) > 2 * tol else (None, "D01")
+    D0 = alpha * F + J * ifr(ka)       # c(0) - c(-1)
+    D1 = alpha * F + J * ifr(ka - 1)   # c(1) - c(0)
+    if D0 > tol and D1 < -tol:
+        return 0, None
+    return None, "D"
 
 
-KINDS = [(40, "up1"), (20, "up1"), (12, "up1"), (8, "up1"), (5, "up1"), (0, "up1"), (-6, "up1"), (None, "noise"), (30, "up6"), (30, "down"), (30, "tone"),
+KINDS = [(40, "up0"), (40, "up1"), (20, "up1"), (12, "up1"), (8, "up1"), (5, "up1"), (0, "up1"), (-6, "up1"), (-15, "up1"), (None, "noise"), (30, "up6"), (30, "down"), (30, "tone"),
          (30, "tonechirp"), (20, "halfn"), (None, "halfz"), (30, "two"), (30, "cfo"), (30, "cfot"), (15, "cfot"), (30, "dc"), (30, "burst"), (30, "clip")]
 
 
 def make_window(kind, snr, rng, up, S, N):
     """one symbol window: the middle chirp of three random ones, cut -1..1 samples off (up6: -6..6), then what `kind` does to it"""
     s = int(rng.integers(0, N))
-    dt = int(rng.integers(-6, 7)) if kind == "up6" else int(rng.integers(-1, 2))
+    dt = int(rng.integers(-6, 7)) if kind == "up6" else 0 if kind == "up0" else int(rng.integers(-1, 2))
     ar = np.arange(S)
     stream = np.concatenate([up[(ar + int(rng.integers(0, N)) * 8) % S], up[(ar + s * 8) % S], up[(ar + int(rng.integers(0, N)) * 8) % S]])
     if kind == "cfo":    # carrier offset absorbed as a timing shift
@@ -113,7 +122,7 @@ def make_window(kind, snr, rng, up, S, N):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("sf", nargs="*", type=int, default=[7, 8])
+    ap.add_argument("sf", nargs="*", type=int, default=[7, 8, 9])
     ap.add_argument("--n", type=int, default=1000)
     ap.add_argument("--seed", type=int, default=1)
     a = ap.parse_args()
