@@ -327,31 +327,51 @@ __device__ __forceinline__ void w3_ifreq16(const v2f (&a)[16], const v2f (&ap)[1
 // fine_sync(bin_idx, 2) (:300-338, :501-502; 0 when drift correction is off); en[g] = determine_energy (:368-375) when
 // want_energy.  Called by all threads of the workgroup (barriers inside); the results of every group come back uniform.
 struct W3DemodOut { uint32_t s[4]; int32_t fine[4]; float en[4]; int slot; };
-struct W3DemodArgs { const float2 *down, *ctab; const float *up_ifreq_v; uint32_t enable_fine_sync, demod_mode; };
+struct W3DemodArgs { const float2 *down, *ctab; const float *up_ifreq_v; uint32_t enable_fine_sync, demod_mode; uint32_t ffs_on; float ffs_alpha, ffs_jump, ffs_tol; /* DevParams::ffs_* */ };
 // fine[g] of a POISONED window (a sample of exactly zero: the NaN of its products has reached the window's fine_sync sums): the caller has the round evaluated
 // again by the ZM = true instantiation, which forms every ifreq value as the reference does (std::arg(0) = 0: lora_kernels.hip, ifreq_prod_z)
 constexpr int32_t kFinePoison = 0x7ffffff0;
 template <int SF, int HV = 0, bool ZM = false>
-__device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds<SF, HV> &L, const float2 *__restrict__ x, bool valid, bool want_energy, int &slot,
+__device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds<SF, HV> &L, const float2 *const (&xa)[W3Geom<SF, HV>::NG] /* every group's window (uniform) */,
+                                               uint32_t vmask /* bit g: group g has a window */, bool want_energy, int &slot,
                                                uint32_t (&s_out)[W3Geom<SF, HV>::NG], int32_t (&fine_out)[W3Geom<SF, HV>::NG], float (&en_out)[W3Geom<SF, HV>::NG],
                                                long long *stamps = nullptr /* tools/demod_bench.py --stamps: clock per phase */)
 {
 #define LORA_W3STAMP(i) do { if (stamps) stamps[i] = clock64(); } while (0)
     LORA_W3STAMP(0);
     using G = W3Geom<SF, HV>;
-    constexpr int N = G::N, SPS = G::SPS, TG = G::TG, CH = G::CH, M2 = G::M2, AR = G::AR, SA = G::SA, PAIRS = G::PAIRS, ROUNDS = G::ROUNDS, NG = G::NG, VT = G::VT, U = G::U;
-    constexpr bool LATE_F = G::LATE_F || ZM; // fine_sync's ifreq from a second read of the window: SF12 (registers), and every ZM evaluation
+    constexpr int N = G::N, SPS = G::SPS, TG = G::TG, CH = G::CH, M2 = G::M2, AR = G::AR, SA = G::SA, PAIRS = G::PAIRS, ROUNDS = G::ROUNDS, NG = G::NG, VT = G::VT, U = G::U, GW = G::GW;
+    // fine_sync's ifreq: never kept from pass 1 (round 6).  The common decision - lag 0 - is taken in closed form from sign tests made while the samples are in
+    // registers for the dechirp (FFS: wave_demod_symbol FMODE 2, lora_wave_demod.inc.hip, explains the rule; ffs_row is the per-sample part); a window the closed
+    // form cannot vouch for has its three sums formed from a second read of the window (the path SF12 always took, and every ZM evaluation takes)
+    constexpr bool LATE_F = true;
+    constexpr bool FFS = !ZM;
     int tt = threadIdx.x;
     asm volatile("" : "+v"(tt)); // keeps per-thread table addresses out of the caller's loop-invariant set
     const int grp = __builtin_amdgcn_readfirstlane(tt / TG), t = tt % TG;
     const int gwave = __builtin_amdgcn_readfirstlane(t >> 6), r = t & 7;
     const bool want_fine = P.enable_fine_sync != 0u;
+    const float2 *__restrict__ x = xa[0];
+#pragma unroll
+    for (int g = 1; g < NG; g++) x = grp == g ? xa[g] : x;
+    const bool valid = ((vmask >> grp) & 1u) != 0u;
     const w3_buf_t xb = w3_buf(w3_uniform_ptr(x)), db = w3_buf(w3_uniform_ptr(P.down)), cb = w3_buf(w3_uniform_ptr(P.ctab));
     W3Shared &ws = *L.ws;
     v2f *data = L.data + (size_t)grp * G::data_entries;
     const uint32_t tu = (uint32_t)t;
+    const int lane = tt & 63;
 
-    float f[LATE_F ? 1 : PAIRS][16]; // ifreq[n - 1] of this thread's samples (kept from pass 1 unless LATE_F)
+    // closed-form fine_sync: this thread's rows are (p, c) <-> n = c CH + p TG + t, row index 16 p + c; the lanes of a wavefront hold 64 consecutive samples of a row
+    constexpr int NROW = 16 * PAIRS, NMW = (NROW + 31) / 32, CLS = kFfsClass<SF>;
+    const bool ffs = FFS && want_fine && P.ffs_on != 0u; // (uniform)
+    uint32_t mA[NMW], mC[NMW];
+#pragma unroll
+    for (int g = 0; g < NMW; g++) { mA[g] = 0u; mC[g] = 0u; }
+    float zmin = 3.0e38f;
+    v2f raw0 = (v2f){0.0f, 0.0f}, rawE = (v2f){0.0f, 0.0f}; // x[0] (thread 0) / x[sps-2], x[sps-1] (the group's last two threads)
+    float ffs_W = 0.0f, ffs_th = 0.0f;                      // this wavefront's winding count; arg of raw0 / rawE
+    int ffs_zb = 0;                                          // this wavefront's min of the class / non-zero test, as integer bits (<= 0: the closed form may not vouch)
+
     v2f hold[ROUNDS > 1 ? PAIRS : 1][8]; // SF12: rows 8..15 of pass 1 wait here for round 1
     float en = 0.0f;
 
@@ -368,28 +388,23 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
 #pragma unroll
                 for (int c = 0; c < 16; c++) en += a[c].x * a[c].x + a[c].y * a[c].y;
             }
-            if constexpr (!LATE_F) {
-                if (want_fine) {
-                    // x[n - 1], eight at a time (a + all 16 predecessors + the dechirp table would not fit the register budget)
+            if (ffs) { // (uniform) sign tests of this thread's 16 samples (ffs_row)
+                if (p == 0) raw0 = a[0];
+                if (p == PAIRS - 1) rawE = a[15];
 #pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        v2f ap[8];
-#pragma unroll
-                        for (int c = 0; c < 8; c++)
-                            ap[c] = (h == 0 && c == 0) ? w3_ld2(xb, (p == 0) ? (ob >= 8u ? ob - 8u : 0u) : ob - 8u, 0u) : w3_ld2(xb, ob, (uint32_t)((8 * h + c) * CH * 8 - 8));
-#pragma unroll
-                        for (int c = 0; c < 8; c += 4) {
-                            const int q = 8 * h + c;
-                            v2f im0, re0, im1, re1, o0, o1;
-                            im0 = (v2f){a[q].y * ap[c].x - a[q].x * ap[c].y, a[q + 1].y * ap[c + 1].x - a[q + 1].x * ap[c + 1].y};
-                            re0 = (v2f){a[q].x * ap[c].x + a[q].y * ap[c].y, a[q + 1].x * ap[c + 1].x + a[q + 1].y * ap[c + 1].y};
-                            im1 = (v2f){a[q + 2].y * ap[c + 2].x - a[q + 2].x * ap[c + 2].y, a[q + 3].y * ap[c + 3].x - a[q + 3].x * ap[c + 3].y};
-                            re1 = (v2f){a[q + 2].x * ap[c + 2].x + a[q + 2].y * ap[c + 2].y, a[q + 3].x * ap[c + 3].x + a[q + 3].y * ap[c + 3].y};
-                            w3_atan2_x4(im0, re0, im1, re1, o0, o1);
-                            f[LATE_F ? 0 : p][q] = (p == 0 && q == 0 && t == 0) ? 0.0f : o0.x; // n = 0 has no predecessor in the window
-                            f[LATE_F ? 0 : p][q + 1] = o0.y; f[LATE_F ? 0 : p][q + 2] = o1.x; f[LATE_F ? 0 : p][q + 3] = o1.y;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
+                for (int c = 0; c < 16; c++) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int row = p * 16 + c;
+                    float tq, re;
+                    // the first and the last four products of the window are not held to the class bound (wave_demod_symbol), only to being non-zero
+                    const bool ends = CLS != 0 && ((p == 0 && c == 0) || (p == PAIRS - 1 && c == 15));
+                    if (ends) {
+                        ffs_row<CLS, false>(a[c].x, a[c].y, mA[row >> 5], mC[row >> 5], zmin, tq, re);
+                        float u = CLS == 1 ? re : __builtin_fmaf(-2.0f, fabsf(tq), re);
+                        u = ((p == 0 && c == 0) ? (gwave == 0 && lane < 4) : (gwave == GW - 1 && lane >= 60)) ? 1.0f : u;
+                        asm("v_min3_f32 %0, %1, |%2|, %3" : "=v"(zmin) : "v"(u), "v"(tq), "v"(zmin));
+                    } else {
+                        ffs_row<CLS, true>(a[c].x, a[c].y, mA[row >> 5], mC[row >> 5], zmin, tq, re);
                     }
                 }
             }
@@ -418,6 +433,37 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
                 for (int i = 0; i < 8; i++) hold[p][i] = a[8 + i];
             }
         }
+    }
+
+    if (ffs && valid) { // this wavefront's share of the window's winding number, and its class / non-zero test
+        zmin = lane == 0 ? 3.0e38f : zmin; // (lane 0's products were taken with lane 63's sample of its own row)
+        int cnt = 0;
+#pragma unroll
+        for (int g = 0; g < NMW; g++) {
+            const uint32_t A = mA[g], Cm = mC[g];
+            const uint32_t B = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)A, kDppWaveRor1, 0xf, 0xf, true); // Im x[n-1] < 0: the neighbour's bit of the same row
+            uint32_t q = ((Cm & B) | (~Cm & A)) & (A ^ B);
+            q = lane == 0 ? 0u : q;
+            cnt += __builtin_popcount(q) - 2 * __builtin_popcount(q & Cm);
+        }
+        { // the rows' first samples: lane l < NROW holds (x[n - 1], x[n]) of row l = 16 p + c, n = c CH + p TG + 64 gwave (the window's n = 0 has no predecessor)
+            const int pl = lane >> 4, cl = lane & 15;
+            const int nl = cl * CH + pl * TG + 64 * gwave;
+            const bool mine = lane < NROW && nl > 0;
+            typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
+            const f4u pb = *reinterpret_cast<const __attribute__((address_space(1))) f4u *>((const __attribute__((address_space(1))) float *)x + (mine ? 2 * nl - 2 : 0));
+            const float tq = pb.w * pb.x - pb.z * pb.y, re = pb.z * pb.x + pb.w * pb.y; // x[n] conj x[n-1]
+            const uint32_t A = __builtin_bit_cast(uint32_t, pb.w), B = __builtin_bit_cast(uint32_t, pb.y), Cm = __builtin_bit_cast(uint32_t, tq);
+            const uint32_t q = mine ? (((Cm & B) | (~Cm & A)) & (A ^ B)) : 0u;
+            cnt += (int)(q >> 31) - 2 * (int)((q & Cm) >> 31);
+            float u = fabsf(tq);
+            if constexpr (CLS != 0) u = fminf(u, CLS == 1 ? re : __builtin_fmaf(-2.0f, u, re));
+            zmin = mine ? fminf(zmin, u) : zmin;
+        }
+        ffs_W = wave_sum_u((float)cnt);
+        ffs_zb = wave_min_u(__builtin_bit_cast(int, zmin));
+        const v2f sel = (gwave == 0 && lane == 0) ? raw0 : rawE;
+        ffs_th = lean_atan2_pk((v2f){sel.y, sel.y}, (v2f){sel.x, sel.x}).x; // arg x[0] (lane 0 of the group's first wavefront), arg x[sps-2], arg x[sps-1] (lanes 62, 63 of its last)
     }
 
     LORA_W3STAMP(1);
@@ -518,7 +564,54 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
     const bool all = grp == 0 && gwave == 0; // thread 0's wavefront: the replay needs every group's results
     float bvs[NG];
     int bis[NG];
-    w3_group_argmax_first<SF, HV>(bv, bi, ws, slot, grp, gwave, bvs, bis, all);
+    float ffs_F[NG];  // (closed form) F = sum_k ifreq[k] of every group's window
+    bool ffs_ok[NG];  // (closed form) the group's window passed the class / non-zero test
+    { // the group arg-max (first maximum in bin order) and the closed form's sums, one barrier; every thread gets every group's results
+        float (*red)[72] = ws.red[slot];
+        slot ^= 1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) {
+            red[grp][gwave] = bv; ((int *)red[grp])[32 + gwave] = bi;
+            if (FFS) { red[grp][8 + gwave] = ffs_W; ((int *)red[grp])[16 + gwave] = (ffs && valid) ? ffs_zb : 0; }
+        }
+        if (FFS && ffs && valid) {
+            if (gwave == 0 && lane == 0) red[grp][24] = ffs_th;
+            if (gwave == GW - 1 && lane >= 62) red[grp][25 + (lane - 62)] = ffs_th;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            float gv = red[g][0];
+            int gi = ((int *)red[g])[32];
+#pragma unroll
+            for (int w = 1; w < GW; w++) {
+                const float ov = red[g][w];
+                const int oi = ((int *)red[g])[32 + w];
+                if (ov > gv || (ov == gv && oi < gi)) { gv = ov; gi = oi; }
+            }
+            bvs[g] = w3_uni(gv);
+            bis[g] = __builtin_amdgcn_readfirstlane(gi);
+            ffs_F[g] = 0.0f; ffs_ok[g] = false;
+            if constexpr (FFS) {
+                if (ffs) {
+                    float Wg = 0.0f;
+                    int zb = 0x7fffffff;
+#pragma unroll
+                    for (int w = 0; w < GW; w++) { Wg += red[g][8 + w]; zb = min(zb, ((int *)red[g])[16 + w]); }
+                    const float th0 = red[g][24], th2 = red[g][25], the = red[g][26];
+                    float last = the - th2; // ifreq[sps-1] = ifreq[sps-2] (:243)
+                    last = last > 3.14159265358979324f ? last - 6.28318530717958648f : (last < -3.14159265358979324f ? last + 6.28318530717958648f : last);
+                    ffs_F[g] = w3_uni((the - th0) + 6.28318530717958648f * Wg + last);
+                    ffs_ok[g] = w3_ub(zb > 0 && ffs_F[g] == ffs_F[g]);
+                }
+            }
+        }
+    }
     LORA_W3STAMP(6);
 #pragma unroll
     for (int g = 0; g < NG; g++) { s_out[g] = (uint32_t)bis[g]; fine_out[g] = 0; en_out[g] = 0.0f; }
@@ -529,15 +622,50 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
         for (int g = 0; g < NG; g++) en_out[g] = eo[g][0];
     }
     if (!want_fine) return;
-    // fine_sync (:300-338) with search = max(D/4, 2) = 2 -> lags -1, 0, +1
+    // fine_sync (:300-338) with search = max(D/4, 2) = 2 -> lags -1, 0, +1.  First the closed form, for every group in every thread (the decisions are
+    // uniform over the WORKGROUP, so that the sums below - a barrier - are skipped by everybody or by nobody)
+    bool need[NG];
+    bool any_need = false;
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        const bool gval = ((vmask >> g) & 1u) != 0u;
+        bool sure = false;
+        if constexpr (FFS) {
+            const uint32_t sg = s_out[g];
+            const uint32_t bin_g = (sg == 0u && P.demod_mode == 2u) ? 0u : (sg + (uint32_t)N - 1u) % (uint32_t)N;
+            if (gval && ffs_ok[g] && bin_g != (uint32_t)N - 1u) { // (uniform)
+                // ifreq[ka - 1], ifreq[ka] next to the template's step (ka = sps - 8 (bin_idx + 1)) from three samples read again, as the reference forms them
+                const int ka = SPS - 8 * ((int)bin_g + 1);
+                const auto xv = (const __attribute__((address_space(1))) v2f *)xa[g];
+                const v2f xs = xv[ka - 1 + (lane < 2 ? lane : 2)];
+                const float th = lean_atan2_pk((v2f){xs.y, xs.y}, (v2f){xs.x, xs.x}).x;
+                float d = th - dpp_f<kDppWaveRor1>(th);
+                d = d > 3.14159265358979324f ? d - 6.28318530717958648f : (d < -3.14159265358979324f ? d + 6.28318530717958648f : d);
+                const float fb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), 1)); // ifreq[ka - 1]
+                const float fa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), 2)); // ifreq[ka]
+                const float D0 = P.ffs_alpha * ffs_F[g] + P.ffs_jump * fa, D1 = P.ffs_alpha * ffs_F[g] + P.ffs_jump * fb; // c(0) - c(-1), c(1) - c(0)
+                sure = w3_ub(D0 > P.ffs_tol && D1 < -P.ffs_tol); // c(0) above c(-1), c(1) below c(0), both beyond the table's noise: lag 0 whatever the signs
+            }
+        }
+        need[g] = gval && !sure;
+        any_need = any_need || need[g];
+    }
+    if (!any_need) { // (uniform over the workgroup)
+        LORA_W3STAMP(7);
+        LORA_W3STAMP(8);
+        return;
+    }
+    bool need_mine = need[0];
+#pragma unroll
+    for (int g = 1; g < NG; g++) need_mine = grp == g ? need[g] : need_mine;
     float cs[3] = {0.f, 0.f, 0.f};
-    // this thread's taps.  LATE: the window's ifreq from a second read of the window (SF12, and every ZM evaluation); Z: the values next to a sample of exactly
-    // zero as the reference forms them (w3_ifreq16 ZM).  (Re-evaluating a poisoned window's taps inside the wavefront, ahead of the group sums, instead of in a ZM
-    // round was measured as well: the same to +-1 %, profiles/r05_ab_zero_samples.txt.)
-    auto tap_sums = [&](auto late_t, auto z_t) {
-        constexpr bool LATE = decltype(late_t)::value, Z = decltype(z_t)::value;
+    // this thread's taps: the window's ifreq from a second read of the window.  Z: the values next to a sample of exactly zero as the reference forms them
+    // (w3_ifreq16 ZM).  (Re-evaluating a poisoned window's taps inside the wavefront, ahead of the group sums, instead of in a ZM round was measured as well:
+    // the same to +-1 %, profiles/r05_ab_zero_samples.txt.)
+    auto tap_sums = [&](auto z_t) {
+        constexpr bool Z = decltype(z_t)::value;
         cs[0] = 0.f; cs[1] = 0.f; cs[2] = 0.f;
-        if (!valid) return;
+        if (!valid || !need_mine) return;
         uint32_t s = s_out[0];
 #pragma unroll
         for (int g = 1; g < NG; g++) s = (grp == g) ? s_out[g] : s;
@@ -555,7 +683,7 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
                 v0[c] = w3_ld1(vb, 4u * nb, (uint32_t)(c * CH * 4 - 4)); v1[c] = w3_ld1(vb, 4u * nb, (uint32_t)(c * CH * 4)); v2[c] = w3_ld1(vb, 4u * nb, (uint32_t)(c * CH * 4 + 4));
             }
             float fl[16];
-            if constexpr (LATE) { // second read of the window
+            { // second read of the window
                 const uint32_t ob = 8u * nb;
                 v2f a[16], ap[16];
 #pragma unroll
@@ -568,17 +696,17 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
             }
 #pragma unroll
             for (int c = 0; c < 16; c++) {
-                const float fk = LATE ? fl[c] : f[LATE_F ? 0 : p][c];
+                const float fk = fl[c];
                 cs[0] += fk * v0[c]; cs[1] += fk * v1[c]; cs[2] += fk * v2[c];
             }
             if (p == PAIRS - 1 && t == TG - 1) { // ifreq[sps-1] = ifreq[sps-2] (:243): the duplicated tap at k = sps-1
-                const float flast = LATE ? fl[15] : f[LATE_F ? 0 : p][15];
+                const float flast = fl[15];
                 const uint32_t ko = 4u * (uint32_t)(SPS - 1);
                 cs[0] += flast * w3_ld1(vb, ko, 0u); cs[1] += flast * w3_ld1(vb, ko, 4u); cs[2] += flast * w3_ld1(vb, ko, 8u);
             }
         }
     };
-    tap_sums(std::integral_constant<bool, LATE_F>{}, std::integral_constant<bool, ZM>{});
+    tap_sums(std::integral_constant<bool, ZM>{});
     LORA_W3STAMP(7);
     float co[NG][3];
     w3_group_sums<SF, 3, HV>(cs, ws, slot, grp, gwave, co, all);
@@ -592,7 +720,7 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
         if (co[g][1] > mx) { mx = co[g][1]; lag = 0; }
         if (co[g][2] > mx) { mx = co[g][2]; lag = 1; }
         if (!ZM && poisoned(co[g][0] + co[g][1] + co[g][2])) lag = -kFinePoison; // (every group's sums reach thread 0's wavefront, whose replay looks at them)
-        fine_out[g] = __builtin_amdgcn_readfirstlane(-lag);
+        fine_out[g] = need[g] ? __builtin_amdgcn_readfirstlane(-lag) : 0;
     }
 }
 
@@ -1230,13 +1358,16 @@ __device__ __forceinline__ void w3_touch(const float2 *X, int64_t first_item, in
 #define LORA_W3_ZM_ATTR __attribute__((noinline)) // (inlined into the round loop it cost SF9-SF12 another 1.5-4 %: profiles/r05_ab_zero_samples.txt)
 #endif
 template <int SF, int HV>
-__device__ LORA_W3_ZM_ATTR W3DemodOut w3_demod_round_zm(W3DemodArgs DA, W3Lds<SF, HV> L, const float2 *xg, bool dvalid, bool want_energy, int slot)
+__device__ LORA_W3_ZM_ATTR W3DemodOut w3_demod_round_zm(W3DemodArgs DA, W3Lds<SF, HV> L, const float2 *x0, int64_t gstride /* group g's window: x0 + g gstride */, uint32_t vmask, bool want_energy, int slot)
 {
     constexpr int NG = W3Geom<SF, HV>::NG;
     uint32_t sq[NG];
     int32_t fq[NG];
     float eq[NG];
-    w3_demod_round<SF, HV, true>(DA, L, xg, dvalid, want_energy, slot, sq, fq, eq);
+    const float2 *xa[NG];
+#pragma unroll
+    for (int g = 0; g < NG; g++) xa[g] = x0 + (int64_t)g * gstride;
+    w3_demod_round<SF, HV, true>(DA, L, xa, vmask, want_energy, slot, sq, fq, eq);
     W3DemodOut o{};
 #pragma unroll
     for (int g = 0; g < NG; g++) { o.s[g] = sq[g]; o.fine[g] = fq[g]; o.en[g] = eq[g]; }
@@ -1273,7 +1404,7 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
     const bool t0 = threadIdx.x == 0;
     const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x / G::TG);
     int slot = 0;
-    const W3DemodArgs DA{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode};
+    const W3DemodArgs DA{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode, P.ffs_on, P.ffs_alpha, P.ffs_jump, P.ffs_tol};
 
     WaveTabs WT{};
     if constexpr (WFFT) WT = wave_tabs_to_lds<SF>(P, smem + G::kWfftScratch, (uint32_t)T); // (visible behind the round loop's first barrier)
@@ -1526,16 +1657,24 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
                     }
                 }
             } else {
-            const bool dvalid = gvalid && grp < plan_n_win;
+            // every group's window and whether it has one (uniform): group g reads at pos + g sps while that lies inside the data (:91), up to plan_n_win windows
+            uint32_t dmask = 0u;
+            const float2 *xall[NG];
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                const bool gv = pos + (int64_t)(g + 2) * sps <= n_items && g < plan_n_win;
+                dmask |= gv ? (1u << g) : 0u;
+                xall[g] = X + (gv ? pos + (int64_t)g * sps : pos);
+            }
             if (plan_z) { // (uniform) a round of ZM evaluations: a window of the previous round holds a sample of exactly zero
-                const W3DemodOut zo = w3_demod_round_zm<SF, HV>(DA, L, xg, dvalid, P.implicit != 0u, slot);
+                const W3DemodOut zo = w3_demod_round_zm<SF, HV>(DA, L, X + pos, (int64_t)sps, dmask, P.implicit != 0u, slot);
 #pragma unroll
                 for (int g = 0; g < NG; g++) {
                     sq[g] = (uint32_t)__builtin_amdgcn_readfirstlane((int)zo.s[g]); fq[g] = __builtin_amdgcn_readfirstlane(zo.fine[g]); eq[g] = w3_uni(zo.en[g]);
                 }
                 slot = __builtin_amdgcn_readfirstlane(zo.slot);
             } else
-            w3_demod_round<SF, HV>(DA, L, xg, dvalid, P.implicit != 0u, slot, sq, fq, eq); // fq = kFinePoison: see W2Plan.zmode
+            w3_demod_round<SF, HV>(DA, L, xall, dmask, P.implicit != 0u, slot, sq, fq, eq); // fq = kFinePoison: see W2Plan.zmode
             }
             if (t0) {
                 bool zreq = false;
@@ -1734,15 +1873,22 @@ __global__ __launch_bounds__((W3Geom<SF, HV>::T), (W3Geom<SF, HV>::T512 ? 2 : 4)
     __syncthreads();
     int slot = 0;
     const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x / G::TG);
-    const W3DemodArgs DA{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode};
+    const W3DemodArgs DA{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode, P.ffs_on, P.ffs_alpha, P.ffs_jump, P.ffs_tol};
     for (uint32_t s0 = blockIdx.x * G::NG; s0 < n; s0 += gridDim.x * G::NG) {
-        const bool valid = s0 + (uint32_t)grp < n;
         uint32_t b[G::NG];
         int32_t fs[G::NG];
         float en[G::NG];
         long long stamps[9];
         static_assert(!GRAD, "the gradient demodulator has a kernel of its own: demod_symbols_w3_grad_kernel");
-        w3_demod_round<SF, HV>(DA, L, iq + offsets[valid ? s0 + grp : s0], valid, false, slot, b, fs, en, stamps_out ? stamps : nullptr);
+        const float2 *xa[G::NG]; // every group's window (uniform)
+        uint32_t vmask = 0u;
+#pragma unroll
+        for (int g = 0; g < G::NG; g++) {
+            const bool gv = s0 + (uint32_t)g < n;
+            vmask |= gv ? (1u << g) : 0u;
+            xa[g] = iq + offsets[gv ? s0 + (uint32_t)g : s0];
+        }
+        w3_demod_round<SF, HV>(DA, L, xa, vmask, false, slot, b, fs, en, stamps_out ? stamps : nullptr);
         if (stamps_out && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && s0 == blockIdx.x * G::NG + gridDim.x * G::NG) // (second round of block 0: every wavefront's stamps)
             for (int i = 0; i < 9; i++) stamps_out[(threadIdx.x >> 6) * 9 + i] = stamps[i];
         int32_t *fs_all = L.ws->sh.ibuf; // every group's d_fine_sync (the demodulator hands all groups' results to thread 0's wavefront only)
@@ -1758,7 +1904,7 @@ __global__ __launch_bounds__((W3Geom<SF, HV>::T), (W3Geom<SF, HV>::T512 ? 2 : 4)
 #pragma unroll
             for (int g = 0; g < G::NG; g++) pz = pz || __builtin_amdgcn_readfirstlane(fs_all[g]) == kFinePoison;
             if (pz) { // (uniform over the workgroup)
-                w3_demod_round<SF, HV, true>(DA, L, iq + offsets[valid ? s0 + grp : s0], valid, false, slot, b, fs, en, nullptr);
+                w3_demod_round<SF, HV, true>(DA, L, xa, vmask, false, slot, b, fs, en, nullptr);
                 if (threadIdx.x == 0) {
                     for (int g = 0; g < G::NG; g++) {
                         if (s0 + (uint32_t)g < n) { bins[s0 + g] = b[g]; if (fine) fine[s0 + g] = fs[g]; }
@@ -1771,21 +1917,22 @@ __global__ __launch_bounds__((W3Geom<SF, HV>::T), (W3Geom<SF, HV>::T512 ? 2 : 4)
         if (alt.shift) { // second reads (DemodAlt): the successors of the symbols that moved the symbol clock, that far further on
 #pragma unroll
             for (int g = 0; g < G::NG; g++) fs[g] = __builtin_amdgcn_readfirstlane(fs_all[g]);
-            bool any = false;
-            int64_t mine = -1; // this group's second window
+            const float2 *xa2[G::NG]; // the groups' second windows
+            uint32_t vmask2 = 0u;
 #pragma unroll
             for (int g = 0; g < G::NG; g++) {
+                xa2[g] = iq + offsets[s0];
                 if (s0 + (uint32_t)g + 1u >= n || fs[g] == 0) continue; // (fs: uniform over the workgroup)
                 const int64_t o0 = offsets[s0 + g], o1 = offsets[s0 + g + 1];
                 const int64_t a = o1 + (int64_t)fs[g];
                 if (o1 != o0 + (int64_t)G::SPS || a < 0 || a > alt.max_start) continue;
-                any = true;
-                if (g == grp) mine = a;
+                vmask2 |= 1u << g;
+                xa2[g] = iq + a;
             }
-            if (any) {
+            if (vmask2 != 0u) {
                 uint32_t b2[G::NG];
                 int32_t f2[G::NG];
-                w3_demod_round<SF, HV>(DA, L, iq + (mine >= 0 ? mine : offsets[s0]), mine >= 0, false, slot, b2, f2, en, nullptr);
+                w3_demod_round<SF, HV>(DA, L, xa2, vmask2, false, slot, b2, f2, en, nullptr);
                 if (threadIdx.x == 0) {
                     for (int g = 0; g < G::NG; g++) {
                         if (s0 + (uint32_t)g + 1u >= n || fs[g] == 0) continue;
@@ -1812,7 +1959,7 @@ template <int SF>
 __global__ __launch_bounds__(512, 2) void demod_symbols_w3_grad_kernel(DevParams P, const float2 *iq, const int64_t *offsets, uint32_t n, uint32_t *bins, int32_t *fine, DemodAlt alt)
 {
     constexpr int SPS = 8 << SF;
-    const W3DemodArgs DA{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode};
+    const W3DemodArgs DA{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode, P.ffs_on, P.ffs_alpha, P.ffs_jump, P.ffs_tol};
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *fcache = reinterpret_cast<float *>(smem) + wave * (kW3GradCacheChunks * 1024);
