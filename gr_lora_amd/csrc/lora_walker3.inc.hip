@@ -797,10 +797,29 @@ __device__ __forceinline__ void w3_wave_window_grad(const W3DemodArgs &P, const 
     int bi = 0x7fffffff;
     float gs = 0.0f, prev_perm = 0.0f; // gs carries the poison of a zero sample when there is no fine_sync sum to carry it
     const int m = lane >> 3, perm_addr = ((lane - 8) & 63) << 2;
+    // closed-form fine_sync (wave_demod_symbol FMODE 2 explains the rule): here the ifreq values exist anyway, so F = sum_k ifreq[k] is one add per sample and
+    // the class bound one max; the two values next to the template's step are formed again behind the bin.  A window it vouches for skips pass B.
+    constexpr int CLS = kFfsClass<SF>;
+    const bool ffs = !ZM && P.enable_fine_sync != 0u && P.ffs_on != 0u; // (uniform)
+    float fsum = 0.0f, amax = 0.0f;
     const float e = pass([&](int q, const float (&f)[16]) {
         if (q < NCC) { // (uniform) kept for pass B
 #pragma unroll
             for (int j = 0; j < 16; j++) fc[(q * 16 + j) * 64 + lane] = f[j];
+        }
+        if (ffs) { // (uniform)
+#pragma unroll
+            for (int j = 0; j < 16; j++) fsum += f[j];
+            if constexpr (CLS != 0) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    float am = fabsf(f[j]);
+                    // (the first three and the last five ifreq values - the products next to the window's ends - are not held to the class: wave_demod_symbol)
+                    if (j == 0) am = (q == 0 && lane < 3) ? 0.0f : am;
+                    if (j == 15) am = (q == NCH - 1 && lane >= 59) ? 0.0f : am;
+                    amax = fmaxf(amax, am);
+                }
+            }
         }
 #pragma unroll
         for (int j = 0; j < 16; j++) {
@@ -826,6 +845,22 @@ __device__ __forceinline__ void w3_wave_window_grad(const W3DemodArgs &P, const 
     if (P.enable_fine_sync == 0u) {
         if (!ZM && poisoned(wave_sum_u(gs))) fine_out = kFinePoison;
         return;
+    }
+    if (ffs && bin_idx != (uint32_t)N - 1u) { // (uniform)
+        const float F = wave_sum_u(fsum); // (NaN: a sample of exactly zero - not vouched for; pass B then reports the poison)
+        const float amx = CLS != 0 ? wave_max_nonneg_u(amax) : 0.0f;
+        constexpr float kBound = CLS == 1 ? 1.57079632679489662f : 0.46364760900080609f; // pi / 2, atan(1/2): what ffs_tol is computed for (lora_hip_create)
+        if (F == F && (CLS == 0 || amx < kBound)) {
+            const int ka = SPS - 8 * ((int)bin_idx + 1);
+            const v2f xs = xv[ka - 1 + (lane < 2 ? lane : 2)];
+            const float th = lean_atan2_pk((v2f){xs.y, xs.y}, (v2f){xs.x, xs.x}).x;
+            float d = th - dpp_f<kDppWaveRor1>(th);
+            d = d > 3.14159265358979324f ? d - 6.28318530717958648f : (d < -3.14159265358979324f ? d + 6.28318530717958648f : d);
+            const float fb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), 1)); // ifreq[ka - 1]
+            const float fa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), 2)); // ifreq[ka]
+            const float D0 = P.ffs_alpha * F + P.ffs_jump * fa, D1 = P.ffs_alpha * F + P.ffs_jump * fb; // c(0) - c(-1), c(1) - c(0)
+            if (D0 > P.ffs_tol && D1 < -P.ffs_tol) return; // (uniform) lag 0 whatever the signs of the sums
+        }
     }
     // pass B: fine_sync (:300-338), lags -1, 0, +1: c_lag = sum_k f[k] v[(bin_idx + 1) 8 + sps + lag + k]
     const float *__restrict__ vp = P.up_ifreq_v + ((int)(bin_idx + 1u) * 8 + SPS) + (lane - 1);

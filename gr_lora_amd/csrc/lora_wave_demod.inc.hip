@@ -712,6 +712,36 @@ __device__ __forceinline__ void wave_demod_symbol_grad(const DevParams &P, const
         if (poisoned(wave_sum_u(gs))) bin_out = kPoisonBin; // (a sample of exactly zero in the window)
         return;
     }
+    // the closed form first (wave_demod_symbol FMODE 2 explains the rule): the ifreq values are in registers, so F = sum_k ifreq[k] is one add per sample;
+    // a window it vouches for - lag 0 - skips the three correlations
+    if (P.ffs_on != 0u && bin_idx != (uint32_t)N - 1u) { // (uniform; the ZM instantiation has returned above)
+        constexpr int CLS = kFfsClass<SF>;
+        float fsum = 0.0f, amax = 0.0f;
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            fsum += f[j];
+            if constexpr (CLS != 0) {
+                float am = fabsf(f[j]);
+                if (j == 0) am = lane < 3 ? 0.0f : am;         // (the ifreq values next to the window's ends are not held to the class)
+                if (j == J - 1) am = lane >= 59 ? 0.0f : am;
+                amax = fmaxf(amax, am);
+            }
+        }
+        const float F = wave_sum_u(fsum); // (NaN: a sample of exactly zero - not vouched for; the sums below then report the poison)
+        const float amx = CLS != 0 ? wave_max_nonneg_u(amax) : 0.0f;
+        constexpr float kBound = CLS == 1 ? 1.57079632679489662f : 0.46364760900080609f;
+        if (F == F && (CLS == 0 || amx < kBound)) {
+            const int ka = SPS - 8 * ((int)bin_idx + 1);
+            const v2f xs = xv[ka - 1 + (lane < 2 ? lane : 2)];
+            const float th = lean_atan2_pk((v2f){xs.y, xs.y}, (v2f){xs.x, xs.x}).x;
+            float d = th - dpp_f<kDppWaveRor1>(th);
+            d = d > 3.14159265358979324f ? d - 6.28318530717958648f : (d < -3.14159265358979324f ? d + 6.28318530717958648f : d);
+            const float fb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), 1)); // ifreq[ka - 1]
+            const float fa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), 2)); // ifreq[ka]
+            const float D0 = P.ffs_alpha * F + P.ffs_jump * fa, D1 = P.ffs_alpha * F + P.ffs_jump * fb; // c(0) - c(-1), c(1) - c(0)
+            if (D0 > P.ffs_tol && D1 < -P.ffs_tol) return; // (uniform) lag 0 whatever the signs of the sums
+        }
+    }
     // fine_sync (:300-338), lags -1, 0, +1: c_lag = sum_k f[k] v[(bin_idx + 1) 8 + sps + lag + k], k = 64 j + lane
     const float *__restrict__ vp = Tv + ((int)(bin_idx + 1u) * 8 + SPS) + (lane - 1);
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
