@@ -24,7 +24,7 @@ EXPORTS = [
     "lora_hip_abi_version", "lora_hip_strerror", "lora_hip_last_error", "lora_hip_create", "lora_hip_destroy",
     "lora_hip_get_geometry", "lora_hip_set_sf", "lora_hip_set_samp_rate", "lora_hip_work", "lora_hip_flush",
     "lora_hip_decode_device", "lora_hip_frames_available", "lora_hip_poll_frame", "lora_hip_drain_frames", "lora_hip_drain_slots", "lora_hip_demod_symbols_device", "lora_hip_demod_symbols_ex_device",
-    "lora_hip_last_timing", "lora_hip_last_plan", "lora_hip_last_payload_pass", "lora_hip_gap_starts_device", "lora_hip_decode_device_begin", "lora_hip_decode_device_end", "lora_hip_decode_device_prepass", "lora_hip_trace", "lora_hip_trace_clear", "lora_hip_check_frame", "lora_hip_estimate_cfo_device", "lora_hip_ref_ifreq_device",
+    "lora_hip_last_timing", "lora_hip_last_plan", "lora_hip_get_table", "lora_hip_last_payload_pass", "lora_hip_gap_starts_device", "lora_hip_decode_device_begin", "lora_hip_decode_device_end", "lora_hip_decode_device_prepass", "lora_hip_trace", "lora_hip_trace_clear", "lora_hip_check_frame", "lora_hip_estimate_cfo_device", "lora_hip_ref_ifreq_device",
     "lora_hip_set_stream_latency", "lora_hip_stream_info", "lora_hip_walker_kernel_name", "lora_hip_window_stats_device", "lora_hip_detect_preambles_device", "lora_hip_decode_at_headers_device",
     "lora_hip_mux_create", "lora_hip_mux_destroy", "lora_hip_mux_work", "lora_hip_mux_flush", "lora_hip_mux_set_latency", "lora_hip_mux_set_max_ahead", "lora_hip_mux_frames_available",
     "lora_hip_mux_poll_frame", "lora_hip_mux_passes", "lora_hip_mux_last_error",
@@ -153,6 +153,8 @@ def load():
     L.lora_hip_estimate_cfo_device.restype = C.c_int
     L.lora_hip_ref_ifreq_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float), vp]
     L.lora_hip_ref_ifreq_device.restype = C.c_int
+    L.lora_hip_get_table.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_size_t)]
+    L.lora_hip_get_table.restype = C.c_int
     L.lora_hip_window_stats_device.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(WindowStats), vp]
     L.lora_hip_detect_preambles_device.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_uint32, C.c_float, C.POINTER(Preamble), C.c_size_t, C.POINTER(C.c_size_t), vp]
     L.lora_hip_decode_at_headers_device.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_uint32, C.POINTER(Preamble), C.c_size_t, vp]
@@ -426,6 +428,14 @@ class Handle:
         b, n = C.c_uint32(0), C.c_uint32(0)
         self._check(self.L.lora_hip_last_plan(self.h, C.byref(b), C.byref(n)))
         return bool(b.value), int(n.value)
+
+    def table(self, which: int) -> np.ndarray:
+        """The handle's ideal-chirp table `which` (0 downchirp, 1 upchirp, 2 downchirp ifreq, 3 upchirp ifreq, 4 d_upchirp_ifreq_v + guard) as float32: lora_hip_get_table."""
+        n = C.c_size_t()
+        self._check(self.L.lora_hip_get_table(self.h, which, None, 0, C.byref(n)))
+        out = np.empty(n.value, np.float32)
+        self._check(self.L.lora_hip_get_table(self.h, which, out.ctypes.data_as(C.POINTER(C.c_float)), n.value, C.byref(n)))
+        return out
 
     def payload_pass(self):
         """dict(packets, moved, rerun, rounds, symbols, ms) of the last pass's payload pass (all zero unless it ran decoupled): lora_hip_last_payload_pass."""

@@ -108,6 +108,8 @@ struct lora_hip_decoder {
     float *d_wave_tabs = nullptr;
     float2 *d_w3_tw = nullptr, *d_w3_ctab = nullptr;
     float *d_up_ifreq = nullptr, *d_down_ifreq = nullptr, *d_up_ifreq_v = nullptr;
+    std::vector<float2> h_up;          // d_upchirp (:160): no kernel reads it; kept for lora_hip_get_table
+    size_t n_up_ifreq_v = 0;           // floats in d_up_ifreq_v (3 sps + the guard tail)
     // per-pass buffers
     DevBuf<Job> d_jobs;
     DevBuf<JobResult> d_results;
@@ -185,7 +187,7 @@ struct lora_hip_decoder {
     const char *last_kernel = nullptr; // name of the walker kernel the last pass's main launch ran
     uint32_t last_kernel_jobs = 0;     // ... and its job count (reset when a pass begins)
     uint32_t resident_slots = 0;
-    uint32_t resident_slots_alt = ~0u; // slots of the full-size kernel where a half-size variant exists (walker3 SF9 / SF10), else 0
+    uint32_t resident_slots_alt = ~0u; // walker_resident_slots_full: the one-workgroup-per-CU slot count where the kernel family has a second geometry (walker3 SF9 / SF10: the full-size kernel beside the half-size one; walker2 SF7 / SF8: the CU count - the plan for passes with fewer bursts than two-per-CU slots), else 0
     uint32_t eager_recs = 4;
     uint32_t last_plan_burst = 0, last_plan_segments = 0;
     // decoupled passes (lora_stitch.hpp payload_round): header-only segment jobs + the payload pass
@@ -368,6 +370,7 @@ lora_hip_status build_tables(lora_hip_decoder *h)
     if ((s = upload(h, &h->d_up_ifreq, up_ifreq)) != LORA_HIP_OK) return s;
     if ((s = upload(h, &h->d_down_ifreq, down_ifreq)) != LORA_HIP_OK) return s;
     if ((s = upload(h, &h->d_up_ifreq_v, up3)) != LORA_HIP_OK) return s;
+    h->h_up = up; h->n_up_ifreq_v = up3.size();
     P.down = h->d_down; P.twN = h->d_twN; P.tws = h->d_tws;
     P.wave_tabs = nullptr;
     if (D == 8u && wave_tables_floats(c.sf) != 0u) { // packed twiddle block of the wave demodulator
@@ -738,7 +741,8 @@ static lora_hip_status payload_launch_round(lora_hip_decoder *h, const float2 *d
     if (n_sym) {
         HIP_TRY(h, hipMemcpyAsync(h->d_offsets.p, h->p_pay_off.p, n_sym * sizeof(int64_t), hipMemcpyHostToDevice, st));
         DemodAlt ar{alt.shift ? alt.shift + ps.used : nullptr, alt.bins + ps.used, alt.fine + ps.used, alt.max_start};
-        if (ar.shift) HIP_TRY(h, hipMemsetAsync(ar.shift, 0, n_sym * sizeof(int32_t), st));
+        // (DemodAlt.shift needs no clearing: every entry is written by the symbol kernel - the wavefront / round of symbol s owns entry s + 1 - whether a second read was taken or not;
+        //  until round 6 two hipMemsetAsync fills of a few hundred KB were 11.6 % of a config-4 pass's device time)
         if (launch_demod_symbols(h->P, d_iq, h->d_offsets.p, (uint32_t)n_sym, (int)h->P.demod_mode, h->d_bins.p + ps.used, h->d_fine.p + ps.used, nullptr, st, has_alt ? &ar : nullptr) != 0)
             return fail(h, LORA_HIP_ERR_HIP, "payload pass: symbol launch failed: %s", hipGetErrorString(hipGetLastError()));
     }
@@ -1007,6 +1011,29 @@ void lora_hip_destroy(lora_hip_decoder_t *h)
     if (h->pre_stream) (void)hipStreamDestroy(h->pre_stream);
     if (h->pay_stream) (void)hipStreamDestroy(h->pay_stream);
     delete h;
+}
+
+lora_hip_status lora_hip_get_table(const lora_hip_decoder_t *h, int which, float *buf, size_t cap_floats, size_t *n_floats)
+{
+    if (!h) return LORA_HIP_ERR_ARG;
+    const size_t sps = h->P.sps;
+    const void *src = nullptr;
+    size_t n = 0;
+    bool on_device = true;
+    switch (which) {
+    case 0: src = h->d_down; n = 2 * sps; break;
+    case 1: src = h->h_up.data(); n = 2 * sps; on_device = false; break;
+    case 2: src = h->d_down_ifreq; n = sps; break;
+    case 3: src = h->d_up_ifreq; n = sps; break;
+    case 4: src = h->d_up_ifreq_v; n = h->n_up_ifreq_v; break;
+    default: return LORA_HIP_ERR_ARG;
+    }
+    if (n_floats) *n_floats = n;
+    if (!buf) return LORA_HIP_OK;
+    if (cap_floats < n || !src) return LORA_HIP_ERR_ARG;
+    if (!on_device) { memcpy(buf, src, n * sizeof(float)); return LORA_HIP_OK; }
+    if (hipSetDevice(h->device) != hipSuccess || hipMemcpy(buf, src, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return LORA_HIP_ERR_HIP;
+    return LORA_HIP_OK;
 }
 
 lora_hip_status lora_hip_get_geometry(const lora_hip_decoder_t *h, uint32_t *sps, uint32_t *bins, uint32_t *decim)
@@ -1746,7 +1773,7 @@ lora_hip_status lora_hip_demod_symbols_ex_device(lora_hip_decoder_t *h, const vo
     if (demod != 0) P.demod_mode = (uint32_t)demod; // FFT vs FFT_COMPAT decides the bin fine_sync is run with
     if (launch_demod_symbols(P, (const float2 *)d_iq, h->d_offsets.p, (uint32_t)n, demod, h->d_bins.p, d_fine,
                              h->P.ifreq_in_lds_1 ? nullptr : h->d_scratch.p, st) != 0)
-        return fail(h, fine_out ? LORA_HIP_ERR_BAD_CONFIG : LORA_HIP_ERR_HIP, "demod launch failed (fine_sync output needs SF7/SF8 at decimation 8 and an FFT demodulator): %s",
+        return fail(h, fine_out ? LORA_HIP_ERR_BAD_CONFIG : LORA_HIP_ERR_HIP, "demod launch failed (fine_sync output needs SF7 .. SF12 at decimation 8): %s",
                     hipGetErrorString(hipGetLastError()));
     HIP_TRY(h, hipMemcpyAsync(bins_out, h->d_bins.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     if (fine_out) HIP_TRY(h, hipMemcpyAsync(fine_out, d_fine, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));

@@ -709,6 +709,7 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
         pguard.armed = true;
         s = payload_begin(env, streams, ctx, R1, pround);
         if (s != 0) return s;
+        pguard.armed = pround.open; // (a pass without a header-only record launched nothing: no stream to drain, and the staging vectors keep their capacity)
     }
     env.set_skip_payload(false);
     struct Probe { uint32_t stream; size_t target; Cursor start; int job; int tail_of; }; // job: index into pjobs, or -1 with tail_of = the job whose tail it is

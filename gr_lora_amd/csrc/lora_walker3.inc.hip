@@ -1970,15 +1970,18 @@ __global__ __launch_bounds__((W3Geom<SF, HV>::T), (W3Geom<SF, HV>::T512 ? 2 : 4)
                 w3_demod_round<SF, HV>(DA, L, xa2, vmask2, false, slot, b2, f2, en, nullptr);
                 if (threadIdx.x == 0) {
                     for (int g = 0; g < G::NG; g++) {
-                        if (s0 + (uint32_t)g + 1u >= n || fs[g] == 0) continue;
-                        const int64_t o0 = offsets[s0 + g], o1 = offsets[s0 + g + 1];
-                        const int64_t a = o1 + (int64_t)fs[g];
-                        if (o1 != o0 + (int64_t)G::SPS || a < 0 || a > alt.max_start) continue;
-                        if (f2[g] == kFinePoison) continue; // (a zero sample in the second window: no second read on offer - the walk asks for this shift as a read of its own)
-                        alt.bins[s0 + g + 1] = b2[g]; alt.fine[s0 + g + 1] = f2[g]; alt.shift[s0 + g + 1] = fs[g];
+                        if (!((vmask2 >> g) & 1u)) continue;
+                        if (f2[g] == kFinePoison) { vmask2 &= ~(1u << g); continue; } // (a zero sample in the second window: no second read on offer - the walk asks for this shift as a read of its own)
+                        alt.bins[s0 + g + 1] = b2[g]; alt.fine[s0 + g + 1] = f2[g];
                     }
                 }
                 __syncthreads();
+            }
+            // DemodAlt.shift[s + 1] is written by the round that demodulated symbol s, taken or not (and shift[0] by the first round): the caller clears nothing
+            if (threadIdx.x == 0) {
+                for (int g = 0; g < G::NG; g++)
+                    if (s0 + (uint32_t)g + 1u < n) alt.shift[s0 + g + 1] = ((vmask2 >> g) & 1u) ? fs[g] : 0;
+                if (s0 == 0u) alt.shift[0] = 0;
             }
         }
     }
@@ -2006,6 +2009,7 @@ __global__ __launch_bounds__(512, 2) void demod_symbols_w3_grad_kernel(DevParams
         w3_wave_window_grad<SF>(DA, iq + o0, false, b, fs, en, fcache);
         if (fs == kFinePoison) w3_wave_window_grad<SF, true>(DA, iq + o0, false, b, fs, en, fcache); // (uniform over the wavefront)
         if (lane == 0u) { bins[s] = b; if (fine) fine[s] = fs; }
+        int32_t sh = 0; // the shift this wavefront's second read of its successor was made at (0: none)
         if (alt.shift && fs != 0 && s + 1u < n) {
             const int64_t o1 = offsets[s + 1u], a = o1 + (int64_t)fs;
             if (o1 == o0 + (int64_t)SPS && a >= 0 && a <= alt.max_start) {
@@ -2013,9 +2017,12 @@ __global__ __launch_bounds__(512, 2) void demod_symbols_w3_grad_kernel(DevParams
                 int32_t f2;
                 w3_wave_window_grad<SF>(DA, iq + a, false, b2, f2, en, fcache);
                 if (f2 == kFinePoison) w3_wave_window_grad<SF, true>(DA, iq + a, false, b2, f2, en, fcache);
-                if (lane == 0u) { alt.bins[s + 1u] = b2; alt.fine[s + 1u] = f2; alt.shift[s + 1u] = fs; }
+                if (lane == 0u) { alt.bins[s + 1u] = b2; alt.fine[s + 1u] = f2; }
+                sh = fs;
             }
         }
+        // DemodAlt.shift[s + 1] is this wavefront's to write, taken or not (and shift[0] the first one's): the caller clears nothing
+        if (alt.shift && lane == 0u) { if (s + 1u < n) alt.shift[s + 1u] = sh; if (s == 0u) alt.shift[0] = 0; }
     }
 }
 

@@ -869,6 +869,7 @@ __global__ __launch_bounds__(512, OCC) void demod_symbols_wave_kernel(DevParams 
         wave_demod_symbol<SF, kWaveFmode<SF>>(P, T, iq + o0, b, fs);
         if (b == kPoisonBin) wave_demod_symbol<SF, 1, true>(P, T, iq + o0, b, fs); // (uniform) a window with a sample of exactly zero
         if (lane == 0u) { bins[s] = b; if (fine) fine[s] = fs; }
+        int32_t sh = 0; // the shift this wavefront's second read of its successor was made at (0: none)
         if (alt.shift && fs != 0 && s + 1u < n) {
             const int64_t o1 = offsets[s + 1u], a = o1 + (int64_t)fs;
             if (o1 == o0 + (int64_t)SPS && a >= 0 && a <= alt.max_start) {
@@ -876,8 +877,11 @@ __global__ __launch_bounds__(512, OCC) void demod_symbols_wave_kernel(DevParams 
                 int32_t f2;
                 wave_demod_symbol<SF, kWaveFmode<SF>>(P, T, iq + a, b2, f2);
                 if (b2 == kPoisonBin) wave_demod_symbol<SF, 1, true>(P, T, iq + a, b2, f2);
-                if (lane == 0u) { alt.bins[s + 1u] = b2; alt.fine[s + 1u] = f2; alt.shift[s + 1u] = fs; }
+                if (lane == 0u) { alt.bins[s + 1u] = b2; alt.fine[s + 1u] = f2; }
+                sh = fs;
             }
         }
+        // DemodAlt.shift[s + 1] is this wavefront's to write, taken or not (and shift[0] the first one's): the caller clears nothing
+        if (alt.shift && lane == 0u) { if (s + 1u < n) alt.shift[s + 1u] = sh; if (s == 0u) alt.shift[0] = 0; }
     }
 }

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LORA_HIP_ABI_VERSION 3   /* 3: LORA_HIP_FLAG_FAST_SYNC (strict SYNC is the default), lora_hip_ref_ifreq_device; 2: lora_hip_set_stream_latency, lora_hip_stream_info, lora_hip_walker_kernel_name, lora_hip_window_stats_device, lora_hip_detect_preambles_device, lora_hip_decode_at_headers_device, lora_hip_mux_* */
+#define LORA_HIP_ABI_VERSION 4   /* 4: lora_hip_get_table; 3: LORA_HIP_FLAG_FAST_SYNC (strict SYNC is the default), lora_hip_ref_ifreq_device; 2: lora_hip_set_stream_latency, lora_hip_stream_info, lora_hip_walker_kernel_name, lora_hip_window_stats_device, lora_hip_detect_preambles_device, lora_hip_decode_at_headers_device, lora_hip_mux_* */
 
 typedef enum lora_hip_status {
     LORA_HIP_OK = 0,
@@ -279,6 +279,12 @@ lora_hip_status lora_hip_last_payload_pass(const lora_hip_decoder_t *h, uint32_t
  * in the gaps between bursts found by the energy-envelope pre-pass, 0 for the fixed grid (configured segment length,
  * sparse or weak traffic, tracing); *segments = segments = workgroups of the main launch.                      */
 lora_hip_status lora_hip_last_plan(const lora_hip_decoder_t *h, uint32_t *burst_aware, uint32_t *segments);
+/* The handle's ideal-chirp tables (diagnostics; ABI 4): what build_ideal_chirps (decoder_impl.cc:141-175) leaves in d_downchirp (which = 0, 2 sps floats:
+ * re, im), d_upchirp (1, 2 sps floats), d_downchirp_ifreq (2, sps floats), d_upchirp_ifreq (3, sps floats) and d_upchirp_ifreq_v (4, 3 sps floats, followed
+ * by this library's guard tail of 4 D + 8 copies of the last value: the reference indexes past the vector for bin_idx = N - 1, :301,:310).  Tables 0, 2, 3, 4
+ * are read back from the device memory the kernels use; the upchirp itself is needed by no kernel and is the host copy its ifreq tables were made from.
+ * *n_floats = the table's length; buf (cap_floats floats) may be NULL to ask for the length only.  LORA_HIP_ERR_ARG: unknown table, or buf too small. */
+lora_hip_status lora_hip_get_table(const lora_hip_decoder_t *h, int which, float *buf, size_t cap_floats, size_t *n_floats);
 size_t          lora_hip_trace(const lora_hip_decoder_t *h, const lora_hip_step_t **steps);
 void            lora_hip_trace_clear(lora_hip_decoder_t *h);
 

@@ -103,6 +103,29 @@ def test_shim_block_in_the_reference_default_mode_vs_compiled_reference(tmp_path
     assert len(frames) >= 1
 
 
+@pytest.mark.gpu
+def test_shim_block_out_of_the_box_is_the_fft_estimator(tmp_path):
+    """LORA_HIP_DEMOD unset: the block's default estimator is the dechirp + FFT one with the gradient path's s = 0 convention (FFT_COMPAT,
+    shim/gnuradio/decoder_impl.cc:32) - NOT the gradient estimator upstream ships (decoder_impl.cc:499; INTEGRATION.md section 1, first row).  What the block
+    publishes is then the oracle's FFT_COMPAT decode of the same IQ; on this clean case the shipped estimator decodes the same frames, which is what makes the
+    difference one of robustness (the ~2 % of clean SF7 packets the gradient estimator gets wrong), not of format."""
+    import numpy as np
+    import test_golden as G
+    from oracle import oracle as O
+    case = G.GOLD["cases"][3]
+    cfg, st = G._stream(case)
+    iq_path = tmp_path / "case.cf32"
+    np.ascontiguousarray(st.iq, dtype=np.complex64).tofile(str(iq_path))
+    exe = _build(tmp_path)
+    env = {k: v for k, v in os.environ.items() if k != "LORA_HIP_DEMOD"}
+    res = subprocess.run([str(exe), str(iq_path), str(case["sf"]), str(case["cr"])], timeout=180, capture_output=True, env=env)
+    assert res.returncode == 0, (res.returncode, res.stderr.decode()[-400:])
+    frames = [l for l in res.stdout.decode().split("\n") if l and all(c in "0123456789abcdef" for c in l)]
+    want = O.decode_stream(st.iq, demod=O.DEMOD_FFT_COMPAT, sf=case["sf"], cr=case["cr"])
+    assert frames == [w[15:].hex() for w in want] and len(frames) >= 1
+    assert frames == [f[30:] for f in case["ref"]["frames"]]
+
+
 XLATING_HARNESS = textwrap.dedent(r'''
     #include <cstdio>
     #include <fstream>

@@ -75,8 +75,8 @@ def test_config5_sf12_cfo_awgn_bins_within_one(oracle_mod, reduced_rate):
     cfo = float(rng.uniform(-cfg.bw / 4, cfg.bw / 4))
     sigma = synth.awgn_sigma_for_snr(-10.0, cfg)
     st = synth.build_stream([payload], cfg, gaps=[3 * cfg.sps], rng=rng, noise_sigma=sigma, cfo_hz=cfo, tail_symbols=2.5)
-    n_sym = 8 + len(st.shifts[0][1])
-    n_sym = min(n_sym, 160)                                     # ~5 M items is plenty
+    n_sym = 8 + len(st.shifts[0][1])                            # the whole packet: 8 header symbols + 344 payload symbols (416 at the reduced rate)
+    assert n_sym == (424 if reduced_rate else 352), n_sym
     offs = st.header_starts[0] + np.arange(n_sym) * cfg.sps
     o = oracle_mod.Oracle(sf=12, cr=4, reduced_rate=reduced_rate)
     want = o.demod_at(st.iq, offs, 1).astype(np.int64)

@@ -455,3 +455,20 @@ def test_pipelined_passes_equal_sequential(torch_cuda, oracle_mod):
         hs[1].close()
         assert got == ref
     h.close()
+
+
+@pytest.mark.parametrize("sf", [7, 8, 9, 10, 11, 12])
+def test_handle_tables_equal_the_oracles_bit_for_bit(oracle_mod, sf):
+    """SURVEY 8 row a2, build_ideal_chirps (decoder_impl.cc:141-175): d_downchirp, d_upchirp, their instantaneous frequencies and d_upchirp_ifreq_v as the
+    handle holds them (read back from the device through lora_hip_get_table) against the oracle's - which tests/test_ref_pin.py holds bit for bit to the
+    compiled reference's.  Bit equality, float by float: the casts of :159-160 (gr_expj takes a float) and the float division of :77 are part of the tables."""
+    from gr_lora_amd import capi
+    o = oracle_mod.Oracle(sf=sf)
+    h = capi.Handle(sf=sf)
+    try:
+        for which in range(5):
+            got, want = h.table(which), o.table(which).astype(np.float32)
+            assert got.shape == want.shape, (sf, which, got.shape, want.shape)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (sf, which, int(np.flatnonzero(got.view(np.uint32) != want.view(np.uint32))[0]))
+    finally:
+        h.close()

@@ -28,7 +28,7 @@ def test_c_abi_exports_every_declared_symbol():
     out = subprocess.check_output(["nm", "-D", "--defined-only", capi.LIB_PATH]).decode()
     exported = set(re.findall(r" T (lora_hip_[a-z_]+)", out))
     assert declared <= exported
-    assert lib.lora_hip_abi_version() == 3
+    assert lib.lora_hip_abi_version() == 4
     # the channeliser's header
     hdr2 = open(os.path.join(ROOT, "include", "lora_hip_channelizer.h")).read()
     declared2 = set(re.findall(r"\b(lora_hip_channelizer_[a-z_]+)\s*\(", hdr2))
