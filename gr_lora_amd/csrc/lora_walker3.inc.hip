@@ -46,6 +46,9 @@
 // scalar registers (uniform_job); the replay's power-of-two reductions as masks; the replay's short path for a full round of unmoved payload symbols;
 // fine_sync's ifreq kept from pass 1 except at SF12 (LATE_F: its eight held rows leave no registers for it).  Dropped after measurement: a register
 // prefetch of the next pair in pass 1, pass 1 as a load pipeline, acquisition rounds over several windows at K > 1 (kept only for the header-only variants).
+#ifndef LORA_W3_P1_PREFETCH
+#define LORA_W3_P1_PREFETCH 0   // pass 1 of w3_demod_round as a load pipeline (see there): built and measured in round 6 as in round 3 - off
+#endif
 #ifndef LORA_W3_REPLAY_STATS
 #define LORA_W3_REPLAY_STATS 1  // LORA_HIP_DEBUG accounting of thread 0's replay inside the decode rounds (2: finer)
 #endif
@@ -377,13 +380,36 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
 
     // ---- pass 1 ----
     if (valid) {
+        // Pass 1 is a chain of memory round trips if written pair by pair (16 samples, then their 16 dechirp entries, pair after pair: 19 k of a round's 38 k
+        // clocks at SF10 with under 4 k of arithmetic in them, LORA_HIP_W3_STAMPS).  LORA_W3_P1_PREFETCH requests pair p + 1's samples and pair p's dechirp
+        // entries before pair p is worked on: with fine_sync's 32 ifreq registers gone it fits without a spill and takes block 0's pass 1 from 19 k to 12 k
+        // clocks - and the device as a whole 4-7 % DOWN (standalone 0.283 / 0.273 / 0.253 -> 0.264 / 0.256 / 0.237 at SF10 / SF11 / SF12, walkers -1 ... -4 %):
+        // every workgroup of the launch then asks for twice as much at once.  Off.
+        v2f nx[16];
+#if LORA_W3_P1_PREFETCH
+#pragma unroll
+        for (int c = 0; c < 16; c++) nx[c] = w3_ld2(xb, 8u * tu, (uint32_t)(c * CH * 8));
+#endif
 #pragma unroll
         for (int p = 0; p < PAIRS; p++) {
             const int base = p * TG + t;
             const uint32_t ob = 8u * ((uint32_t)(p * TG) + tu); // byte offset of this thread's sample inside a chunk
             v2f a[16];
+#if LORA_W3_P1_PREFETCH
+            v2f dd[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) dd[c] = w3_ld2(db, ob, (uint32_t)(c * CH * 8));
+#pragma unroll
+            for (int c = 0; c < 16; c++) a[c] = nx[c];
+            if (p + 1 < PAIRS) {
+#pragma unroll
+                for (int c = 0; c < 16; c++) nx[c] = w3_ld2(xb, ob + 8u * (uint32_t)TG, (uint32_t)(c * CH * 8));
+            }
+            __builtin_amdgcn_sched_barrier(0); // (the requests stay in front of the work)
+#else
 #pragma unroll
             for (int c = 0; c < 16; c++) a[c] = w3_ld2(xb, ob, (uint32_t)(c * CH * 8));
+#endif
             if (want_energy) {
 #pragma unroll
                 for (int c = 0; c < 16; c++) en += a[c].x * a[c].x + a[c].y * a[c].y;
@@ -410,10 +436,14 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
             }
 #pragma unroll
             for (int h = 0; h < 2; h++) { // dechirp (:437)
+#if LORA_W3_P1_PREFETCH
+                cmul_batch<8>(a + 8 * h, dd + 8 * h);
+#else
                 v2f d[8];
 #pragma unroll
                 for (int c = 0; c < 8; c++) d[c] = w3_ld2(db, ob, (uint32_t)((8 * h + c) * CH * 8));
                 cmul_batch<8>(a + 8 * h, d);
+#endif
             }
             fft_inlane_dif_pk<16>(a);
             const int q0 = base >> 3;
