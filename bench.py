@@ -262,6 +262,10 @@ def main():
                     "3 = also the envelope pre-pass of step k+2 is issued ahead (it runs in the tail of step k's walker)")
     ap.add_argument("--chunk", type=int, default=1 << 22, help="--path work: items per lora_hip_work call")
     ap.add_argument("--batch", type=int, default=1 << 24, help="--path work: items per device pass (lora_hip_config_t.batch_items)")
+    ap.add_argument("--lanes", type=int, default=0, help="independent pass pipelines (each `--depth` handles on a HIP stream of its own) driven by one host thread each; the K "
+                    "steps are shared out among them.  A pass of a few hundred jobs (config 4 at 2 s per stream: three dependent launches of 100-160 us with the "
+                    "host's planning between them) leaves device AND host waiting on each other; lanes overlap those waits the way a gateway serving several "
+                    "antennas would.  0 = the default: 1, config 4 on one GPU: 6 (2 s per stream: 52.6 / 70.6 / 86.3 / 96.7 Gsamples/s with 1 / 2 / 3 / 6 lanes)")
     ap.add_argument("--overlap", action="store_true", help="passes alternate between TWO HIP streams: the walker kernel of pass k+1 starts on the CUs that "
                     "pass k's shorter jobs have left (a streaming receiver's mode; not the default: the per-kernel HIP-event durations then "
                     "include the time a kernel shares the device with its neighbour, and roofline.frac is computed from them)")
@@ -390,12 +394,57 @@ def main():
     # (gr_lora_amd.gather.PassPipeline: begin(k+1) before end(k) on one HIP stream, the frames of step k in an asynchronous
     # all_gather that is collected while step k+1 runs).
     pipe = gather.PassPipeline(hs, gat, d_iq.data_ptr(), n_items, offs, lens, stream)
-    run = pipe.run
+    lanes = args.lanes if args.lanes > 0 else (6 if (args.config == 4 and not use_dist and not args.overlap) else 1)
+    if use_dist or args.overlap:
+        lanes = 1   # (the ranks' all_gathers must be issued in one order; --overlap is its own experiment)
+    if lanes == 1:
+        run = pipe.run
+    else:
+        import threading
+        lane_streams = [torch.cuda.Stream(device=dev) for _ in range(lanes - 1)]
+        pipes = [pipe] + [gather.PassPipeline([capi.Handle(**kw) for _ in range(depth)], gather.AsyncSlotGather(dev, gather_cap), d_iq.data_ptr(), n_items, offs, lens,
+                                              ls.cuda_stream) for ls in lane_streams]
+        lock = threading.Lock()
+
+        def run(n_steps, keep=None, check=None):
+            """n_steps passes shared out among the lanes (lane i takes every lanes-th step's worth); same return value as PassPipeline.run"""
+            share = [n_steps // lanes + (1 if i < n_steps % lanes else 0) for i in range(lanes)]
+            out = [None] * lanes
+            errs = []
+
+            def locked(fn):
+                if fn is None:
+                    return None
+
+                def g(done):
+                    with lock:
+                        fn(done)
+                return g
+
+            def work(i):
+                try:
+                    torch.cuda.set_device(dev)
+                    k = [] if keep is not None else None
+                    out[i] = pipes[i].run(share[i], k, locked(check))
+                    if k:
+                        with lock:
+                            keep.extend(k)
+                except Exception as e:  # noqa: BLE001 - reported by the caller's thread
+                    errs.append(e)
+            th = [threading.Thread(target=work, args=(i,)) for i in range(1, lanes)]
+            for t in th:
+                t.start()
+            work(0)
+            for t in th:
+                t.join()
+            if errs:
+                raise errs[0]
+            return sum(o[0] for o in out if o), sum(o[1] for o in out if o)
 
     # correctness of what is being timed (outside the timed region): frames as gathered, this rank's share, every handle
     kept = []
-    run(depth, kept)
-    verified = len(kept) == depth
+    run(depth * lanes, kept)
+    verified = len(kept) == depth * lanes
     for slots, counts in kept:
         r = rank if len(counts) > 1 else 0
         got, full = {}, {}
@@ -541,7 +590,7 @@ def main():
                                     if ref_checked[0] else "payloads as sent"),
                        "parallelism": "streams sharded, dp%d; frame gather: 1 async all_gather per step" % world,
                        "process_group": ("nccl (RCCL), world %d" % world) if use_dist else "none (single process)",
-                       "pipeline_depth": depth, "path": "device (IQ resident in HBM)" + (", passes alternating between two HIP streams" if args.overlap else ""),
+                       "pipeline_depth": depth, "lanes": lanes, "path": "device (IQ resident in HBM)" + (", passes alternating between two HIP streams" if args.overlap else ""),
                        "source_hash": source_hash()},
             # `achieved` / `frac`: THIS run's measurement - the walker kernel's average launch duration from HIP events on the launch stream
             # over the (median) timed block.  `frac_rocprof`: the same kernel's average duration in the committed `rocprofv3 --kernel-trace
@@ -588,6 +637,10 @@ def main():
         print(json.dumps(res))
     for hk in hs:
         hk.close()
+    if lanes > 1:
+        for pl in pipes[1:]:
+            for hk in pl.hs:
+                hk.close()
     if use_dist:
         dist.destroy_process_group()
 

@@ -8,6 +8,8 @@ mkdir -p gpurun_out
 tools/profile_round.sh sf7
 export PROFILE_LINE_FLAGS=--no-cpu-baseline   # (the CPU legs once, in the sf7 set and the default line; the gradient second line needs them on: see below)
 tools/profile_round.sh sf8 --config 3 --sf 8 --packets 1024
+tools/profile_round.sh sf7_256 --config 3 --sf 7 --packets 256    # config 3's own cell size (BASELINE: 256 packets per SF): one workgroup per CU
+tools/profile_round.sh sf8_256 --config 3 --sf 8 --packets 256
 PROFILE_STEPS=8 tools/profile_round.sh sf9 --config 3 --sf 9
 PROFILE_STEPS=8 tools/profile_round.sh sf10 --config 3 --sf 10
 PROFILE_STEPS=6 tools/profile_round.sh sf11 --config 3 --sf 11
@@ -30,6 +32,8 @@ python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.
 python bench.py --streams 1 --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/streams1_line.json
 python bench.py --config 3 --sf 7 --packets 256 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/sf7_256_line.json   # config 3's own cell size at SF7 / SF8: no more jobs than CUs (the plan for one workgroup per CU; SF8: walker2_kernel_sf8_wide)
 python bench.py --config 3 --sf 8 --packets 256 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/sf8_256_line.json
+for sf in 7 8 9; do python bench.py --config 3 --sf $sf --packets 256 --lanes 2 --no-cpu-baseline --no-grad-line 2>/dev/null | tail -1 > gpurun_out/sf${sf}_256_lanes2_line.json; done   # two passes in flight on streams of their own: the job rate of a cell that leaves half of every CU idle
+python bench.py --config 4 --seconds 2 --lanes 1 --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/cfg4_2s_lanes1_line.json                          # config 4's default is six lanes (bench.py --lanes): this is the single pipeline of round 5
 tools/pmc_walker.sh sq_sf7
 tools/pmc_walker.sh sq_sf9 --config 3 --sf 9
 tools/pmc_walker.sh sq_sf12 --config 3 --sf 12
