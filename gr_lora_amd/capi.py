@@ -153,8 +153,9 @@ def load():
     L.lora_hip_estimate_cfo_device.restype = C.c_int
     L.lora_hip_ref_ifreq_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float), vp]
     L.lora_hip_ref_ifreq_device.restype = C.c_int
-    L.lora_hip_get_table.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_size_t)]
-    L.lora_hip_get_table.restype = C.c_int
+    if hasattr(L, "lora_hip_get_table") or not os.environ.get("LORA_HIP_LIB"):   # (a library variant of an older ABI under tools/ab.sh does without)
+        L.lora_hip_get_table.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_size_t)]
+        L.lora_hip_get_table.restype = C.c_int
     L.lora_hip_window_stats_device.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(WindowStats), vp]
     L.lora_hip_detect_preambles_device.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_uint32, C.c_float, C.POINTER(Preamble), C.c_size_t, C.POINTER(C.c_size_t), vp]
     L.lora_hip_decode_at_headers_device.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_uint32, C.POINTER(Preamble), C.c_size_t, vp]

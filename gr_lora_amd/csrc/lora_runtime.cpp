@@ -351,7 +351,7 @@ lora_hip_status build_tables(lora_hip_decoder *h)
         P.sync_closed_form = sps >= 4096u ? 1u : 0u;
         // near-tied SYNC shifts decided by the reference's own float sums (lora_strict_sync.inc.hip): on unless the caller opts out
         P.strict_sync = (c.flags & LORA_HIP_FLAG_FAST_SYNC) ? 0u : 1u;
-        if (const char *e = getenv("LORA_HIP_STRICT_SYNC")) P.strict_sync = (uint32_t)atoi(e); // (A/B runs; 2: the exact arctangents without the re-evaluation - timing only)
+        if (const char *e = getenv("LORA_HIP_STRICT_SYNC")) P.strict_sync = (e[0] != '0') ? 1u : 0u; // (A/B runs)
         h->decoupled_policy = (c.flags & LORA_HIP_FLAG_NO_DECOUPLED) ? 0 : -1;
         if (const char *e = getenv("LORA_HIP_DECOUPLED")) h->decoupled_policy = e[0] == '0' ? 0 : e[0] == '1' ? 1 : -1; // 0 never, 1 always, anything else: auto
     }

@@ -15,7 +15,7 @@
 // (8 k clocks per SYNC at SF7, 262 k at SF12), the exact arctangents cost about as much again at SF7: 7-8 % of a pass at every
 // spreading factor (6-8 %: the figure include/lora_hip.h quotes as well).  Pinned to ONE arithmetic environment - glibc 2.35's atan2f, VOLK's generic
 // sequential dot product (oracle/ref_build) - as the flag's description in include/lora_hip.h says.  LORA_HIP_FLAG_FAST_SYNC skips it (the closed-form maximum stands: one sample beside the reference at SF11 / SF12).
-// Round 6, in the SF7 walker (two workgroups per CU; LORA_HIP_STRICT_SYNC=2 runs the exact arctangents without the re-evaluation): of a SYNC round's 56 k
+// Round 6, in the SF7 walker (two workgroups per CU; builds with the re-evaluation, and with its chain alone, skipped): of a SYNC round's 56 k
 // clocks the exact arctangents are 7 k and the re-evaluation 24 k - its adding lane runs at 22 clocks per tap there, not at the 5.5 of an idle CU.  Not the
 // LDS round trip: the same chain with the products in registers and the running sums walking through the lanes (v_add_f32 with a DPP row_shr:2 operand, one
 // instruction per tap for both candidates, exact) takes as long, a ring of eight batches instead of four spills (128-register kernel), and v_readlane feeding

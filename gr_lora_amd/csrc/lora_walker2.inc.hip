@@ -796,7 +796,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             const float my_bv = bv;
             const int my_bi = bi;
             w2_block_argmax_first<WAVES>(bv, bi, W.red);
-            if (P.strict_sync == 1u) { // shifts within rounding of the maximum: the reference's own float sums decide (:399-407)
+            if (P.strict_sync) { // shifts within rounding of the maximum: the reference's own float sums decide (:399-407)
                 strict::cands_push(W.sc, bv, my_bv, my_bi, b2, i2);
                 __syncthreads();
                 const int nc = W.sc.n;
