@@ -1108,6 +1108,10 @@ __global__ __launch_bounds__(64 * kW2WavesSf8, LORA_W2_EU_SF8) void walker2_kern
 // the same body at the 256-register budget (one workgroup per CU by registers): what launch_walker picks for a launch with no more jobs than CUs, where a
 // workgroup has its CU to itself anyway - 0.161 against 0.138 of HBM peak at 256 packets; with more jobs the two-per-CU build above wins, 0.251 against 0.211 at 1024
 __global__ __launch_bounds__(64 * kW2WavesSf8, 2) void walker2_kernel_sf8_wide(DevParams P, LaunchCfg C) { walker2_body<8, kW2WavesSf8, false>(P, C); }
+// ... and SF7's (round 6: 192 registers, nothing spilled; 256 packets 125 -> 138 Gsamples/s), and the gradient kernels'
+__global__ __launch_bounds__(64 * kW2WavesSf7, 2) void walker2_kernel_sf7_wide(DevParams P, LaunchCfg C) { walker2_body<7, kW2WavesSf7, false>(P, C); }
+__global__ __launch_bounds__(64 * kW2WavesSf7, 2) void walker2_kernel_sf7_grad_wide(DevParams P, LaunchCfg C) { walker2_body<7, kW2WavesSf7, true>(P, C); }
+__global__ __launch_bounds__(64 * kW2WavesSf8, 2) void walker2_kernel_sf8_grad_wide(DevParams P, LaunchCfg C) { walker2_body<8, kW2WavesSf8, true>(P, C); }
 // the gradient demodulator (demod_mode 0, the reference's default): no FFT tables, fewer live registers
 #ifndef LORA_W2_EU_GRAD_SF7
 #define LORA_W2_EU_GRAD_SF7 4

@@ -264,7 +264,7 @@ lora_hip_status lora_hip_demod_symbols_ex_device(lora_hip_decoder_t *h, const vo
 lora_hip_status lora_hip_last_timing(const lora_hip_decoder_t *h, lora_hip_timing_t *t);
 /* Name of the state-machine kernel this handle's passes launch (diagnostics; what a rocprofv3 kernel trace will show): before the first pass
  * the default of the configuration, afterwards the variant the last pass's main launch ran.
- * walker2_kernel_sf7/8[_grad] (wavefront per symbol; walker2_kernel_sf8_wide: the 256-register build of the same body, for launches with no more jobs than
+ * walker2_kernel_sf7/8[_grad] (wavefront per symbol; walker2_kernel_sf7/8[_grad]_wide: the 256-register builds of the same body, for launches with no more jobs than
  * CUs), walker3_kernel_sf9..12[_grad] (SF9 and every _grad: wavefront per symbol; SF10-SF12 FFT: workgroup per symbol; _half: SF10 and SF9_grad as two
  * workgroups per CU), *_skip (the header-only variants of a decoupled pass), walker_kernel* (generic: other decimations, SF6, LORA_HIP_NO_FAST).          */
 const char     *lora_hip_walker_kernel_name(const lora_hip_decoder_t *h);

@@ -161,15 +161,19 @@ def test_config4_64_channels(oracle_mod):
     assert [[f[15:] for f in g[0]] for g in got] == expect
 
 
-def test_sf8_two_builds_of_one_body_by_job_count():
-    """walker2 at SF8 (round 5): two workgroups per CU at 128 registers when a launch has more jobs than CUs, the 256-register build of the same body
-    (walker2_kernel_sf8_wide) when every job has a CU to itself - config 3's own 256 packets per cell, planned for one workgroup per CU.  Same frames;
-    SF7 has one build and the same plan."""
+def test_walker2_two_builds_of_one_body_by_job_count():
+    """walker2 (SF8: round 5; SF7 and the gradient kernels: round 6): two workgroups per CU at 128 registers when a launch has more jobs than CUs, the 256-register
+    build of the same body (walker2_kernel_sf7/8[_grad]_wide) when every job has a CU to itself - config 3's own 256 packets per cell, planned for one workgroup
+    per CU.  Same frames."""
     from gr_lora_amd import capi
-    for sf, packets, want in ((8, 1024, "walker2_kernel_sf8"), (8, 256, "walker2_kernel_sf8_wide"), (7, 256, "walker2_kernel_sf7")):
+    for sf, packets, demod, want in ((8, 1024, 2, "walker2_kernel_sf8"), (8, 256, 2, "walker2_kernel_sf8_wide"), (7, 256, 2, "walker2_kernel_sf7_wide"), (7, 1024, 2, "walker2_kernel_sf7"),
+                                     (7, 256, 0, "walker2_kernel_sf7_grad_wide"), (8, 256, 0, "walker2_kernel_sf8_grad_wide")):
         cfg, iq, offs, lens, expect = bench.make_workload(sf, 4, packets, 32, 8, seed=100 * sf + 4)
+        if demod == 0:   # (the workload's expectation is the transmitted payloads: the shipped estimator gets ~2 % of clean SF7 packets wrong - hold it to the oracle's decode)
+            from oracle import oracle as O
+            expect = [[f[15:] for f in O.decode_stream(iq[o:o + n], demod=O.DEMOD_GRAD, sf=sf, cr=4)] for o, n in zip(offs, lens)]
         dev = _dev(iq)
-        h = capi.Handle(demod=2, sf=sf, cr=4)
+        h = capi.Handle(demod=demod, sf=sf, cr=4)
         h.decode_device(dev.data_ptr(), iq.size, offs, lens, 0)
         by = {}
         for g, i in h.drain():
