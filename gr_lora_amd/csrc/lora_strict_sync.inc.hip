@@ -15,12 +15,12 @@
 // (8 k clocks per SYNC at SF7, 262 k at SF12), the exact arctangents cost about as much again at SF7: 7-8 % of a pass at every
 // spreading factor (6-8 %: the figure include/lora_hip.h quotes as well).  Pinned to ONE arithmetic environment - glibc 2.35's atan2f, VOLK's generic
 // sequential dot product (oracle/ref_build) - as the flag's description in include/lora_hip.h says.  LORA_HIP_FLAG_FAST_SYNC skips it (the closed-form maximum stands: one sample beside the reference at SF11 / SF12).
-// Round 6, in the SF7 walker (two workgroups per CU; builds with the re-evaluation, and with its chain alone, skipped): of a SYNC round's 56 k
-// clocks the exact arctangents are 7 k and the re-evaluation 24 k - its adding lane runs at 22 clocks per tap there, not at the 5.5 of an idle CU.  Not the
-// LDS round trip: the same chain with the products in registers and the running sums walking through the lanes (v_add_f32 with a DPP row_shr:2 operand, one
-// instruction per tap for both candidates, exact) takes as long, a ring of eight batches instead of four spills (128-register kernel), and v_readlane feeding
-// two independent chains costs two instructions per tap and candidate.  What is left is the SIMD itself: the adding wavefront shares it with three others,
-// two of them in the neighbour workgroup's decode rounds, and a dependent instruction waits for whatever was issued into its gap.
+// Round 6, in the SF7 walker (two workgroups per CU; a build with the re-evaluation skipped): of a SYNC round's 56 k clocks the exact arctangents are 7 k and the
+// re-evaluation 24 k.  Four other adding chains were built, all exact (tests/test_gpu_strict_sync.py, test_gpu_a16.py, test_golden.py, test_gpu_fullsize.py), none
+// faster: a ring of eight LDS batches instead of four (spills), the products in registers fed to two independent chains through v_readlane (two instructions per tap
+// and candidate), the running sums walking through the lanes with the taps (v_add_f32 with a DPP row_shr:2 operand), and the whole sum by 64 lanes at once - integer
+// increments inside a binade, tests/host_sim/par_sum_model.c - with ~7 VALU instructions per tap and nothing outside the registers.  The time was never in the chain:
+// it was in the CALL (resolve_lds below).
 #pragma once
 
 namespace strict {
@@ -294,51 +294,18 @@ __device__ __attribute__((noinline)) int resolve(const float2 *__restrict__ x, i
 // the 2 sps window, ul = d_upchirp_ifreq[0 .. sps-1) (= the first sps-1 entries of d_upchirp_ifreq_v), buf: LDS, cap floats.  Chunks of
 // W = cap / ST taps: the workgroup multiplies, wave 0 adds.
 template <int T>
+__device__ __forceinline__ int resolve_lds_inl(const float *f, int sps, const float *ul, Cands *Cp, float *buf, int cap, float *bv_out)
+{
+#include "lora_strict_resolve_lds.inc"
+}
+
+// ... as a call.  Where the caller's registers are worth more than the call: the SF8 walker, whose 128-register build spills 120 more with the body inline (-10 %).  In
+// the SF7 walker it is the call that costs - the state machine's registers saved and restored around it, 30 k of a job's 159 k SYNC clocks (round 6: the three faster
+// adding chains above were hunting time that was never in the chain) - and the body is inline: 249 -> 261 Gsamples/s.
+template <int T>
 __device__ __attribute__((noinline)) int resolve_lds(const float *f, int sps, const float *ul, Cands *Cp, float *buf, int cap, float *bv_out)
 {
-#pragma clang fp contract(off)
-    typedef __attribute__((address_space(3))) const float lds_cf;
-    typedef __attribute__((address_space(3))) float lds_f;
-    Cands &C = *Cp;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int nc = C.n;
-    int id[kK]; // ascending shifts (the reference meets them in this order), sorted by every thread for itself
-#pragma unroll
-    for (int c = 0; c < kK; c++) id[c] = c < nc ? C.idx[c] : 0x7fffffff;
-#pragma unroll
-    for (int a = 1; a < kK; a++)
-#pragma unroll
-        for (int b = kK - 1; b >= a; b--) { const int lo = min(id[b - 1], id[b]), hi = max(id[b - 1], id[b]); id[b - 1] = lo; id[b] = hi; }
-    const int nsteps = sps - 1;
-    const int ST = nc <= 2 ? 2 : 4;
-    const int W = ((cap / ST) / 64) * 64;
-    const int nch = (nsteps + W - 1) / W;
-    lds_cf *fl = (lds_cf *)f, *u = (lds_cf *)ul;
-    lds_f *dst = (lds_f *)buf;
-    float acc = 0.0f;
-    for (int j = 0; j < nch; j++) {
-        const int k0 = j * W, wv = nsteps - k0, taps = ((wv < W ? wv : W) + 63) & ~63;
-        for (int i = t; i < nc * taps; i += T) {
-            const int c = i / taps, kk = i - c * taps, k = k0 + kk;
-            const int ic = c == 0 ? id[0] : c == 1 ? id[1] : c == 2 ? id[2] : id[3];
-            dst[((kk >> 2) * ST + c) * 4 + (kk & 3)] = k < nsteps ? fl[ic + k] * u[k] : 0.0f; // taps past sps-2: +0.0f leaves a float sum as it is
-        }
-        __syncthreads();
-        if (wave == 0) {
-            __builtin_amdgcn_s_setprio(3); // everyone else waits for this ONE wavefront
-            if (lane < nc) acc = ST == 2 ? chain_add<2>(buf, lane, taps / 4, acc) : chain_add<4>(buf, lane, taps / 4, acc);
-            __builtin_amdgcn_s_setprio(0);
-        }
-        __syncthreads();
-    }
-    if (wave == 0 && lane < nc) C.acc[lane] = acc;
-    __syncthreads();
-    float best = 0.0f; // max_correlation = 0 (:400)
-    int bi = 0x7fffffff;
-#pragma unroll
-    for (int c = 0; c < kK; c++) if (c < nc) { const float v = C.acc[c]; if (v > best) { best = v; bi = id[c]; } }
-    *bv_out = best;
-    return bi;
+#include "lora_strict_resolve_lds.inc"
 }
 
 } // namespace strict

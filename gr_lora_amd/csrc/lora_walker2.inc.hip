@@ -802,7 +802,8 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 const int nc = W.sc.n;
                 if (nc >= 2 && nc <= strict::kK) {
                     float ev;
-                    bi = strict::resolve_lds<kW2>(f2, SPS, vl, &W.sc, reinterpret_cast<float *>(pre), 1024, &ev); // (the closed form's prefix sums are done with: 4160 bytes; vl[k] = d_upchirp_ifreq[k], k < sps-1)
+                    if constexpr (SF == 7) bi = strict::resolve_lds_inl<kW2>(f2, SPS, vl, &W.sc, reinterpret_cast<float *>(pre), 1024, &ev); // (inline: see resolve_lds)
+                    else bi = strict::resolve_lds<kW2>(f2, SPS, vl, &W.sc, reinterpret_cast<float *>(pre), 1024, &ev); // (the closed form's prefix sums are done with: 4160 bytes; vl[k] = d_upchirp_ifreq[k], k < sps-1)
                     bv = ev;
                 }
             }
