@@ -74,6 +74,7 @@ struct DevParams {
     const float  *wave_tabs;    // packed table block of the wave demodulator (lora_wave_demod.inc.hip), SF7/SF8 at D = 8
     const float2 *w3_tw;        // walker3 (SF9-12 at D = 8): W_N^t, and the combine coefficients in pass-3 thread order
     const float2 *w3_ctab;
+    const float  *team_tabs;    // SF10-12 at D = 8: the table block of the team demodulator (lora_team_demod.inc.hip)
 };
 
 struct Job {
@@ -210,6 +211,8 @@ uint32_t w3_tw_entries(uint32_t sf);
 void build_w3_tables(uint32_t sf, float2 *tw, float2 *ctab /* sps entries */);
 uint32_t wave_tables_floats(uint32_t sf);                                  // 0 when the wave demodulator does not cover sf
 void build_wave_tables(uint32_t sf, const float2 *down, float *out);
+uint32_t team_tables_entries(uint32_t sf);                                 // 8-byte entries; 0 when the team demodulator does not cover sf
+void build_team_tables(uint32_t sf, const float2 *down, double dt, double bandwidth, float2 *out);
 uint32_t walker_lds_bytes(const DevParams &p);
 uint32_t walker_resident_slots(const DevParams &p);
 uint32_t walker_resident_slots_full(const DevParams &p);                  // second, smaller slot count where the kernel exists as half- and full-size workgroups (0: none)

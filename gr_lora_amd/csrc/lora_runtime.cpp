@@ -107,6 +107,7 @@ struct lora_hip_decoder {
     float2 *d_down = nullptr, *d_twN = nullptr, *d_tws = nullptr;
     float *d_wave_tabs = nullptr;
     float2 *d_w3_tw = nullptr, *d_w3_ctab = nullptr;
+    float2 *d_team_tabs = nullptr;
     float *d_up_ifreq = nullptr, *d_down_ifreq = nullptr, *d_up_ifreq_v = nullptr;
     std::vector<float2> h_up;          // d_upchirp (:160): no kernel reads it; kept for lora_hip_get_table
     size_t n_up_ifreq_v = 0;           // floats in d_up_ifreq_v (3 sps + the guard tail)
@@ -386,6 +387,13 @@ lora_hip_status build_tables(lora_hip_decoder *h)
         if ((s = upload(h, &h->d_w3_tw, tw)) != LORA_HIP_OK) return s;
         if ((s = upload(h, &h->d_w3_ctab, ct)) != LORA_HIP_OK) return s;
         P.w3_tw = h->d_w3_tw; P.w3_ctab = h->d_w3_ctab;
+    }
+    P.team_tabs = nullptr;
+    if (D == 8u && team_tables_entries(c.sf) != 0u) { // SF10-12: the team demodulator's table block
+        std::vector<float2> tt(team_tables_entries(c.sf));
+        build_team_tables(c.sf, down.data(), dt, (double)c.bandwidth, tt.data());
+        if ((s = upload(h, &h->d_team_tabs, tt)) != LORA_HIP_OK) return s;
+        P.team_tabs = reinterpret_cast<const float *>(h->d_team_tabs);
     }
     P.up_ifreq = h->d_up_ifreq; P.down_ifreq = h->d_down_ifreq; P.up_ifreq_v = h->d_up_ifreq_v;
     return LORA_HIP_OK;
@@ -996,6 +1004,7 @@ void lora_hip_destroy(lora_hip_decoder_t *h)
     if (h->d_tws) (void)hipFree(h->d_tws);
     if (h->d_wave_tabs) (void)hipFree(h->d_wave_tabs);
     if (h->d_w3_tw) (void)hipFree(h->d_w3_tw);
+    if (h->d_team_tabs) (void)hipFree(h->d_team_tabs);
     if (h->d_w3_ctab) (void)hipFree(h->d_w3_ctab);
     if (h->d_up_ifreq) (void)hipFree(h->d_up_ifreq);
     if (h->d_down_ifreq) (void)hipFree(h->d_down_ifreq);

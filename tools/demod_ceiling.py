@@ -46,7 +46,7 @@ else:
                 if demod == 0:
                     pats = ["demod_symbols_wave_grad_kernel<%d>" % sf if sf <= 8 else "demod_symbols_w3_grad_kernel<%d>" % sf]
                 else:
-                    pats = ["demod_symbols_wave_kernel<%d," % sf] if sf <= 9 else ["demod_symbols_w3_kernel<%d, false" % sf, "demod_symbols_w3_kernel<%d,false" % sf]
+                    pats = ["demod_symbols_wave_kernel<%d," % sf] if sf <= 9 else ["demod_symbols_w3_kernel<%d, false" % sf, "demod_symbols_w3_kernel<%d,false" % sf, "demod_symbols_team_kernel<%d>" % sf]
                 if any(p in name for p in pats):
                     items = plan(sf) * (8 << sf)
                     cells["sf%d-demod%d" % (sf, demod)] = {"kernel": name, "calls": int(r.get("Calls") or 0), "avg_ms": round(avg_ns / 1e6, 4), "items": items,
