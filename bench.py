@@ -401,6 +401,7 @@ def main():
         run = pipe.run
     else:
         import threading
+        os.environ.setdefault("LORA_HIP_NO_WIDE", "1")   # (two passes in flight share the CUs: the two-per-CU builds of the walker2 kernels, not the 256-register ones a lone launch of <= CUs jobs gets)
         lane_streams = [torch.cuda.Stream(device=dev) for _ in range(lanes - 1)]
         pipes = [pipe] + [gather.PassPipeline([capi.Handle(**kw) for _ in range(depth)], gather.AsyncSlotGather(dev, gather_cap), d_iq.data_ptr(), n_items, offs, lens,
                                               ls.cuda_stream) for ls in lane_streams]
