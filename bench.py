@@ -177,7 +177,7 @@ def _strip_comments(text):
 
 # what a decode pass is made of: the kernels, the device structs, the scheduler and the runtime that plans and launches
 HASHED_SOURCES = ("lora_device.h", "lora_kernels.hip", "lora_runtime.cpp", "lora_stitch.hpp", "lora_walker2.inc.hip",
-                  "lora_walker3.inc.hip", "lora_team_demod.inc.hip", "lora_wave_demod.inc.hip", "lora_detect.inc.hip", "lora_strict_sync.inc.hip", "lora_strict_resolve_lds.inc", "whitening_data.inc")
+                  "lora_walker3.inc.hip", "lora_team_demod.inc.hip", "lora_wave_demod.inc.hip", "lora_wave_decim.inc.hip", "lora_detect.inc.hip", "lora_strict_sync.inc.hip", "lora_strict_resolve_lds.inc", "whitening_data.inc")
 
 
 def source_hash(raw=False):

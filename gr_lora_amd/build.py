@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "liblora_hip.so")
 SOURCES = ["lora_kernels.hip", "lora_runtime.cpp", "lora_channelizer.hip", "lora_frame_check.cpp"]
-DEPS = SOURCES + ["lora_device.h", "lora_stitch.hpp", "lora_walker2.inc.hip", "lora_walker3.inc.hip", "lora_team_demod.inc.hip", "lora_wave_demod.inc.hip", "lora_detect.inc.hip", "lora_strict_sync.inc.hip", "lora_strict_resolve_lds.inc", "whitening_data.inc",
+DEPS = SOURCES + ["lora_device.h", "lora_stitch.hpp", "lora_walker2.inc.hip", "lora_walker3.inc.hip", "lora_team_demod.inc.hip", "lora_wave_demod.inc.hip", "lora_wave_decim.inc.hip", "lora_detect.inc.hip", "lora_strict_sync.inc.hip", "lora_strict_resolve_lds.inc", "whitening_data.inc",
                   os.path.join("..", "..", "include", "lora_hip.h"), os.path.join("..", "..", "include", "lora_hip_channelizer.h")]
 
 

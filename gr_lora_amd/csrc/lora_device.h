@@ -71,7 +71,7 @@ struct DevParams {
     const float  *up_ifreq_v;   // d_upchirp_ifreq_v (+ guard tail)
     const float2 *twN;          // e^{-2 pi i t / N},   t < N/2
     const float2 *tws;          // e^{-2 pi i m / sps}, m < sps
-    const float  *wave_tabs;    // packed table block of the wave demodulator (lora_wave_demod.inc.hip), SF7/SF8 at D = 8
+    const float  *wave_tabs;    // packed table block of the wave demodulator (lora_wave_demod.inc.hip: SF7-SF9 at D = 8; lora_wave_decim.inc.hip: D = 2 / 4)
     const float2 *w3_tw;        // walker3 (SF9-12 at D = 8): W_N^t, and the combine coefficients in pass-3 thread order
     const float2 *w3_ctab;
     const float  *team_tabs;    // SF10-12 at D = 8: the table block of the team demodulator (lora_team_demod.inc.hip)
@@ -211,6 +211,8 @@ uint32_t w3_tw_entries(uint32_t sf);
 void build_w3_tables(uint32_t sf, float2 *tw, float2 *ctab /* sps entries */);
 uint32_t wave_tables_floats(uint32_t sf);                                  // 0 when the wave demodulator does not cover sf
 void build_wave_tables(uint32_t sf, const float2 *down, float *out);
+uint32_t wave_tables_floats_d(uint32_t sf, uint32_t decim);                // decimation 2 / 4 (lora_wave_decim.inc.hip); 0 when not covered
+void build_wave_tables_d(uint32_t sf, uint32_t decim, const float2 *down, float *out);
 uint32_t team_tables_entries(uint32_t sf);                                 // 8-byte entries; 0 when the team demodulator does not cover sf
 void build_team_tables(uint32_t sf, const float2 *down, double dt, double bandwidth, float2 *out);
 uint32_t walker_lds_bytes(const DevParams &p);

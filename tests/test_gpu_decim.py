@@ -1,0 +1,170 @@
+"""Decimation 2 and 4 (a 250 / 500 kHz channel at 1 Msps, 125 kHz at 250 / 500 ksps; decoder::make takes any samp_rate / bandwidth,
+decoder_impl.cc:57, :79-87) on the wave-per-symbol kernels of lora_wave_decim.inc.hip: until round 6 everything but
+decimation 8 ran the generic kernels.
+
+* the symbol-level kernels against the oracle's get_shift_fft / max_frequency_gradient_idx + fine_sync, window by window: clean symbols,
+  windows cut early / late (fine_sync = -+1), AWGN, windows holding samples of exactly zero.
+"""
+import numpy as np
+import pytest
+
+from gr_lora_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+RATES = {2: 2.5e5, 4: 5e5}
+
+
+def _dev(iq):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(iq).view(np.float32)).cuda()
+
+
+def _windows(cfg, rng, n_sym):
+    up = synth.base_upchirp(cfg)
+    shifts = rng.integers(0, cfg.nbins, n_sym)
+    shifts[:6] = [0, 1, 2, cfg.nbins - 1, cfg.nbins - 2, cfg.nbins // 2]
+    ar = np.arange(cfg.sps)
+    # every symbol three times in a row so that a window cut early / late still sees the same chirp around its edges
+    iq = np.concatenate([np.tile(up[(ar + s * cfg.decim) % cfg.sps], 3) for s in shifts]).astype(np.complex64)
+    slip = rng.integers(-2, 3, n_sym)
+    slip[:8] = [0, 0, 0, 0, 1, -1, 2, -2]
+    offs = np.arange(n_sym) * 3 * cfg.sps + cfg.sps + slip
+    return shifts, iq, offs, slip
+
+
+def _noisy(iq, sigma, rng):
+    if not sigma:
+        return iq
+    return (iq + (rng.standard_normal(iq.size) + 1j * rng.standard_normal(iq.size)).astype(np.complex64) * np.float32(sigma / np.sqrt(2))).astype(np.complex64)
+
+
+def _only_ties(oracle_mod, cfg, x, offs, g, w):
+    """max_frequency_gradient_idx keeps the FIRST largest drop between neighbouring bin averages (:479-488): where the two largest drops of a
+    window are equal to float rounding - a window cut half a bin off its symbol; a zero sample whose step equals the chirp's own wrap - the
+    summation order decides, and either may win.  Every mismatch must be such a tie (float64 check on the oracle's ifreq)."""
+    for i in np.nonzero(g.astype(np.int64) != w)[0]:
+        f = oracle_mod.instantaneous_frequency(x[offs[i]:offs[i] + cfg.sps]).astype(np.float64)
+        avg = f.reshape(-1, cfg.decim).mean(axis=1)
+        drops = avg[:-1] - avg[1:]
+        kg, kw = cfg.nbins - 2 - int(g[i]), cfg.nbins - 2 - int(w[i])
+        assert 0 <= kg < drops.size and 0 <= kw < drops.size, (i, int(g[i]), int(w[i]))
+        assert abs(drops[kg] - drops[kw]) <= 2e-6 * abs(drops[kw]) and drops[kg] >= drops.max() * (1 - 2e-6), (i, int(g[i]), int(w[i]), drops[kg], drops[kw], drops.max())
+
+
+def _check_fine(oracle_mod, o, vtab, cfg, x, offs, bins_idx, gf, same, what):
+    """fine_sync per window where the bin agrees; only a near-tie between two lags may differ (float64 check)"""
+    n_nonzero = 0
+    for i in np.nonzero(same)[0]:
+        win = x[offs[i]:offs[i] + cfg.sps]
+        b = int(bins_idx[i])
+        wf = o.fine_sync(win, b, 2)
+        if int(gf[i]) != wf:
+            fq = oracle_mod.instantaneous_frequency(win).astype(np.float64)
+            base = (b + 1) * cfg.decim + cfg.sps
+            cq = {lag: float(np.dot(fq, vtab[base + lag:base + lag + cfg.sps])) for lag in (-1, 0, 1)}
+            a, w = (cq[-int(gf[i])] if int(gf[i]) or max(cq.values()) > 0 else 0.0), (cq[-wf] if wf or max(cq.values()) > 0 else 0.0)
+            assert abs(a - w) <= 2e-6 * max(abs(w), 1e-3), (what, i, b, int(gf[i]), wf, cq)
+        n_nonzero += wf != 0
+    return n_nonzero
+
+
+@pytest.mark.parametrize("decim", [2, 4])
+@pytest.mark.parametrize("sf", [7, 8, 9])
+def test_fft_shift_and_fine_sync_vs_oracle(oracle_mod, sf, decim):
+    from gr_lora_amd import capi
+    cfg = synth.TxConfig(sf=sf, samp_rate=RATES[decim])
+    assert cfg.decim == decim
+    rng = np.random.default_rng(1000 + 10 * sf + decim)
+    shifts, iq, offs, slip = _windows(cfg, rng, 96)
+    o = oracle_mod.Oracle(sf=sf, samp_rate=RATES[decim])
+    vtab = o.table(4).astype(np.float64)
+    for mode in (1, 2):
+        h = capi.Handle(sf=sf, samp_rate=RATES[decim], demod=mode)
+        for sigma in (0.0, synth.awgn_sigma_for_snr(-3.0, cfg)):
+            x = _noisy(iq, sigma, rng)
+            dev = _dev(x)
+            g, gf = h.demod_symbols_ex_device(dev.data_ptr(), x.size, offs, mode)
+            w = o.demod_at(x, offs, 1).astype(np.int64)
+            d = np.abs(g.astype(np.int64) - w)
+            d = np.minimum(d, cfg.nbins - d)
+            if sigma == 0.0:
+                # (a window cut D / 2 samples off its symbol sits half a bin off: two bins tie up to float rounding - either may win)
+                half = (np.abs(slip) % decim) == decim // 2
+                assert (d[~half] == 0).all() and d.max() <= 1, (sf, decim, mode, np.nonzero(d)[0][:8], g[d != 0][:8], w[d != 0][:8], slip[d != 0][:8])
+                assert (g[slip == 0] == shifts[slip == 0]).all()
+            else:
+                assert d.max() <= 1 and (d == 0).mean() > 0.9, (sf, decim, mode, d.max(), (d == 0).mean())
+            bin_idx = np.where((w == 0) & (mode == 2), 0, (w + cfg.nbins - 1) % cfg.nbins)
+            n_nonzero = _check_fine(oracle_mod, o, vtab, cfg, x, offs, bin_idx, gf, d == 0, (sf, decim, mode, sigma))
+            assert n_nonzero > 10   # the slipped windows exercise lags -1 and +1
+        h.close()
+
+
+@pytest.mark.parametrize("decim", [2, 4])
+@pytest.mark.parametrize("sf", [7, 8, 9])
+def test_gradient_bin_and_fine_sync_vs_oracle(oracle_mod, sf, decim):
+    from gr_lora_amd import capi
+    cfg = synth.TxConfig(sf=sf, samp_rate=RATES[decim])
+    rng = np.random.default_rng(2000 + 10 * sf + decim)
+    shifts, iq, offs, slip = _windows(cfg, rng, 96)
+    o = oracle_mod.Oracle(sf=sf, samp_rate=RATES[decim], demod=0)
+    vtab = o.table(4).astype(np.float64)
+    h = capi.Handle(sf=sf, samp_rate=RATES[decim], demod=0)
+    for sigma in (0.0, synth.awgn_sigma_for_snr(20.0, cfg), synth.awgn_sigma_for_snr(6.0, cfg)):
+        x = _noisy(iq, sigma, rng)
+        dev = _dev(x)
+        g, gf = h.demod_symbols_ex_device(dev.data_ptr(), x.size, offs, 0)
+        w = np.array([o.max_frequency_gradient_idx(x[a:a + cfg.sps]) for a in offs], dtype=np.int64)
+        same = g.astype(np.int64) == w
+        if sigma == 0.0:
+            half = (np.abs(slip) % decim) == decim // 2   # (half a bin off: the drop is shared by two neighbouring differences that tie)
+            assert same[~half].all(), (sf, decim, np.nonzero(~same)[0][:8], g[~same][:8], w[~same][:8])
+            _only_ties(oracle_mod, cfg, x, offs, g, w)
+        else:
+            # the largest drop between D-sample averages of a noisy ifreq: where two drops tie to float rounding (tree sum here,
+            # sequential sum there) the pick may differ - rare, and never on clean input
+            assert same.mean() > 0.95, (sf, decim, sigma, same.mean())
+        n_nonzero = _check_fine(oracle_mod, o, vtab, cfg, x, offs, w, gf, same, (sf, decim, sigma))
+        if sigma == 0.0:
+            assert n_nonzero > 10
+    h.close()
+
+
+@pytest.mark.parametrize("decim", [2, 4])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_windows_with_zero_samples(oracle_mod, decim, mode):
+    """samples of exactly zero inside a window: std::arg(0) = 0 in the reference's instantaneous frequency (:231-243); the fast evaluation
+    comes back poisoned and the ZM instantiation decides - same bins, same fine_sync as the oracle."""
+    from gr_lora_amd import capi
+    sf = 8
+    cfg = synth.TxConfig(sf=sf, samp_rate=RATES[decim])
+    rng = np.random.default_rng(3000 + decim + mode)
+    shifts, iq, offs, slip = _windows(cfg, rng, 48)
+    x = iq.copy()
+    for i in range(0, 48, 2):   # every other window: one to three zeros, some at the window's ends
+        a = int(offs[i])
+        for p in rng.integers(0, cfg.sps, int(rng.integers(1, 4))):
+            x[a + int(p)] = 0
+    x[int(offs[2])] = 0
+    x[int(offs[4]) + cfg.sps - 1] = 0
+    x[int(offs[6]) + cfg.sps - 2] = 0
+    o = oracle_mod.Oracle(sf=sf, samp_rate=RATES[decim], demod=mode)
+    h = capi.Handle(sf=sf, samp_rate=RATES[decim], demod=mode)
+    dev = _dev(x)
+    g, gf = h.demod_symbols_ex_device(dev.data_ptr(), x.size, offs, mode)
+    if mode == 0:
+        w = np.array([o.max_frequency_gradient_idx(x[a:a + cfg.sps]) for a in offs], dtype=np.int64)
+        bin_idx = w
+    else:
+        w = o.demod_at(x, offs, 1).astype(np.int64)
+        bin_idx = (w + cfg.nbins - 1) % cfg.nbins
+    same = g.astype(np.int64) == w
+    if mode == 0:
+        _only_ties(oracle_mod, cfg, x, offs, g, w)
+        assert same.mean() > 0.8
+    else:
+        assert same.all(), (np.nonzero(~same)[0], g[~same], w[~same])
+    vtab = o.table(4).astype(np.float64)
+    _check_fine(oracle_mod, o, vtab, cfg, x, offs, bin_idx, gf, same, (decim, mode))
+    h.close()
