@@ -303,7 +303,7 @@ __device__ __forceinline__ void w2_detect_windows(const float2 *__restrict__ p, 
 // FIND_SFD (:385-390, :283-298, :801-803): Pearson correlation of the window's ifreq with the ideal
 // downchirp ifreq, and -- for an upchirp (c < -0.97) -- fine_sync(-1, 4*D) over the 63 lags.
 struct W2SfdOut { float c; int32_t fine; int32_t pz; }; // pz: the window holds a sample of exactly zero (its sums are NaN): to be evaluated again with ZM = true
-template <int SF, bool ZM = false>
+template <int SF, bool ZM = false, int SEARCH = 32 /* fine_sync(-1, 4 D), :801-803: the lags |i| < 4 D (decimation 2 / 4: 8 / 16) */>
 __device__ __forceinline__ W2SfdOut w2_sfd_window(const float2 *p, const float *Tv, const float *Tdd, float *scr /* this wavefront's 72 floats */,
                                                           float down_ifreq_sd, float down_ifreq_dsum, double sync_a, double sync_b)
 {
@@ -382,7 +382,9 @@ __device__ __forceinline__ W2SfdOut w2_sfd_window(const float2 *p, const float *
     }
     const float hsum = __shfl(ps, lane < 31 ? 30 - lane : 0, 64); // H_{-i} for the negative lags
     float c_i = -3.0e38f;
-    if (lane <= 62) {
+    bool in_range = lane <= 62;
+    if constexpr (SEARCH < 32) in_range = in_range && i > -SEARCH && i < SEARCH;
+    if (in_range) {
         const double a = sync_a, b = sync_b;
         const double wd = (double)Tv[2 * SPS - 1] - (a + b * (double)(SPS - 1));
         double edge;
@@ -420,7 +422,7 @@ __device__ __attribute__((noinline)) void w2_sync_closed_form(const float *f2, d
                 //   C[i] = a S0[i] + b S1[i],   S0[i] = sum_k f[i+k],   S1[i] = sum_k k f[i+k]
                 // and both come from prefix sums of f and (t - sps) f in double: O(sps) instead of O(sps^2).
                 // Prefixes are kept per chunk of CH samples (256 chunks); a thread adds the few samples up to its shift.
-                constexpr uint32_t NCH = 256u, CH = 2u * sps / NCH, n = sps - 1u;
+                constexpr uint32_t NCH = 2u * sps / 4u < 256u ? 2u * sps / 4u : 256u, CH = 2u * sps / NCH, n = sps - 1u; // (chunks of at least one float4: sps = 256 has 128)
                 double sF = 0.0, sG = 0.0;
                 if (threadIdx.x < NCH) {
     #pragma unroll
@@ -505,23 +507,29 @@ __device__ __attribute__((noinline)) void w2_sync_exact_ifreq(const float2 *__re
 #ifndef LORA_W2_ZM_ATTR
 #define LORA_W2_ZM_ATTR __forceinline__ // (as calls - noinline - they cost the gradient kernels 7 % in register allocation, and the calls themselves faulted: profiles/r05_ab_zero_samples.txt)
 #endif
-template <int SF>
+template <int SF, int SEARCH = 32>
 __device__ LORA_W2_ZM_ATTR W2SfdOut w2_sfd_window_zm(const float2 *p, const float *Tv, const float *Tdd, float *scr, float down_ifreq_sd, float down_ifreq_dsum, double sync_a, double sync_b)
 {
-    return w2_sfd_window<SF, true>(p, Tv, Tdd, scr, down_ifreq_sd, down_ifreq_dsum, sync_a, sync_b);
+    return w2_sfd_window<SF, true, SEARCH>(p, Tv, Tdd, scr, down_ifreq_sd, down_ifreq_dsum, sync_a, sync_b);
 }
 template <int SF> constexpr bool kW2Alias = SF == 8; // SYNC's work areas inside the FFT table block (walker2_body ALIAS)
 struct W2DemodZ { uint32_t s; int32_t fine; float en; };
-template <int SF, bool GRAD>
+template <int SF, bool GRAD, int LD = 3>
 __device__ LORA_W2_ZM_ATTR W2DemodZ w2_demod_zm(uint32_t enable_fine_sync, uint32_t demod_mode, bool want_energy, WaveTabs T, const float2 *x)
 {
     DevParams Q{}; // (only the fields the demodulators read)
     Q.enable_fine_sync = enable_fine_sync; Q.demod_mode = demod_mode;
     W2DemodZ r{0u, 0, 0.0f};
+    if constexpr (LD != 3) {
+        if constexpr (GRAD) wave_demod_symbol_grad_d<SF, LD, true>(Q, T.v, x, want_energy, r.s, r.fine, r.en);
+        else wave_demod_symbol_d<SF, LD, true>(Q, T, x, r.s, r.fine, want_energy ? &r.en : nullptr);
+    } else
     if constexpr (GRAD) wave_demod_symbol_grad<SF, true>(Q, T.v, x, want_energy, r.s, r.fine, r.en);
     else wave_demod_symbol<SF, 0, true>(Q, T, x, r.s, r.fine, want_energy ? &r.en : nullptr);
     return r;
 }
+// 8-byte entries of the demodulator's table block (decimation 8: lora_wave_demod.inc.hip; 2 / 4: lora_wave_decim.inc.hip)
+template <int SF, int LD> constexpr uint32_t w2_table_entries() { if constexpr (LD == 3) return WaveGeom<SF>::n_ent; else return WaveGeomD<SF, LD>::n_ent; }
 
 // ---- the kernel -----------------------------------------------------------------------------------------
 // GRAD: the reference's shipped demodulator (max_frequency_gradient_idx, :466-491, :499) in the decode rounds instead of the
@@ -529,10 +537,14 @@ __device__ LORA_W2_ZM_ATTR W2DemodZ w2_demod_zm(uint32_t enable_fine_sync, uint3
 // SKIP: the header-only variant of a decoupled pass (LaunchCfg.skip_payload; docs/LAB_NOTEBOOK.md 4.13, as walker3's): behind the header parse (:831-847) the attempt is
 // closed as kAttemptHeaderOnly - the record carries d_phdr, the header block's spare codewords and d_payload_symbols - and the job goes on in DETECT where
 // DECODE_PAYLOAD would end if no symbol moved the symbol clock; the payload pass (launch_demod_symbols + payload_chain_kernel) does the rest.
-template <int SF, int WAVES, bool GRAD, bool SKIP = false>
+// LD: log2 of the decimation.  2 / 1 (decimation 4 / 2, round 6): the same state machine on windows of sps = D N samples - the window-level helpers are
+// instantiated for the SF that has this sps at decimation 8 (GSF), the demodulators come from lora_wave_decim.inc.hip, FIND_SFD's fine_sync searches 4 D lags.
+template <int SF, int WAVES, bool GRAD, bool SKIP = false, int LD = 3>
 __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg &C)
 {
-    constexpr int N = 1 << SF, SPS = 8 * N;
+    constexpr int N = 1 << SF, SPS = N << LD;
+    constexpr int GSF = SF + LD - 3; // 8 << GSF == SPS
+    constexpr uint32_t NENT = w2_table_entries<SF, LD>();
     constexpr int kW2 = 64 * WAVES, kW2Workers = WAVES - 1; // the last wavefront is the control wavefront
     // Decode rounds look at kW2Win windows: one per worker.  (A second window for the worker that shares its SIMD with the mostly waiting control
     // wavefront was built and measured 13 % slower - the SIMD time-slices its wavefronts evenly, docs/LAB_NOTEBOOK.md 5.2 - and is gone from the sources.)
@@ -548,7 +560,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     // demodulator | chunk prefix sums of the SYNC correlation
     // ALIAS (SF8): SYNC's two work areas lie IN the twiddle block - which only decode rounds read - and every SYNC round ends by copying the
     // block in again (36 KB from L2, once per acquisition): 73 KB instead of 94 KB, two workgroups per CU
-    constexpr bool ALIAS = kW2Alias<SF> && !GRAD;
+    constexpr bool ALIAS = kW2Alias<SF> && !GRAD && LD == 3;
     constexpr uint32_t NV = (3u * SPS + 40u + 3u) & ~3u;
     float *lds0 = reinterpret_cast<float *>(smem + ((sizeof(W2Shared) + 15) & ~(size_t)15));
     float *vl = ALIAS ? lds0 : lds0 + 2 * SPS;
@@ -556,8 +568,8 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
     v2f *tab2 = reinterpret_cast<v2f *>(ddl + SPS);
     float *f2 = ALIAS ? reinterpret_cast<float *>(tab2) : lds0;
     double *pre = ALIAS ? reinterpret_cast<double *>(f2 + 2 * SPS)
-                        : reinterpret_cast<double *>(tab2 + (GRAD ? 0u : WaveGeom<SF>::n_ent)); // SYNC: chunk prefix sums (2 x 256) + per-wavefront totals
-    static_assert(!ALIAS || (2u * SPS * 4u + (2u * 256u + 8u) * 8u <= WaveGeom<SF>::n_ent * 8u), "SYNC's work areas fit the table block");
+                        : reinterpret_cast<double *>(tab2 + (GRAD ? 0u : NENT)); // SYNC: chunk prefix sums (2 x 256) + per-wavefront totals
+    static_assert(!ALIAS || (2u * SPS * 4u + (2u * 256u + 8u) * 8u <= NENT * 8u), "SYNC's work areas fit the table block");
 
     const uint32_t jid = blockIdx.x;
     if (jid >= C.n_jobs) return;
@@ -579,7 +591,8 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         for (uint32_t i = threadIdx.x; i < 3u * sps + 40u; i += kW2) vl[i] = P.up_ifreq_v[i];
         FT.v = vl;
     } else {
-        FT = wave_tabs_to_lds<SF>(P, tab2, vl, kW2);
+        if constexpr (LD == 3) FT = wave_tabs_to_lds<SF>(P, tab2, vl, kW2);
+        else FT = wave_tabs_to_lds_d<SF, LD>(P, tab2, vl, kW2);
     }
     for (uint32_t i = threadIdx.x; i < sps; i += kW2) ddl[i] = P.down_ifreq[i] - P.down_ifreq_avg;
 
@@ -685,8 +698,8 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 }
                 float a[kW2DetectK][4];
                 if (nvalid > 0) {
-                    if (kd == 1) { const float4 r = w2_detect_window<SF>(X + dpos); a[0][0] = r.x; a[0][1] = r.y; a[0][2] = r.z; a[0][3] = r.w; }
-                    else w2_detect_windows<SF, kW2DetectK>(X + dpos, nvalid, a);
+                    if (kd == 1) { const float4 r = w2_detect_window<GSF>(X + dpos); a[0][0] = r.x; a[0][1] = r.y; a[0][2] = r.z; a[0][3] = r.w; }
+                    else w2_detect_windows<GSF, kW2DetectK>(X + dpos, nvalid, a);
                 }
                 if (lane == 0) {
                     W.detn[wave] = nvalid;
@@ -770,7 +783,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         if (plan_mode == kPlanSync) { // :770-783, detect_upchirp :392-413 -- all wavefronts together
             const float2 *__restrict__ x = X + pos;
             if (P.strict_sync) {
-                w2_sync_exact_ifreq<SF, WAVES>(x, f2);
+                w2_sync_exact_ifreq<GSF, WAVES>(x, f2);
             } else {
                 constexpr int NI = (2 * SPS + kW2 - 1) / kW2; // samples per thread: all loads first, then the arithmetic
                 float2 xb[NI], xa[NI];
@@ -792,7 +805,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             __syncthreads();
             float bv, b2;
             int bi, i2;
-            w2_sync_closed_form<SF, WAVES>(f2, pre, P.sync_a, P.sync_b, bv, bi, b2, i2);
+            w2_sync_closed_form<GSF, WAVES>(f2, pre, P.sync_a, P.sync_b, bv, bi, b2, i2);
             const float my_bv = bv;
             const int my_bi = bi;
             w2_block_argmax_first<WAVES>(bv, bi, W.red);
@@ -802,7 +815,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 const int nc = W.sc.n;
                 if (nc >= 2 && nc <= strict::kK) {
                     float ev;
-                    if constexpr (SF == 7) bi = strict::resolve_lds_inl<kW2>(f2, SPS, vl, &W.sc, reinterpret_cast<float *>(pre), 1024, &ev); // (inline: see resolve_lds)
+                    if constexpr (SF == 7 && LD == 3) bi = strict::resolve_lds_inl<kW2>(f2, SPS, vl, &W.sc, reinterpret_cast<float *>(pre), 1024, &ev); // (inline: see resolve_lds)
                     else bi = strict::resolve_lds<kW2>(f2, SPS, vl, &W.sc, reinterpret_cast<float *>(pre), 1024, &ev); // (the closed form's prefix sums are done with: 4160 bytes; vl[k] = d_upchirp_ifreq[k], k < sps-1)
                     bv = ev;
                 }
@@ -819,7 +832,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             if constexpr (ALIAS) { // the twiddle block back over SYNC's work areas (visible behind the next round's barrier)
                 __syncthreads();
                 const v2f *__restrict__ src = reinterpret_cast<const v2f *>(P.wave_tabs);
-                for (uint32_t i = threadIdx.x; i < WaveGeom<SF>::n_ent; i += kW2) tab2[i] = src[i];
+                for (uint32_t i = threadIdx.x; i < NENT; i += kW2) tab2[i] = src[i];
             }
             continue;
         }
@@ -839,8 +852,8 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 int32_t fine = 0;
                 int32_t pz = 0;
                 if (kvalid) {
-                    const W2SfdOut r = plan_z ? w2_sfd_window_zm<SF>(X + kpos, T.v, T.dd, T.scratch + wave * 72, P.down_ifreq_sd, P.down_ifreq_dsum, P.sync_a, P.sync_b)
-                                              : w2_sfd_window<SF>(X + kpos, T.v, T.dd, T.scratch + wave * 72, P.down_ifreq_sd, P.down_ifreq_dsum, P.sync_a, P.sync_b);
+                    const W2SfdOut r = plan_z ? w2_sfd_window_zm<GSF, (4 << LD)>(X + kpos, T.v, T.dd, T.scratch + wave * 72, P.down_ifreq_sd, P.down_ifreq_dsum, P.sync_a, P.sync_b)
+                                              : w2_sfd_window<GSF, false, (4 << LD)>(X + kpos, T.v, T.dd, T.scratch + wave * 72, P.down_ifreq_sd, P.down_ifreq_dsum, P.sync_a, P.sync_b);
                     c = r.c; fine = r.fine; pz = r.pz;
                 }
                 if (lane == 0 && !is_ctl) { W.specf[wave][k] = c; W.speci[k][wave][0] = kvalid ? 1 : 0; W.speci[k][wave][1] = fine; W.speci[k][wave][2] = pz; }
@@ -946,8 +959,12 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                 float wen = 0.0f;
                 if (dvalid) {
                     if (plan_z) { // (uniform) a round of ZM evaluations: a window of the previous round holds a sample of exactly zero
-                        const W2DemodZ z = w2_demod_zm<SF, GRAD>(P.enable_fine_sync, P.demod_mode, P.implicit != 0u, FT, X + dwpos);
+                        const W2DemodZ z = w2_demod_zm<SF, GRAD, LD>(P.enable_fine_sync, P.demod_mode, P.implicit != 0u, FT, X + dwpos);
                         ws = z.s; wfine = z.fine; wen = z.en;
+                    } else
+                    if constexpr (LD != 3) {
+                        if constexpr (GRAD) wave_demod_symbol_grad_d<SF, LD>(P, FT.v, X + dwpos, P.implicit != 0u, ws, wfine, wen);
+                        else wave_demod_symbol_d<SF, LD>(P, FT, X + dwpos, ws, wfine, P.implicit != 0u ? &wen : nullptr);
                     } else
                     if constexpr (GRAD) wave_demod_symbol_grad<SF>(P, FT.v, X + dwpos, P.implicit != 0u, ws, wfine, wen); // ws = bin_idx itself; kPoisonBin: see W2Plan.zmode
                     else wave_demod_symbol<SF, kWaveFmode<SF>>(P, FT, X + dwpos, ws, wfine, P.implicit != 0u ? &wen : nullptr);
@@ -1128,12 +1145,26 @@ __global__ __launch_bounds__(64 * kW2WavesSf8, 2) void walker2_kernel_sf8_skip(D
 __global__ __launch_bounds__(64 * kW2WavesSf7, LORA_W2_EU_GRAD_SF7) void walker2_kernel_sf7_grad_skip(DevParams P, LaunchCfg C) { walker2_body<7, kW2WavesSf7, true, true>(P, C); }
 __global__ __launch_bounds__(64 * kW2WavesSf8, LORA_W2_EU_GRAD_SF8) void walker2_kernel_sf8_grad_skip(DevParams P, LaunchCfg C) { walker2_body<8, kW2WavesSf8, true, true>(P, C); }
 
+// decimation 4 / 2 (lora_wave_decim.inc.hip): 128 registers, two workgroups per CU
+#define LORA_W2_DECIM_KERNEL(SFV, DV, LDV) \
+    __global__ __launch_bounds__(512, 4) void walker2_kernel_sf##SFV##_d##DV(DevParams P, LaunchCfg C) { walker2_body<SFV, 8, false, false, LDV>(P, C); } \
+    __global__ __launch_bounds__(512, 4) void walker2_kernel_sf##SFV##_d##DV##_grad(DevParams P, LaunchCfg C) { walker2_body<SFV, 8, true, false, LDV>(P, C); }
+LORA_W2_DECIM_KERNEL(7, 2, 1)
+LORA_W2_DECIM_KERNEL(7, 4, 2)
+LORA_W2_DECIM_KERNEL(8, 2, 1)
+LORA_W2_DECIM_KERNEL(8, 4, 2)
+#undef LORA_W2_DECIM_KERNEL
+static bool walker2_decim_covers(uint32_t sf, uint32_t decim) { return (decim == 2u || decim == 4u) && (sf == 7u || sf == 8u); }
+
 static uint32_t walker2_threads(uint32_t sf) { return 64u * (uint32_t)(sf == 7u ? kW2WavesSf7 : kW2WavesSf8); }
 
-static uint32_t walker2_lds_bytes(uint32_t sf, bool grad = false)
+static uint32_t walker2_lds_bytes(uint32_t sf, bool grad = false, uint32_t decim = 8u)
 {
-    const uint32_t sps = 8u << sf;
+    const uint32_t sps = decim << sf;
     const uint32_t nv = (3u * sps + 40u + 3u) & ~3u;
+    if (decim != 8u)
+        return (uint32_t)((sizeof(W2Shared) + 15) & ~(size_t)15) + (2u * sps + nv + sps) * (uint32_t)sizeof(float) +
+               (grad ? 0u : wave_tables_floats_d(sf, decim) * (uint32_t)sizeof(float)) + (2u * 256u + 8u) * (uint32_t)sizeof(double);
     if (!grad && sf == 8u && kW2Alias<8>) // (SYNC's work areas inside the table block)
         return (uint32_t)((sizeof(W2Shared) + 15) & ~(size_t)15) + (nv + sps) * (uint32_t)sizeof(float) + wave_tables_floats(sf) * (uint32_t)sizeof(float);
     return (uint32_t)((sizeof(W2Shared) + 15) & ~(size_t)15) + (2u * sps + nv + sps) * (uint32_t)sizeof(float) +

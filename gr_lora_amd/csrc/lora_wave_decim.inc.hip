@@ -48,17 +48,21 @@ __device__ __forceinline__ v2f dpp2_xor4(v2f v)
 }
 
 template <int SF, int LD>
-__device__ __forceinline__ WaveTabs wave_tabs_to_lds_d(const DevParams &P, unsigned char *lds, uint32_t nthreads)
-{ // WaveGeomD::lds_bytes bytes: [down | twn | tws | xst | ifreq template]
+__device__ __forceinline__ WaveTabs wave_tabs_to_lds_d(const DevParams &P, v2f *l2, float *lv, uint32_t nthreads)
+{ // [down | twn | tws | xst] -> l2 (n_ent entries), the ifreq template -> lv (n_v floats)
     using G = WaveGeomD<SF, LD>;
-    v2f *l2 = reinterpret_cast<v2f *>(lds);
-    float *lv = reinterpret_cast<float *>(l2 + G::n_ent);
     const v2f *__restrict__ src = reinterpret_cast<const v2f *>(P.wave_tabs);
     for (uint32_t i = threadIdx.x; i < G::n_ent; i += nthreads) l2[i] = src[i];
     for (uint32_t i = threadIdx.x; i < 3u * G::SPS + 40u; i += nthreads) lv[i] = P.up_ifreq_v[i];
     WaveTabs T{};
     T.down = l2; T.twn = l2 + G::n_down; T.tws = T.twn + G::n_twn; T.xst = T.tws + G::n_tws; T.v = lv;
     return T;
+}
+template <int SF, int LD>
+__device__ __forceinline__ WaveTabs wave_tabs_to_lds_d(const DevParams &P, unsigned char *lds, uint32_t nthreads)
+{ // WaveGeomD::lds_bytes bytes
+    v2f *l2 = reinterpret_cast<v2f *>(lds);
+    return wave_tabs_to_lds_d<SF, LD>(P, l2, reinterpret_cast<float *>(l2 + WaveGeomD<SF, LD>::n_ent), nthreads);
 }
 
 // fine_sync (:300-338) with search = max(D / 4, 2) = 2: lags -1, 0, +1, the window's ifreq from memory.  ZM: every value as the reference forms it

@@ -168,3 +168,119 @@ def test_windows_with_zero_samples(oracle_mod, decim, mode):
     vtab = o.table(4).astype(np.float64)
     _check_fine(oracle_mod, o, vtab, cfg, x, offs, bin_idx, gf, same, (decim, mode))
     h.close()
+
+
+# ---- the whole receive path: walker2 at decimation 2 / 4 (SF7 / SF8) ---------------------------------------------------------------------------
+
+def _gpu_decode(iq, streams=None, **kw):
+    import torch
+    from gr_lora_amd import capi
+    h = capi.Handle(**kw)
+    dev = _dev(iq)
+    if streams is None:
+        streams = [(0, iq.size)]
+    h.decode_device(dev.data_ptr(), iq.size, [s[0] for s in streams], [s[1] for s in streams], torch.cuda.current_stream().cuda_stream)
+    out, tr, tm, name = h.drain(), h.trace(), h.timing(), h.kernel_name()
+    h.close()
+    return out, tr, tm, name
+
+
+@pytest.mark.parametrize("decim", [2, 4])
+@pytest.mark.parametrize("sf", [7, 8, 9])
+def test_kernel_selection(sf, decim):
+    """no silent fall-back to the generic walker (lora_hip_walker_kernel_name): SF7 / SF8 run walker2's decimation-2 / 4 builds; SF9's words
+    do not fit walker2's one-byte word registers - its walker stays the generic one (its symbol-level kernels are the wave ones)"""
+    from gr_lora_amd import capi
+    for demod, implicit in ((0, False), (0, True), (2, False), (1, True)):
+        h = capi.Handle(sf=sf, samp_rate=RATES[decim], demod=demod, implicit=implicit)
+        want = "walker2_kernel_sf%d_d%d%s" % (sf, decim, "_grad" if demod == 0 else "") if sf <= 8 else None
+        if want:
+            assert h.kernel_name() == want, (sf, decim, demod, implicit, h.kernel_name())
+        else:
+            assert h.kernel_name().startswith("walker_kernel")
+        h.close()
+
+
+@pytest.mark.parametrize("decim", [2, 4])
+@pytest.mark.parametrize("sf", [7, 8])
+@pytest.mark.parametrize("demod", [0, 1, 2])
+def test_frames_positions_and_trace_match_oracle(oracle_mod, sf, decim, demod):
+    """every step of decoder_impl::work (:740-903) - state, samples consumed, position, bin, d_fine_sync - against the oracle's trace"""
+    from gr_lora_amd import capi
+    cfg = synth.TxConfig(sf=sf, cr=4, samp_rate=RATES[decim])
+    rng = np.random.default_rng(4000 + 10 * sf + decim)
+    payloads = [bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8)) for _ in range(5)]
+    st = synth.build_stream(payloads, cfg, rng=rng)
+    o = oracle_mod.Oracle(sf=sf, cr=4, samp_rate=RATES[decim], demod=demod)
+    o.enable_trace()
+    o.run(st.iq)
+    want = o.frames()
+    assert len(want) == 5
+    got, tr, _, name = _gpu_decode(st.iq, sf=sf, cr=4, samp_rate=RATES[decim], demod=demod, flags=capi.FLAG_TRACE)
+    assert name.startswith("walker2_kernel_sf%d_d%d" % (sf, decim))
+    assert [g for g, _ in got] == want
+    assert [i.header_pos for _, i in got] == o.frame_positions()
+    otr = o.trace()
+    assert len(tr) == len(otr)
+    for a, b in zip(tr, otr):
+        assert (a[0], a[1], a[2], a[3], a[4]) == (b[0], b[1], b[2], b[3], b[4]), (a, b)
+        if np.isfinite(b[5]):
+            assert abs(a[5] - b[5]) <= 1e-3 * max(1.0, abs(b[5])), (a, b)
+
+
+@pytest.mark.parametrize("decim", [2, 4])
+@pytest.mark.parametrize("sf,cr,demod", [(7, 1, 0), (7, 3, 2), (8, 2, 0), (8, 4, 1)])
+def test_many_packets_with_noise_in_segments(oracle_mod, sf, cr, demod, decim):
+    """a stream long enough for the scheduler to cut it into jobs (speculation segments, tail probes): frames and header positions"""
+    cfg = synth.TxConfig(sf=sf, cr=cr, samp_rate=RATES[decim])
+    rng = np.random.default_rng(5000 + 100 * sf + 10 * cr + decim)
+    payloads = [bytes(rng.integers(0, 256, int(rng.integers(1, 64)), dtype=np.uint8)) for _ in range(48)]
+    # (the reference's acquisition and its gradient estimator work on D-sample statistics of the instantaneous frequency: at decimation 2 / 4 they
+    # need a cleaner channel than at 8 - at 25 dB the oracle itself finds 15-20 of these 48 packets)
+    st = synth.build_stream(payloads, cfg, rng=rng, gap_symbols=(2.0, 12.0), noise_sigma=synth.awgn_sigma_for_snr(45.0, cfg))
+    o = oracle_mod.Oracle(sf=sf, cr=4, samp_rate=RATES[decim], demod=demod)
+    o.run(st.iq)
+    want = o.frames()
+    assert len(want) >= 24
+    got, _, tm, name = _gpu_decode(st.iq, sf=sf, cr=4, samp_rate=RATES[decim], demod=demod)
+    assert name.startswith("walker2_kernel_sf%d_d%d" % (sf, decim))
+    assert [g for g, _ in got] == want
+    assert [i.header_pos for _, i in got] == o.frame_positions()
+
+
+@pytest.mark.parametrize("decim", [2, 4])
+@pytest.mark.parametrize("sf,demod", [(7, 0), (8, 2)])
+def test_implicit_header(oracle_mod, sf, demod, decim):
+    cfg = synth.TxConfig(sf=sf, cr=3, crc=False, implicit=True, samp_rate=RATES[decim])
+    rng = np.random.default_rng(6000 + 10 * sf + decim)
+    payloads = [bytes(rng.integers(0, 256, int(rng.integers(3, 40)), dtype=np.uint8)) for _ in range(10)]
+    st = synth.build_stream(payloads, cfg, rng=rng, gap_symbols=(3.0, 9.0), noise_sigma=synth.awgn_sigma_for_snr(40.0, cfg))
+    kw = dict(sf=sf, cr=3, crc=False, implicit=True, samp_rate=RATES[decim])
+    o = oracle_mod.Oracle(demod=demod, **kw)
+    o.run(st.iq)
+    want = o.frames()
+    got, _, _, _ = _gpu_decode(st.iq, demod=demod, **kw)
+    assert [g for g, _ in got] == want and len(want) >= 8
+    assert [i.header_pos for _, i in got] == o.frame_positions()
+
+
+@pytest.mark.parametrize("decim", [2, 4])
+@pytest.mark.parametrize("sf,demod", [(7, 2), (8, 1)])   # (the gradient estimator next to a zero sample: ties - test_windows_with_zero_samples)
+def test_stream_with_zero_samples(oracle_mod, sf, demod, decim):
+    """samples of exactly zero scattered over the stream (preambles, sync words, headers, payloads): the poisoned windows go through the ZM rounds"""
+    from gr_lora_amd import capi
+    cfg = synth.TxConfig(sf=sf, cr=4, samp_rate=RATES[decim])
+    rng = np.random.default_rng(7000 + 10 * sf + decim)
+    payloads = [bytes(rng.integers(0, 256, int(rng.integers(4, 30)), dtype=np.uint8)) for _ in range(8)]
+    st = synth.build_stream(payloads, cfg, rng=rng)
+    x = st.iq.copy()
+    x[rng.integers(0, x.size, x.size // (6 * cfg.sps))] = 0
+    o = oracle_mod.Oracle(sf=sf, cr=4, samp_rate=RATES[decim], demod=demod)
+    o.enable_trace()
+    o.run(x)
+    got, tr, _, _ = _gpu_decode(x, sf=sf, cr=4, samp_rate=RATES[decim], demod=demod, flags=capi.FLAG_TRACE)
+    assert [g for g, _ in got] == o.frames()
+    otr = o.trace()
+    assert len(tr) == len(otr)
+    bad = [(a, b) for a, b in zip(tr, otr) if (a[0], a[1], a[2], a[3], a[4]) != (b[0], b[1], b[2], b[3], b[4])]
+    assert not bad, bad[:4]

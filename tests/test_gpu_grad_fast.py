@@ -31,7 +31,7 @@ def test_kernel_selection(sf):
         h = capi.Handle(sf=sf, demod=demod, implicit=implicit)
         assert h.kernel_name() == want, (sf, demod, implicit, h.kernel_name())
         h.close()
-    h = capi.Handle(sf=sf, samp_rate=5e5, demod=0)   # decimation 4: the generic kernels
+    h = capi.Handle(sf=sf, samp_rate=2e6, demod=0)   # decimation 16: the generic kernels (2 / 4: tests/test_gpu_decim.py)
     assert h.kernel_name().startswith("walker_kernel")
     h.close()
 
