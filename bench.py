@@ -59,11 +59,11 @@ def _cached(key, build):
     return iq, offs, lens, expect
 
 
-def make_workload(sf, cr, n_packets, payload_len, n_streams, seed):
+def make_workload(sf, cr, n_packets, payload_len, n_streams, seed, samp_rate=1e6):
     """config 2 / 3: n_packets packets of payload_len bytes in n_streams streams, zero gaps of 2-6 symbols"""
     from gr_lora_amd import synth
-    cfg = synth.TxConfig(sf=sf, cr=cr, crc=True, reduced_rate=(sf > 10))
-    key = "wl-sf%d-cr%d-%dx%dB-%dstreams-seed%d" % (sf, cr, n_packets, payload_len, n_streams, seed)
+    cfg = synth.TxConfig(sf=sf, cr=cr, crc=True, reduced_rate=(sf > 10), samp_rate=samp_rate)
+    key = "wl-sf%d-cr%d-%dx%dB-%dstreams-seed%d" % (sf, cr, n_packets, payload_len, n_streams, seed) + ("" if samp_rate == 1e6 else "-fs%d" % int(samp_rate))
     return (cfg,) + tuple(_cached(key, lambda: _make_workload(cfg, n_packets, payload_len, n_streams, seed)))
 
 
@@ -252,6 +252,7 @@ def main():
     ap.add_argument("--path", default="device", choices=["device", "work", "mux"])
     ap.add_argument("--sf", type=int, default=None)
     ap.add_argument("--cr", type=int, default=4)
+    ap.add_argument("--samp-rate", type=float, default=1e6, help="config 2 / 3: the decoder's sample rate at BW 125 kHz - 5e5 / 2.5e5 = decimation 4 / 2 (BASELINE's configs are all 1e6: decimation 8)")
     ap.add_argument("--packets", type=int, default=None)
     ap.add_argument("--payload", type=int, default=32)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("LORA_BENCH_STREAMS", "8")))
@@ -309,9 +310,10 @@ def main():
         packets = args.packets if args.packets is not None else (1024 if args.config == 2 else 256)
         if args.split:
             args.streams = 1
-        cfg, iq, offs, lens, expect = make_workload(sf, args.cr, packets, args.payload, min(args.streams, packets), seed=(2 if args.config == 2 else 100 * sf + 4) + (0 if args.split else 1000 * rank))
-        wl = "SF%d CR4/%d BW125k fs1M, %d packets x %d B payload per GPU, %d stream(s)" % (sf, 4 + args.cr, packets, args.payload, min(args.streams, packets))
-        wkey = "cfg%d-sf%d-cr%d-%dx%dB-%dstreams" % (args.config, sf, args.cr, packets, args.payload, min(args.streams, packets))
+        cfg, iq, offs, lens, expect = make_workload(sf, args.cr, packets, args.payload, min(args.streams, packets), seed=(2 if args.config == 2 else 100 * sf + 4) + (0 if args.split else 1000 * rank), samp_rate=args.samp_rate)
+        wl = "SF%d CR4/%d BW125k fs%s, %d packets x %d B payload per GPU, %d stream(s)" % (sf, 4 + args.cr, "1M" if args.samp_rate == 1e6 else "%gk (decimation %d)" % (args.samp_rate / 1e3, cfg.decim),
+                                                                                             packets, args.payload, min(args.streams, packets))
+        wkey = "cfg%d-sf%d-cr%d-%dx%dB-%dstreams" % (args.config, sf, args.cr, packets, args.payload, min(args.streams, packets)) + ("" if args.samp_rate == 1e6 else "-fs%d" % int(args.samp_rate))
     if args.demod != 2:
         wkey += "-demod%d" % args.demod        # (profiles/*pmc_traffic*.json are keyed by workload AND demodulator: another kernel)
     split_ranges = None

@@ -250,8 +250,11 @@ __device__ __forceinline__ void wave_demod_symbol_grad_d(const DevParams &P, con
     float prev_perm = 0.0f;
     en_out = 0.0f;
     auto bin_step = [&](int j, float A) { // A: this lane's ifreq[64 j + lane]
-        A += dpp_f<kDppQuadXor1>(A);
-        if constexpr (LD == 2) A += dpp_f<kDppQuadXor2>(A);
+        // the bin's D values added in the reference's order (volk_32f_accumulator_s32f's plain loop, :475: ((f0 + f1) + f2) + f3) - every lane of the group
+        // reads them by quad broadcast: a window cut half a bin off its symbol (two samples at D = 4) shares the drop between two neighbouring
+        // differences that tie up to this rounding
+        if constexpr (LD == 2) A = ((dpp_f<0x00>(A) + dpp_f<0x55>(A)) + dpp_f<0xAA>(A)) + dpp_f<0xFF>(A);
+        else A += dpp_f<kDppQuadXor1>(A); // (two values: the order does not matter)
         A *= 1.0f / (float)D; // / d_decim_factor (a power of two)
         const float perm = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm_addr, __builtin_bit_cast(int, A))); // bin (m - 1) mod LQ of this register
         const float left = (m == 0) ? prev_perm : perm; // bin i - 1: for m = 0 the last bin of the previous register
