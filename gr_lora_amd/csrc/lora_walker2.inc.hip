@@ -87,6 +87,7 @@ struct alignas(16) W2Shared {
     uint32_t prio;        // priority of the worker wavefronts for the coming rounds (see the balance exchange in the round loop)
     uint32_t words_pk[2]; // d_words of the current block, one byte per word (words < 256 for SF <= 8); control thread only
     strict::Cands sc;     // SYNC: near-tied shifts for the exact re-evaluation
+    uint32_t words_pk16[4]; // SF9 (decimation 2 / 4 builds): d_words of the current block as 16-bit fields; control thread only
 };
 
 struct W2Tabs {
@@ -168,7 +169,8 @@ __device__ __forceinline__ void w2_end_step(W2State &S, const Job &job, const La
 // Returns true when the payload is complete: the caller must run the workgroup-wide finalisation.
 // WAVE: called by the whole (converged) control wavefront with identical arguments; the deinterleaver then uses the lanes.
 // do_demod = false: an implicit-header payload step whose energy fell under the threshold (:861-864) - no word, the packet ends.
-template <bool WAVE = false>
+// W16: the words as 16-bit fields of wpk[0..3] (SF9) instead of bytes of wpk[0..1]
+template <bool WAVE = false, bool W16 = false>
 __device__ __forceinline__ bool w2_post_symbol(const DevParams &P, W2State &S, Shared &sh, uint32_t bin_idx, bool is_first, uint32_t *wpk = nullptr, bool do_demod = true)
 {
     const bool reduced = is_first || P.reduced_rate; // :495
@@ -177,6 +179,13 @@ __device__ __forceinline__ bool w2_post_symbol(const DevParams &P, W2State &S, S
     if (reduced) bin_idx = (uint32_t)lroundf((float)bin_idx / 4.0f) & (P.nbins_hdr - 1u); // :507-509 (% N/4, a power of two, of a value >= 0)
     const uint32_t word = bin_idx ^ (bin_idx >> 1u); // :512
     const uint32_t need = 4u + (is_first ? 4u : S.cr); // :521
+    if constexpr (WAVE && W16) {
+        const uint32_t sh16 = 16u * (S.n_words & 1u), ins = (word & 0xffffu) << sh16, keep = ~(0xffffu << sh16), q = S.n_words >> 1;
+        if (q == 0u) wpk[0] = (wpk[0] & keep) | ins; // (no dynamic index: the array stays in registers)
+        else if (q == 1u) wpk[1] = (wpk[1] & keep) | ins;
+        else if (q == 2u) wpk[2] = (wpk[2] & keep) | ins;
+        else if (q == 3u) wpk[3] = (wpk[3] & keep) | ins;
+    } else
     if constexpr (WAVE) { // the block's words stay in a register: no LDS round trip per symbol
         const uint32_t sh8 = 8u * (S.n_words & 3u), ins = (word & 0xffu) << sh8, keep = ~(0xffu << sh8);
         if (S.n_words < 4u) wpk[0] = (wpk[0] & keep) | ins;
@@ -189,7 +198,8 @@ __device__ __forceinline__ bool w2_post_symbol(const DevParams &P, W2State &S, S
     if (S.n_words == need) {
         const uint32_t ppm = reduced ? P.sf - 2u : P.sf;
         uint32_t tmp = S.n_cw;
-        if constexpr (WAVE) deinterleave_block_wave(sh, ((uint64_t)wpk[1] << 32) | wpk[0], need, ppm, tmp); // ppm <= 8 on this kernel's SFs
+        if constexpr (WAVE && W16) { const uint32_t w4[4] = {wpk[0], wpk[1], wpk[2], wpk[3]}; deinterleave_block_wave16(sh, w4, need, ppm, tmp); }
+        else if constexpr (WAVE) deinterleave_block_wave(sh, ((uint64_t)wpk[1] << 32) | wpk[0], need, ppm, tmp); // ppm <= 8 on this kernel's SFs
         else deinterleave_block(sh, need, ppm, tmp);
         S.n_cw = (S.n_cw + ppm <= (uint32_t)kMaxCodewords) ? S.n_cw + ppm : (uint32_t)kMaxCodewords;
         S.n_words = 0;
@@ -974,7 +984,10 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         } else { // the whole control wavefront, uniformly (identical values in every lane); t0 does the stores
             bool predicted = true, zreq = false;
             const long long tr0 = clock64();
-            uint32_t wpk[2] = {W.words_pk[0], W.words_pk[1]};
+            constexpr bool W16 = SF > 8; // (SF9: decimation 2 / 4 only - at 8 it is walker3's)
+            uint32_t wpk[W16 ? 4 : 2];
+            if constexpr (W16) { wpk[0] = W.words_pk16[0]; wpk[1] = W.words_pk16[1]; wpk[2] = W.words_pk16[2]; wpk[3] = W.words_pk16[3]; }
+            else { wpk[0] = W.words_pk[0]; wpk[1] = W.words_pk[1]; }
             W2State L = S; // the resolve works on a register copy: every field access in LDS is a ~130-cycle round trip
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const long long tr1 = clock64();
@@ -1000,7 +1013,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                         const float ew = __builtin_bit_cast(float, __builtin_amdgcn_readlane(my_e, w));
                         if (ew < L.energy_threshold) { L.payload_symbols = 0; L.payload_length = L.n_cw / 2u; do_demod = false; bin_idx = 0u; step_bin = -1; fw = 0; }
                     }
-                    if (w2_post_symbol<true>(P, L, sh, bin_idx, is_first, wpk, do_demod)) { // payload complete: finalise with all threads
+                    if (w2_post_symbol<true, W16>(P, L, sh, bin_idx, is_first, wpk, do_demod)) { // payload complete: finalise with all threads
                         L.fin_pending = 1; L.fin_st = st_w; L.fin_consumed = (int32_t)sps + fw; L.fin_bin = step_bin; L.fin_fine = fw;
                         break;
                     }
@@ -1047,7 +1060,8 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
             if (t0) {
                 next = np;
                 S = L;
-                W.words_pk[0] = wpk[0]; W.words_pk[1] = wpk[1];
+                if constexpr (W16) { W.words_pk16[0] = wpk[0]; W.words_pk16[1] = wpk[1]; W.words_pk16[2] = wpk[2]; W.words_pk16[3] = wpk[3]; }
+                else { W.words_pk[0] = wpk[0]; W.words_pk[1] = wpk[1]; }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 W.stats.ctl[0] += (uint32_t)((tr1 - tr0) >> 6); W.stats.ctl[1] += (uint32_t)((tr2 - tr1) >> 6); W.stats.ctl[2] += (uint32_t)((tr3 - tr2) >> 6);
                 W.stats.ctl[3] += (uint32_t)((clock64() - tr3) >> 6);
@@ -1146,15 +1160,18 @@ __global__ __launch_bounds__(64 * kW2WavesSf7, LORA_W2_EU_GRAD_SF7) void walker2
 __global__ __launch_bounds__(64 * kW2WavesSf8, LORA_W2_EU_GRAD_SF8) void walker2_kernel_sf8_grad_skip(DevParams P, LaunchCfg C) { walker2_body<8, kW2WavesSf8, true, true>(P, C); }
 
 // decimation 4 / 2 (lora_wave_decim.inc.hip): 128 registers, two workgroups per CU
-#define LORA_W2_DECIM_KERNEL(SFV, DV, LDV) \
-    __global__ __launch_bounds__(512, 4) void walker2_kernel_sf##SFV##_d##DV(DevParams P, LaunchCfg C) { walker2_body<SFV, 8, false, false, LDV>(P, C); } \
-    __global__ __launch_bounds__(512, 4) void walker2_kernel_sf##SFV##_d##DV##_grad(DevParams P, LaunchCfg C) { walker2_body<SFV, 8, true, false, LDV>(P, C); }
-LORA_W2_DECIM_KERNEL(7, 2, 1)
-LORA_W2_DECIM_KERNEL(7, 4, 2)
-LORA_W2_DECIM_KERNEL(8, 2, 1)
-LORA_W2_DECIM_KERNEL(8, 4, 2)
+// (SF9 at decimation 4: 2048-sample windows, 32 samples per lane, 95 KB of LDS - one workgroup per CU at 256 registers)
+#define LORA_W2_DECIM_KERNEL(SFV, DV, LDV, EU) \
+    __global__ __launch_bounds__(512, EU) void walker2_kernel_sf##SFV##_d##DV(DevParams P, LaunchCfg C) { walker2_body<SFV, 8, false, false, LDV>(P, C); } \
+    __global__ __launch_bounds__(512, EU) void walker2_kernel_sf##SFV##_d##DV##_grad(DevParams P, LaunchCfg C) { walker2_body<SFV, 8, true, false, LDV>(P, C); }
+LORA_W2_DECIM_KERNEL(7, 2, 1, 4)
+LORA_W2_DECIM_KERNEL(7, 4, 2, 4)
+LORA_W2_DECIM_KERNEL(8, 2, 1, 4)
+LORA_W2_DECIM_KERNEL(8, 4, 2, 4)
+LORA_W2_DECIM_KERNEL(9, 2, 1, 4)
+LORA_W2_DECIM_KERNEL(9, 4, 2, 2)
 #undef LORA_W2_DECIM_KERNEL
-static bool walker2_decim_covers(uint32_t sf, uint32_t decim) { return (decim == 2u || decim == 4u) && (sf == 7u || sf == 8u); }
+static bool walker2_decim_covers(uint32_t sf, uint32_t decim) { return (decim == 2u || decim == 4u) && sf >= 7u && sf <= 9u; }
 
 static uint32_t walker2_threads(uint32_t sf) { return 64u * (uint32_t)(sf == 7u ? kW2WavesSf7 : kW2WavesSf8); }
 

@@ -188,21 +188,22 @@ def _gpu_decode(iq, streams=None, **kw):
 @pytest.mark.parametrize("decim", [2, 4])
 @pytest.mark.parametrize("sf", [7, 8, 9])
 def test_kernel_selection(sf, decim):
-    """no silent fall-back to the generic walker (lora_hip_walker_kernel_name): SF7 / SF8 run walker2's decimation-2 / 4 builds; SF9's words
-    do not fit walker2's one-byte word registers - its walker stays the generic one (its symbol-level kernels are the wave ones)"""
+    """no silent fall-back to the generic walker (lora_hip_walker_kernel_name; VERDICT r05 item 8's "done"): SF7 / SF8 / SF9 run walker2's
+    decimation-2 / 4 builds - by sample count SF9's windows are SF8's (decimation 4) and SF7's (2) at decimation 8; its 9-bit words
+    travel as 16-bit fields"""
     from gr_lora_amd import capi
     for demod, implicit in ((0, False), (0, True), (2, False), (1, True)):
         h = capi.Handle(sf=sf, samp_rate=RATES[decim], demod=demod, implicit=implicit)
-        want = "walker2_kernel_sf%d_d%d%s" % (sf, decim, "_grad" if demod == 0 else "") if sf <= 8 else None
-        if want:
-            assert h.kernel_name() == want, (sf, decim, demod, implicit, h.kernel_name())
-        else:
-            assert h.kernel_name().startswith("walker_kernel")
+        want = "walker2_kernel_sf%d_d%d%s" % (sf, decim, "_grad" if demod == 0 else "")
+        assert h.kernel_name() == want, (sf, decim, demod, implicit, h.kernel_name())
         h.close()
+    h = capi.Handle(sf=10, samp_rate=RATES[decim], demod=2)   # (SF10 and up at these decimations: the generic kernels)
+    assert h.kernel_name().startswith("walker_kernel")
+    h.close()
 
 
 @pytest.mark.parametrize("decim", [2, 4])
-@pytest.mark.parametrize("sf", [7, 8])
+@pytest.mark.parametrize("sf", [7, 8, 9])
 @pytest.mark.parametrize("demod", [0, 1, 2])
 def test_frames_positions_and_trace_match_oracle(oracle_mod, sf, decim, demod):
     """every step of decoder_impl::work (:740-903) - state, samples consumed, position, bin, d_fine_sync - against the oracle's trace"""
@@ -229,7 +230,7 @@ def test_frames_positions_and_trace_match_oracle(oracle_mod, sf, decim, demod):
 
 
 @pytest.mark.parametrize("decim", [2, 4])
-@pytest.mark.parametrize("sf,cr,demod", [(7, 1, 0), (7, 3, 2), (8, 2, 0), (8, 4, 1)])
+@pytest.mark.parametrize("sf,cr,demod", [(7, 1, 0), (7, 3, 2), (8, 2, 0), (8, 4, 1), (9, 1, 2), (9, 3, 0), (9, 4, 1)])
 def test_many_packets_with_noise_in_segments(oracle_mod, sf, cr, demod, decim):
     """a stream long enough for the scheduler to cut it into jobs (speculation segments, tail probes): frames and header positions"""
     cfg = synth.TxConfig(sf=sf, cr=cr, samp_rate=RATES[decim])
@@ -249,7 +250,7 @@ def test_many_packets_with_noise_in_segments(oracle_mod, sf, cr, demod, decim):
 
 
 @pytest.mark.parametrize("decim", [2, 4])
-@pytest.mark.parametrize("sf,demod", [(7, 0), (8, 2)])
+@pytest.mark.parametrize("sf,demod", [(7, 0), (8, 2), (9, 1), (9, 0)])
 def test_implicit_header(oracle_mod, sf, demod, decim):
     cfg = synth.TxConfig(sf=sf, cr=3, crc=False, implicit=True, samp_rate=RATES[decim])
     rng = np.random.default_rng(6000 + 10 * sf + decim)
@@ -265,7 +266,7 @@ def test_implicit_header(oracle_mod, sf, demod, decim):
 
 
 @pytest.mark.parametrize("decim", [2, 4])
-@pytest.mark.parametrize("sf,demod", [(7, 2), (8, 1)])   # (the gradient estimator next to a zero sample: ties - test_windows_with_zero_samples)
+@pytest.mark.parametrize("sf,demod", [(7, 2), (8, 1), (9, 2)])   # (the gradient estimator next to a zero sample: ties - test_windows_with_zero_samples)
 def test_stream_with_zero_samples(oracle_mod, sf, demod, decim):
     """samples of exactly zero scattered over the stream (preambles, sync words, headers, payloads): the poisoned windows go through the ZM rounds"""
     from gr_lora_amd import capi
@@ -286,7 +287,7 @@ def test_stream_with_zero_samples(oracle_mod, sf, demod, decim):
     assert not bad, bad[:4]
 
 
-@pytest.mark.parametrize("sf,decim,demod", [(7, 4, 2), (7, 2, 2), (8, 2, 1), (7, 4, 0), (8, 4, 0)])
+@pytest.mark.parametrize("sf,decim,demod", [(7, 4, 2), (7, 2, 2), (8, 2, 1), (7, 4, 0), (8, 4, 0), (9, 4, 2), (9, 2, 0)])
 def test_bench_cell_equals_oracle(oracle_mod, sf, decim, demod):
     """bench.py's config-3 cell at `--samp-rate 5e5 / 2.5e5` in small: packets of 32 bytes in 8 streams with gaps of 2-6 symbols of silence.  At these
     decimations the reference does not find every packet of such a stream (bench.py reports `bit_exact_vs_expected` false there): what has to hold is
