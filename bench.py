@@ -341,7 +341,7 @@ def main():
     # (fixtures exist for the seeds the ranks 0 .. 7 of the default workload use - config2-8streams[-rankR] - and for rank 0's seed of the config-3
     # cells; with --demod 0 a rank without one has no yardstick - the gradient estimator does not reproduce "payloads as sent" even on clean
     # input - and counts as unverified, not as failed: config.verified_ranks, and bit_exact_vs_expected is then null)
-    if args.demod == 0 and args.config in (2, 3) and not args.split:
+    if args.demod == 0 and args.config in (2, 3) and not args.split and args.samp_rate == 1e6:
         try:
             fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_ref.json")))
             want = dict(sf=sf, cr=args.cr, packets=packets, payload=args.payload, streams=min(args.streams, packets), seed=(2 if args.config == 2 else 100 * sf + 4) + 1000 * rank)
@@ -349,6 +349,10 @@ def main():
         except (OSError, ValueError):
             ref_fix = None
     unverifiable = args.demod == 0 and args.config in (2, 3) and ref_fix is None and rank != 0 and not args.split
+    # --samp-rate (decimation 2 / 4): the reference does not find every packet of these back-to-back workloads there, with any demodulator - "payloads as
+    # sent" is no yardstick; what the pass publishes is held to the oracle in tests/test_gpu_decim.py (test_bench_cell_equals_oracle), and the line says null
+    no_yardstick = args.samp_rate != 1e6
+    unverifiable = unverifiable or no_yardstick
 
     def _digest(frames):
         h = hashlib.sha256()
@@ -528,7 +532,7 @@ def main():
     else:
         total_items = whole_items if split_ranges is not None else n_items
         verified = verified and step_fp["bad"] == 0 and step_fp["n"] == steps_timed
-        verified_ranks = 1
+        verified_ranks = 0 if unverifiable else 1
 
     # The same workload through the reference's SHIPPED demodulator (max_frequency_gradient_idx, decoder_impl.cc:499; --demod 0
     # makes it the headline): its own kernels (walker2/3_*_grad), verified against what the compiled reference published on this IQ
@@ -538,7 +542,7 @@ def main():
         try:
             fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_ref.json")))
             wantk = dict(sf=sf, cr=args.cr, packets=packets, payload=args.payload, streams=min(args.streams, packets), seed=(2 if args.config == 2 else 100 * sf + 4))
-            gfix = next((e for e in fx.values() if all(e[k] == v for k, v in wantk.items())), None)
+            gfix = next((e for e in fx.values() if all(e[k] == v for k, v in wantk.items())), None) if args.samp_rate == 1e6 else None
         except (OSError, ValueError):
             gfix = None
         ghs = [capi.Handle(**dict(kw, demod=0)) for _ in range(depth)]

@@ -15,6 +15,6 @@ tests)
   tail -3 gpurun_out/ceil.log
   ;;
 profiles)
-  timeout 2700 bash tools/profile_all.sh
+  timeout 3300 bash tools/profile_all.sh
   ;;
 esac

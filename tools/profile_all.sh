@@ -34,6 +34,12 @@ python bench.py --config 3 --sf 7 --packets 256 --no-cpu-baseline 2>/dev/null | 
 python bench.py --config 3 --sf 8 --packets 256 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/sf8_256_line.json
 for sf in 7 8 9; do python bench.py --config 3 --sf $sf --packets 256 --lanes 2 --no-cpu-baseline --no-grad-line 2>/dev/null | tail -1 > gpurun_out/sf${sf}_256_lanes2_line.json; done   # two passes in flight on streams of their own: the job rate of a cell that leaves half of every CU idle
 python bench.py --config 4 --seconds 2 --lanes 1 --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/cfg4_2s_lanes1_line.json                          # config 4's default is six lanes (bench.py --lanes): this is the single pipeline of round 5
+# decimation 2 / 4 (round 6: walker2's LD builds, lora_wave_decim.inc.hip): the config-3 cell at 500 / 250 ksps, FFT demodulator; one cell on the generic kernels beside them
+for sf in 7 8 9; do for d in 4 2; do
+  python bench.py --config 3 --sf $sf --packets $([ $sf = 9 ] && echo 256 || echo 1024) --samp-rate $([ $d = 4 ] && echo 5e5 || echo 2.5e5) --no-cpu-baseline --no-grad-line 2>/dev/null | tail -1 > gpurun_out/sf${sf}_d${d}_line.json
+done; done
+LORA_HIP_NO_FAST=1 python bench.py --config 3 --sf 8 --packets 1024 --samp-rate 5e5 --steps 3 --warmup 1 --min-seconds 0.1 --no-cpu-baseline --no-grad-line 2>/dev/null | tail -1 > gpurun_out/sf8_d4_generic_line.json
+PROFILE_LINE_FLAGS="--no-cpu-baseline --no-grad-line" tools/profile_round.sh sf8_d4 --config 3 --sf 8 --packets 1024 --samp-rate 5e5
 tools/pmc_walker.sh sq_sf7
 tools/pmc_walker.sh sq_sf9 --config 3 --sf 9
 tools/pmc_walker.sh sq_sf12 --config 3 --sf 12
