@@ -1,5 +1,5 @@
-// lora_walker2.inc.hip -- the SF7 / SF8 (decimation 8, explicit header, FFT demodulators) walker.
-// Included by lora_kernels.hip.
+// lora_walker2.inc.hip -- the walker of the wave-per-symbol family: SF7 / SF8 at decimation 8 and, since round 6, SF7 / SF8 / SF9 at decimation 2 / 4
+// (walker2_body's LD; lora_wave_decim.inc.hip); every demodulator, explicit or implicit header.  Included by lora_kernels.hip.
 //
 // Same state machine as walker_body (decoder_impl::work, lib/decoder_impl.cc:740-903), organised in
 // ROUNDS: WAVES wavefronts = WAVES-1 workers + 1 control wavefront (512 threads: 7 workers; two workgroups per CU
