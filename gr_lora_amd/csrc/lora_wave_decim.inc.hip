@@ -11,8 +11,8 @@
 // tools/wave_decim_model.py is this dataflow in numpy, register by register, against the pruned DFT (tests/test_wave_decim_model.py);
 // wave_layout_bin_d below and the host's tables follow it.
 //
-// fine_sync's ifreq comes from a second, cache-hot read behind the FFT (the windows are 2-16 KB); the closed form of the D = 8 kernels is
-// not used here (its bounds are derived for |ifreq| <= pi / 8 of a D = 8 chirp).  A window with a sample of exactly zero comes back as
+// fine_sync's ifreq comes from the registers loaded for the dechirp (the ZM evaluation: from memory); the closed
+// form of the D = 8 kernels is not used here (its bounds are derived for |ifreq| <= pi / 8 of a D = 8 chirp).  A window with a sample of exactly zero comes back as
 // kPoisonBin and is evaluated again by the ZM instantiation, as everywhere.
 
 template <int SF, int LD> struct WaveGeomD {
@@ -108,6 +108,33 @@ __device__ __forceinline__ bool wave_fine_sync_reload(const float2 *__restrict__
     return true;
 }
 
+// ... and from ifreq values that are in registers already: f[j] = ifreq[64 j + lane - KOFF].  KOFF = 1: the FFT demodulator's predecessor form (lane 0 of row 0 holds 0; the
+// duplicated last tap, :243, is added here); KOFF = 0: the gradient demodulator's successor form (lane 63 of the last row holds the duplicate already)
+template <int J, int KOFF>
+__device__ __forceinline__ bool wave_fine_sync_regs(const float (&f)[J], const float *__restrict__ v, int lane, int32_t &fine_out)
+{
+    const float *__restrict__ vp = v + (lane - 1 - KOFF);
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const float fj = f[j];
+        c0 += fj * vp[64 * j]; c1 += fj * vp[64 * j + 1]; c2 += fj * vp[64 * j + 2];
+    }
+    if constexpr (KOFF == 1) {
+        const float fl = (lane == 63) ? f[J - 1] : 0.0f;
+        c0 += fl * vp[64 * (J - 1) + 1]; c1 += fl * vp[64 * (J - 1) + 2]; c2 += fl * vp[64 * (J - 1) + 3];
+    }
+    c0 = wave_sum_u(c0); c1 = wave_sum_u(c1); c2 = wave_sum_u(c2);
+    if (poisoned3(c0, c1, c2)) return false; // (uniform) a sample of the window is exactly zero
+    float mx = 0.0f;
+    int32_t lag = 0;
+    if (c0 > mx) { mx = c0; lag = -1; }
+    if (c1 > mx) { mx = c1; lag = 0; }
+    if (c2 > mx) { mx = c2; lag = 1; }
+    fine_out = -lag;
+    return true;
+}
+
 template <int SF, int LD, bool ZM = false>
 __device__ __forceinline__ void wave_demod_symbol_d(const DevParams &P, const WaveTabs &T, const float2 *__restrict__ x, uint32_t &s_out, int32_t &fine_out,
                                                     float *en_out = nullptr /* implicit header: the window's energy (determine_energy, :368-375) */)
@@ -127,6 +154,25 @@ __device__ __forceinline__ void wave_demod_symbol_d(const DevParams &P, const Wa
 #pragma unroll
         for (int j = 0; j < J; j++) e2 = __builtin_elementwise_fma(a[j], a[j], e2);
         *en_out = wave_sum_u(e2.x + e2.y);
+    }
+    // fine_sync's ifreq from the registers loaded for the dechirp (sample n - 1 sits in the neighbouring lane, lane 0's in lane 63 of the previous register - one
+    // wave rotate per register; measured against a second, cache-hot read behind the FFT: walkers +6 ... +12 % at decimation 4).  J = 32 (SF9 at decimation 4) runs
+    // at the 256-register budget, where the 32 values fit beside the FFT's
+    constexpr bool EARLY_F = !ZM;
+    float f[EARLY_F ? J : 1];
+    if constexpr (EARLY_F) {
+        if (P.enable_fine_sync != 0u) {
+            v2f bprev = (v2f){0.0f, 0.0f};
+#pragma unroll
+            for (int j = 0; j < J; j += 2) {
+                const v2f b0 = dpp2<kDppWaveRor1>(a[j]), b1 = dpp2<kDppWaveRor1>(a[j + 1]);
+                const v2f p0 = (lane == 0) ? bprev : b0, p1 = (lane == 0) ? b0 : b1;
+                bprev = b1;
+                const v2f fp = ifreq_prod_pk(p0, a[j], p1, a[j + 1]);
+                f[j] = (j == 0 && lane == 0) ? 0.0f : fp.x; // n = 0 has no predecessor in the window
+                f[j + 1] = fp.y;
+            }
+        }
     }
 #pragma unroll
     for (int j = 0; j < J; j++) a[j] = cmul2(a[j], T.down[j * 64 + lane]); // dechirp (:437)
@@ -226,9 +272,13 @@ __device__ __forceinline__ void wave_demod_symbol_d(const DevParams &P, const Wa
     fine_out = 0;
     if (P.enable_fine_sync == 0u) return;
     const uint32_t bin_idx = (s == 0u && P.demod_mode == 2u) ? 0u : (s + (uint32_t)N - 1u) % (uint32_t)N;
-    int zero = 0; // (the second read stays behind the reduce-scatter: hoisted above the FFT it would hold 2 J more registers)
-    asm volatile("; fine-sync reload after the reduce-scatter" : "+v"(zero) : "v"(bv));
-    if (!wave_fine_sync_reload<SPS, ZM>(x + zero, T.v + ((int)(bin_idx + 1u) * D + SPS), lane, fine_out)) s_out = kPoisonBin;
+    if constexpr (EARLY_F) {
+        if (!wave_fine_sync_regs<J, 1>(f, T.v + ((int)(bin_idx + 1u) * D + SPS), lane, fine_out)) s_out = kPoisonBin;
+    } else {
+        int zero = 0; // (the second read stays behind the reduce-scatter: hoisted above the FFT it would hold 2 J more registers)
+        asm volatile("; fine-sync reload after the reduce-scatter" : "+v"(zero) : "v"(bv));
+        if (!wave_fine_sync_reload<SPS, ZM>(x + zero, T.v + ((int)(bin_idx + 1u) * D + SPS), lane, fine_out)) s_out = kPoisonBin;
+    }
 }
 
 // max_frequency_gradient_idx (:466-491) + fine_sync on one wavefront, as wave_demod_symbol_grad: f[j] = ifreq[n], n = 64 j + lane; the D samples of
@@ -248,6 +298,7 @@ __device__ __forceinline__ void wave_demod_symbol_grad_d(const DevParams &P, con
     int bi = 0x7fffffff;
     float gs = 0.0f; // (carries the poison of a zero sample when there is no fine_sync sum to carry it)
     float prev_perm = 0.0f;
+    float f[ZM ? 1 : J]; // this lane's ifreq[64 j + lane]: the bin averages and fine_sync's sums both come from these registers
     en_out = 0.0f;
     auto bin_step = [&](int j, float A) { // A: this lane's ifreq[64 j + lane]
         // the bin's D values added in the reference's order (volk_32f_accumulator_s32f's plain loop, :475: ((f0 + f1) + f2) + f3) - every lane of the group
@@ -288,7 +339,6 @@ __device__ __forceinline__ void wave_demod_symbol_grad_d(const DevParams &P, con
             for (int j = 0; j < J; j++) e2 = __builtin_elementwise_fma(a[j], a[j], e2);
             en_out = wave_sum_u(e2.x + e2.y);
         }
-        float f[J];
         v2f cn = dpp2<kDppWaveRol1>(a[0]); // a[j] of lane + 1 (lane 63: of lane 0)
 #pragma unroll
         for (int j = 0; j < J; j += 2) {
@@ -315,7 +365,8 @@ __device__ __forceinline__ void wave_demod_symbol_grad_d(const DevParams &P, con
         if (!ZM && poisoned(wave_sum_u(gs))) bin_out = kPoisonBin; // (a sample of exactly zero in the window)
         return;
     }
-    if (!wave_fine_sync_reload<SPS, ZM>(x, Tv + ((int)(bin_idx + 1u) * D + SPS), lane, fine_out)) bin_out = kPoisonBin;
+    if constexpr (ZM) (void)wave_fine_sync_reload<SPS, true>(x, Tv + ((int)(bin_idx + 1u) * D + SPS), lane, fine_out);
+    else if (!wave_fine_sync_regs<J, 0>(f, Tv + ((int)(bin_idx + 1u) * D + SPS), lane, fine_out)) bin_out = kPoisonBin;
 }
 
 // host side: the table block in the layout above, from the handle's downchirp

@@ -35,13 +35,13 @@ def classify(a, b):
     return None
 
 
-def run_point(sf, snr_db, n_packets, demod, seed=0, payload=8):
+def run_point(sf, snr_db, n_packets, demod, seed=0, payload=8, samp_rate=1e6):
     """returns a dict of counts for one (sf, snr) point"""
     import torch
     from gr_lora_amd import capi
     from oracle import oracle as O
     rng = np.random.default_rng(seed + 1000 * sf + int(10 * snr_db))
-    cfg = synth.TxConfig(sf=sf, cr=4)
+    cfg = synth.TxConfig(sf=sf, cr=4, samp_rate=samp_rate)
     sigma = synth.awgn_sigma_for_snr(snr_db, cfg)
     pieces, offs, lens = [], [], []
     off = 0
@@ -50,17 +50,18 @@ def run_point(sf, snr_db, n_packets, demod, seed=0, payload=8):
         st = synth.build_stream([p], cfg, rng=rng, noise_sigma=sigma, gap_symbols=(2.0, 5.0), tail_symbols=3.0)
         pieces.append(st.iq); offs.append(off); lens.append(st.iq.size); off += st.iq.size
     iq = np.concatenate(pieces)
-    up_ifreq = O.Oracle(sf=sf, cr=4).table(3).astype(np.float64)
+    up_ifreq = O.Oracle(sf=sf, cr=4, samp_rate=samp_rate).table(3).astype(np.float64)
 
     def ora(k):
-        o = O.Oracle(sf=sf, cr=4, demod=demod)
+        o = O.Oracle(sf=sf, cr=4, demod=demod, samp_rate=samp_rate)
         o.enable_trace()
         o.run(iq[offs[k]:offs[k] + lens[k]])
         return o.frames(), o.trace()
     with cf.ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as ex:
         want = list(ex.map(ora, range(n_packets)))
     dev = torch.from_numpy(iq.view(np.float32)).cuda()
-    h = capi.Handle(sf=sf, cr=4, demod=demod, flags=capi.FLAG_TRACE)
+    h = capi.Handle(sf=sf, cr=4, demod=demod, flags=capi.FLAG_TRACE, samp_rate=samp_rate)
+    kname = h.kernel_name()
     h.decode_device(dev.data_ptr(), iq.size, offs, lens, 0)
     frames = {}
     for g, i in h.drain():
@@ -69,7 +70,7 @@ def run_point(sf, snr_db, n_packets, demod, seed=0, payload=8):
     for t in h.trace():
         traces.setdefault(t[6], []).append(t)
     h.close()
-    res = {"sf": sf, "snr_db_inband": snr_db, "demod": demod, "packets": n_packets, "oracle_frames": 0, "device_frames": 0, "frames_differ": 0,
+    res = {"sf": sf, "decimation": cfg.decim, "kernel": kname, "snr_db_inband": snr_db, "demod": demod, "packets": n_packets, "oracle_frames": 0, "device_frames": 0, "frames_differ": 0,
            "streams_with_trace_diff": 0, "first_diff": {}, "value_gate_margin_min": None}
     margin = 1e9
     for k in range(n_packets):
@@ -114,10 +115,11 @@ if __name__ == "__main__":
     ap.add_argument("--snr", default="26:42:0.5")
     ap.add_argument("--packets", type=int, default=200)
     ap.add_argument("--demod", type=int, default=2)
+    ap.add_argument("--samp-rate", type=float, default=1e6, help="5e5 / 2.5e5: decimation 4 / 2")
     a = ap.parse_args()
     lo, hi, st = (float(x) for x in a.snr.split(":"))
     for sf in (int(x) for x in a.sf.split(",")):
         snr = lo
         while snr <= hi + 1e-9:
-            print(json.dumps(run_point(sf, snr, a.packets, a.demod)), flush=True)
+            print(json.dumps(run_point(sf, snr, a.packets, a.demod, samp_rate=a.samp_rate)), flush=True)
             snr += st
