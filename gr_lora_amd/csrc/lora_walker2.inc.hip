@@ -530,7 +530,7 @@ __device__ LORA_W2_ZM_ATTR W2DemodZ w2_demod_zm(uint32_t enable_fine_sync, uint3
     DevParams Q{}; // (only the fields the demodulators read)
     Q.enable_fine_sync = enable_fine_sync; Q.demod_mode = demod_mode;
     W2DemodZ r{0u, 0, 0.0f};
-    if constexpr (LD != 3) {
+    if constexpr (LD != 3 || SF < 7) {
         if constexpr (GRAD) wave_demod_symbol_grad_d<SF, LD, true>(Q, T.v, x, want_energy, r.s, r.fine, r.en);
         else wave_demod_symbol_d<SF, LD, true>(Q, T, x, r.s, r.fine, want_energy ? &r.en : nullptr);
     } else
@@ -539,7 +539,7 @@ __device__ LORA_W2_ZM_ATTR W2DemodZ w2_demod_zm(uint32_t enable_fine_sync, uint3
     return r;
 }
 // 8-byte entries of the demodulator's table block (decimation 8: lora_wave_demod.inc.hip; 2 / 4: lora_wave_decim.inc.hip)
-template <int SF, int LD> constexpr uint32_t w2_table_entries() { if constexpr (LD == 3) return WaveGeom<SF>::n_ent; else return WaveGeomD<SF, LD>::n_ent; }
+template <int SF, int LD> constexpr uint32_t w2_table_entries() { if constexpr (LD == 3 && SF >= 7) return WaveGeom<SF>::n_ent; else return WaveGeomD<SF, LD>::n_ent; }
 
 // ---- the kernel -----------------------------------------------------------------------------------------
 // GRAD: the reference's shipped demodulator (max_frequency_gradient_idx, :466-491, :499) in the decode rounds instead of the
@@ -601,7 +601,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
         for (uint32_t i = threadIdx.x; i < 3u * sps + 40u; i += kW2) vl[i] = P.up_ifreq_v[i];
         FT.v = vl;
     } else {
-        if constexpr (LD == 3) FT = wave_tabs_to_lds<SF>(P, tab2, vl, kW2);
+        if constexpr (LD == 3 && SF >= 7) FT = wave_tabs_to_lds<SF>(P, tab2, vl, kW2);
         else FT = wave_tabs_to_lds_d<SF, LD>(P, tab2, vl, kW2);
     }
     for (uint32_t i = threadIdx.x; i < sps; i += kW2) ddl[i] = P.down_ifreq[i] - P.down_ifreq_avg;
@@ -972,7 +972,7 @@ __device__ __forceinline__ void walker2_body(const DevParams &P, const LaunchCfg
                         const W2DemodZ z = w2_demod_zm<SF, GRAD, LD>(P.enable_fine_sync, P.demod_mode, P.implicit != 0u, FT, X + dwpos);
                         ws = z.s; wfine = z.fine; wen = z.en;
                     } else
-                    if constexpr (LD != 3) {
+                    if constexpr (LD != 3 || SF < 7) { // (lora_wave_decim.inc.hip: decimation 2 / 4, and SF6)
                         if constexpr (GRAD) wave_demod_symbol_grad_d<SF, LD>(P, FT.v, X + dwpos, P.implicit != 0u, ws, wfine, wen);
                         else wave_demod_symbol_d<SF, LD>(P, FT, X + dwpos, ws, wfine, P.implicit != 0u ? &wen : nullptr);
                     } else
@@ -1170,8 +1170,10 @@ LORA_W2_DECIM_KERNEL(8, 2, 1, 4)
 LORA_W2_DECIM_KERNEL(8, 4, 2, 4)
 LORA_W2_DECIM_KERNEL(9, 2, 1, 4)
 LORA_W2_DECIM_KERNEL(9, 4, 2, 2)
+LORA_W2_DECIM_KERNEL(6, 4, 2, 4)
+LORA_W2_DECIM_KERNEL(6, 8, 3, 4) // SF6 at decimation 8: the same body on lora_wave_decim.inc.hip's demodulators (LD = 3)
 #undef LORA_W2_DECIM_KERNEL
-static bool walker2_decim_covers(uint32_t sf, uint32_t decim) { return (decim == 2u || decim == 4u) && sf >= 7u && sf <= 9u; }
+static bool walker2_decim_covers(uint32_t sf, uint32_t decim) { return ((decim == 2u || decim == 4u) && sf >= 7u && sf <= 9u) || (sf == 6u && (decim == 4u || decim == 8u)); }
 
 static uint32_t walker2_threads(uint32_t sf) { return 64u * (uint32_t)(sf == 7u ? kW2WavesSf7 : kW2WavesSf8); }
 
@@ -1179,7 +1181,7 @@ static uint32_t walker2_lds_bytes(uint32_t sf, bool grad = false, uint32_t decim
 {
     const uint32_t sps = decim << sf;
     const uint32_t nv = (3u * sps + 40u + 3u) & ~3u;
-    if (decim != 8u)
+    if (decim != 8u || sf < 7u)
         return (uint32_t)((sizeof(W2Shared) + 15) & ~(size_t)15) + (2u * sps + nv + sps) * (uint32_t)sizeof(float) +
                (grad ? 0u : wave_tables_floats_d(sf, decim) * (uint32_t)sizeof(float)) + (2u * 256u + 8u) * (uint32_t)sizeof(double);
     if (!grad && sf == 8u && kW2Alias<8>) // (SYNC's work areas inside the table block)

@@ -16,7 +16,7 @@
 // kPoisonBin and is evaluated again by the ZM instantiation, as everywhere.
 
 template <int SF, int LD> struct WaveGeomD {
-    static_assert(LD == 1 || LD == 2, "decimation 2 or 4 (8: lora_wave_demod.inc.hip)");
+    static_assert(LD >= 1 && LD <= 3, "decimation 2, 4 - or 8 for SF6, which lora_wave_demod.inc.hip's SF7-SF9 instantiations do not cover");
     static constexpr int N = 1 << SF, D = 1 << LD, SPS = N << LD, J = SPS / 64, LQ = 64 >> LD, LOGJ = ilog2(J), NXT = 5 - LD;
     static_assert(J >= 4 && J <= 64, "4 .. 64 samples per lane");
     static constexpr uint32_t n_down = SPS, n_twn = J * LQ, n_tws = J * 64, n_xst = NXT * 64;
@@ -206,13 +206,17 @@ __device__ __forceinline__ void wave_demod_symbol_d(const DevParams &P, const Wa
                 a[g] = lo + hi;
                 a[g + J / 4] = cmul2(lo - hi, w2);
             }
-        { // lane bit 3: a' = +-a + partner, then the lane twiddle (1 on the lower lane of a pair)
+        if constexpr (LD == 3) { // lane bit 3: the last stage (decimation 8)
+            const v2f sg = (lane & 8) ? (v2f){-1.f, -1.f} : (v2f){1.f, 1.f};
+            xstage_last_pk<kDppRor8, J>(a, sg);
+        } else { // lane bit 3: a' = +-a + partner, then the lane twiddle (1 on the lower lane of a pair)
             const v2f sg = (lane & 8) ? (v2f){-1.f, -1.f} : (v2f){1.f, 1.f};
             const v2f w3 = T.xst[2 * 64 + lane];
 #pragma unroll
             for (int m = 0; m < J; m++) a[m] = cmul2(__builtin_elementwise_fma(sg, a[m], dpp2<kDppRor8>(a[m])), w3);
         }
-        if constexpr (LD == 2) { // lane bit 2: the last stage
+        if constexpr (LD == 3) {
+        } else if constexpr (LD == 2) { // lane bit 2: the last stage
             const v2f sg = (lane & 4) ? (v2f){-1.f, -1.f} : (v2f){1.f, 1.f};
 #pragma unroll
             for (int m = 0; m < J; m++) a[m] = __builtin_elementwise_fma(sg, a[m], dpp2_xor4(a[m]));
@@ -232,7 +236,30 @@ __device__ __forceinline__ void wave_demod_symbol_d(const DevParams &P, const Wa
     // reduce-scatter over r = the LD low lane bits: lanes with the bit clear keep the first half of the registers
     constexpr int R = J >> LD;
     v2f b1[R];
-    if constexpr (LD == 2) {
+    if constexpr (LD == 3) { // (as wave_demod_symbol: lane bit 2 by row_shr:4 into banks 1,3 / row_shl:4 into banks 0,2, then bits 1, 0)
+        v2f b4[J / 2], b2[J / 4];
+#pragma unroll
+        for (int i = 0; i < J / 2; i++) {
+            const float lx = a[i].x, ly = a[i].y, hx = a[i + J / 2].x, hy = a[i + J / 2].y;
+            v2f X, Y;
+            X.x = dpp_rows_bank_f<0x114, 0xA>(lx, hx); X.y = dpp_rows_bank_f<0x114, 0xA>(ly, hy); // upper lanes: partner's second half
+            Y.x = dpp_rows_bank_f<0x104, 0x5>(hx, lx); Y.y = dpp_rows_bank_f<0x104, 0x5>(hy, ly); // lower lanes: partner's first half
+            b4[i] = X + Y;
+        }
+        const bool hi2 = (lane & 2) != 0, hi1 = (lane & 1) != 0;
+#pragma unroll
+        for (int i = 0; i < J / 4; i++) {
+            const v2f t0 = b4[i] + dpp2<kDppQuadXor2>(b4[i]);
+            const v2f t1 = b4[i + J / 4] + dpp2<kDppQuadXor2>(b4[i + J / 4]);
+            b2[i] = hi2 ? t1 : t0;
+        }
+#pragma unroll
+        for (int i = 0; i < J / 8; i++) {
+            const v2f t0 = b2[i] + dpp2<kDppQuadXor1>(b2[i]);
+            const v2f t1 = b2[i + J / 8] + dpp2<kDppQuadXor1>(b2[i + J / 8]);
+            b1[i] = hi1 ? t1 : t0;
+        }
+    } else if constexpr (LD == 2) {
         v2f b2[J / 2];
         const bool hi2 = (lane & 2) != 0, hi1 = (lane & 1) != 0;
 #pragma unroll
@@ -257,7 +284,8 @@ __device__ __forceinline__ void wave_demod_symbol_d(const DevParams &P, const Wa
         }
     }
     // arg-max on |X|^2 (monotone in the reference's std::abs, :454), first maximum in bin order wins (:463)
-    const int gbase = LD == 2 ? ((lane & 2) ? J / 2 : 0) + ((lane & 1) ? J / 4 : 0) : ((lane & 1) ? J / 2 : 0);
+    const int gbase = LD == 3 ? ((lane & 4) ? J / 2 : 0) + ((lane & 2) ? J / 4 : 0) + ((lane & 1) ? J / 8 : 0)
+                    : LD == 2 ? ((lane & 2) ? J / 2 : 0) + ((lane & 1) ? J / 4 : 0) : ((lane & 1) ? J / 2 : 0);
     float bv = -1.0f;
     int bi = 0x7fffffff;
 #pragma unroll
@@ -304,7 +332,8 @@ __device__ __forceinline__ void wave_demod_symbol_grad_d(const DevParams &P, con
         // the bin's D values added in the reference's order (volk_32f_accumulator_s32f's plain loop, :475: ((f0 + f1) + f2) + f3) - every lane of the group
         // reads them by quad broadcast: a window cut half a bin off its symbol (two samples at D = 4) shares the drop between two neighbouring
         // differences that tie up to this rounding
-        if constexpr (LD == 2) A = ((dpp_f<0x00>(A) + dpp_f<0x55>(A)) + dpp_f<0xAA>(A)) + dpp_f<0xFF>(A);
+        if constexpr (LD == 3) { A += dpp_f<kDppQuadXor1>(A); A += dpp_f<kDppQuadXor2>(A); A += dpp_f<kDppRowHalfMirror>(A); } // (decimation 8: the tree of wave_demod_symbol_grad)
+        else if constexpr (LD == 2) A = ((dpp_f<0x00>(A) + dpp_f<0x55>(A)) + dpp_f<0xAA>(A)) + dpp_f<0xFF>(A);
         else A += dpp_f<kDppQuadXor1>(A); // (two values: the order does not matter)
         A *= 1.0f / (float)D; // / d_decim_factor (a power of two)
         const float perm = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm_addr, __builtin_bit_cast(int, A))); // bin (m - 1) mod LQ of this register
@@ -408,14 +437,15 @@ static void build_wave_tables_d_host(int sf, int ld, const float2 *down, float *
     }
 }
 
-static bool wave_decim_covers(uint32_t sf, uint32_t decim) { return (decim == 2u || decim == 4u) && sf >= 7u && sf <= 9u; }
+// SF7-SF9 at decimation 2 / 4; SF6 (implicit header: an SF6 header block holds 4 of the header's 5 codewords) at 4 / 8
+static bool wave_decim_covers(uint32_t sf, uint32_t decim) { return ((decim == 2u || decim == 4u) && sf >= 7u && sf <= 9u) || (sf == 6u && (decim == 4u || decim == 8u)); }
 uint32_t wave_tables_floats_d(uint32_t sf, uint32_t decim)
 {
     if (!wave_decim_covers(sf, decim)) return 0u;
-    const uint32_t sps = decim << sf, J = sps / 64u, LQ = 64u / decim, ld = decim == 2u ? 1u : 2u;
+    const uint32_t sps = decim << sf, J = sps / 64u, LQ = 64u / decim, ld = decim == 2u ? 1u : decim == 4u ? 2u : 3u;
     return 2u * (sps + J * LQ + J * 64u + (5u - ld) * 64u);
 }
-void build_wave_tables_d(uint32_t sf, uint32_t decim, const float2 *down, float *out) { build_wave_tables_d_host((int)sf, decim == 2u ? 1 : 2, down, out); }
+void build_wave_tables_d(uint32_t sf, uint32_t decim, const float2 *down, float *out) { build_wave_tables_d_host((int)sf, decim == 2u ? 1 : decim == 4u ? 2 : 3, down, out); }
 
 // ---- symbol-level kernels: one wavefront per symbol (lora_hip_demod_symbols_device) -----------------------------------------------------------------------------
 template <int SF, int LD>
@@ -466,6 +496,8 @@ static int wave_decim_dispatch(uint32_t sf, uint32_t decim, A... args)
     case 7u * 8u + 4u: return F<7, 2>::go(args...);
     case 8u * 8u + 4u: return F<8, 2>::go(args...);
     case 9u * 8u + 4u: return F<9, 2>::go(args...);
+    case 6u * 8u + 4u: return F<6, 2>::go(args...);
+    case 6u * 8u + 8u: return F<6, 3>::go(args...);
     default: return -1;
     }
 }

@@ -132,8 +132,8 @@ def payload_symbol_count(length_with_crc: int, sf: int, cr: int, reduced_rate: b
 def encode_shifts(payload: bytes, cfg: TxConfig, crc_bytes: bytes = b"\x70\x0d") -> Tuple[List[int], List[int]]:
     """Returns (header_shifts[8], payload_shifts[...]) : cyclic advance in bins."""
     sf, cr, N = cfg.sf, cfg.cr, cfg.nbins
-    if sf < 7:
-        raise ValueError("transmit model needs sf >= 7 (header block holds 5 codewords)")
+    if sf < 7 and not cfg.implicit:
+        raise ValueError("transmit model needs sf >= 7 for an explicit header (the header block holds 5 codewords; SF6: implicit header only)")
     body = bytes(payload) + (bytes(crc_bytes[:2]) if cfg.crc else b"")
     nibbles = []
     for b in body:
