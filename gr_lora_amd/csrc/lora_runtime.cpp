@@ -1788,7 +1788,7 @@ lora_hip_status lora_hip_demod_symbols_ex_device(lora_hip_decoder_t *h, const vo
     if (demod != 0) P.demod_mode = (uint32_t)demod; // FFT vs FFT_COMPAT decides the bin fine_sync is run with
     if (launch_demod_symbols(P, (const float2 *)d_iq, h->d_offsets.p, (uint32_t)n, demod, h->d_bins.p, d_fine,
                              h->P.ifreq_in_lds_1 ? nullptr : h->d_scratch.p, st) != 0)
-        return fail(h, fine_out ? LORA_HIP_ERR_BAD_CONFIG : LORA_HIP_ERR_HIP, "demod launch failed (fine_sync output needs SF7 .. SF12 at decimation 8 or SF7 .. SF9 at decimation 2 / 4): %s",
+        return fail(h, fine_out ? LORA_HIP_ERR_BAD_CONFIG : LORA_HIP_ERR_HIP, "demod launch failed (fine_sync output needs one of the fast families: SF6 .. SF12 at decimation 8, SF6 .. SF9 at 4, SF7 .. SF9 at 2): %s",
                     hipGetErrorString(hipGetLastError()));
     HIP_TRY(h, hipMemcpyAsync(bins_out, h->d_bins.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     if (fine_out) HIP_TRY(h, hipMemcpyAsync(fine_out, d_fine, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));

@@ -347,7 +347,6 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
     // fine_sync's ifreq: never kept from pass 1 (round 6).  The common decision - lag 0 - is taken in closed form from sign tests made while the samples are in
     // registers for the dechirp (FFS: wave_demod_symbol FMODE 2, lora_wave_demod.inc.hip, explains the rule; ffs_row is the per-sample part); a window the closed
     // form cannot vouch for has its three sums formed from a second read of the window (the path SF12 always took, and every ZM evaluation takes)
-    constexpr bool LATE_F = true;
     constexpr bool FFS = !ZM;
     int tt = threadIdx.x;
     asm volatile("" : "+v"(tt)); // keeps per-thread table addresses out of the caller's loop-invariant set
@@ -385,8 +384,8 @@ __device__ __forceinline__ void w3_demod_round(const W3DemodArgs &P, const W3Lds
         // entries before pair p is worked on: with fine_sync's 32 ifreq registers gone it fits without a spill and takes block 0's pass 1 from 19 k to 12 k
         // clocks - and the device as a whole 4-7 % DOWN (standalone 0.283 / 0.273 / 0.253 -> 0.264 / 0.256 / 0.237 at SF10 / SF11 / SF12, walkers -1 ... -4 %):
         // every workgroup of the launch then asks for twice as much at once.  Off.
-        v2f nx[16];
 #if LORA_W3_P1_PREFETCH
+        v2f nx[16];
 #pragma unroll
         for (int c = 0; c < 16; c++) nx[c] = w3_ld2(xb, 8u * tu, (uint32_t)(c * CH * 8));
 #endif
@@ -1467,7 +1466,6 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
     AttemptRec *recs = C.recs + (size_t)jid * C.recs_per_job;
     StepRec *trace = C.trace ? C.trace + (size_t)jid * C.trace_cap : nullptr;
     const bool t0 = threadIdx.x == 0;
-    const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x / G::TG);
     int slot = 0;
     const W3DemodArgs DA{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode, P.ffs_on, P.ffs_alpha, P.ffs_jump, P.ffs_tol};
 
@@ -1527,9 +1525,6 @@ __device__ __forceinline__ void walker3_body(const DevParams &P, const LaunchCfg
             if (Q.prev_state >= 0) { Q.cyc[Q.prev_state] += (uint32_t)((t_start - Q.prev_t) >> 6); Q.rounds[Q.prev_state]++; }
             Q.prev_state = sidx; Q.prev_t = t_start;
         }
-        const int64_t gpos = pos + (int64_t)grp * sps;
-        const bool gvalid = gpos + 2 * (int64_t)sps <= n_items; // this group's window lies inside the data (:91)
-        const float2 *__restrict__ xg = X + (gvalid ? gpos : pos);
 
         // windows of this round that lie inside the data (:91): the first n_in_data of pos, pos + sps, ...
         const int64_t fit64 = (n_items - pos) / (int64_t)sps - 1;
@@ -1937,7 +1932,6 @@ __global__ __launch_bounds__((W3Geom<SF, HV>::T), (W3Geom<SF, HV>::T512 ? 2 : 4)
     w3_tables_to_lds<SF, HV>(P, L);
     __syncthreads();
     int slot = 0;
-    const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x / G::TG);
     const W3DemodArgs DA{P.down, P.w3_ctab, P.up_ifreq_v, P.enable_fine_sync, P.demod_mode, P.ffs_on, P.ffs_alpha, P.ffs_jump, P.ffs_tol};
     for (uint32_t s0 = blockIdx.x * G::NG; s0 < n; s0 += gridDim.x * G::NG) {
         uint32_t b[G::NG];

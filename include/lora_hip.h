@@ -255,7 +255,7 @@ lora_hip_status lora_hip_demod_symbols_device(lora_hip_decoder_t *h, const void 
 /* Same, and additionally fine_out[i] = d_fine_sync after fine_sync(bin_idx, max(D/4, 2)) on that window
  * (decoder_impl.cc:300-338, called from demodulate() :514-518).  fine_out may be NULL; non-NULL needs one of the
  * fast demodulator families (SF7-SF12 at decimation 8: wave-per-symbol at SF7 / SF8, workgroup-per-symbol at SF9-SF12;
- * SF7-SF9 at decimation 2 / 4: wave-per-symbol; every demod mode), else BAD_CONFIG.                             */
+ * SF7-SF9 at decimation 2 / 4 and SF6 at 4 / 8: wave-per-symbol; every demod mode), else BAD_CONFIG.          */
 lora_hip_status lora_hip_demod_symbols_ex_device(lora_hip_decoder_t *h, const void *d_iq, size_t total_items,
                                                  const int64_t *offsets, size_t n, int demod,
                                                  uint32_t *bins_out, int32_t *fine_out, void *hip_stream);
@@ -267,7 +267,7 @@ lora_hip_status lora_hip_last_timing(const lora_hip_decoder_t *h, lora_hip_timin
  * walker2_kernel_sf7/8[_grad] (wavefront per symbol; walker2_kernel_sf7/8[_grad]_wide: the 256-register builds of the same body, for launches with no more jobs than
  * CUs), walker3_kernel_sf9..12[_grad] (SF9 and every _grad: wavefront per symbol; SF10-SF12 FFT: workgroup per symbol; _half: SF10 and SF9_grad as two
  * workgroups per CU), *_skip (the header-only variants of a decoupled pass), walker2_kernel_sf7..9_d2 / _d4[_grad] (decimation 2 / 4: samp_rate = 2 or 4
- * x bandwidth), walker_kernel* (generic: other decimations, SF10-SF12 at decimation 2 / 4, SF6, LORA_HIP_NO_FAST).                                      */
+ * x bandwidth), walker2_kernel_sf6_d8 / _d4[_grad] (SF6), walker_kernel* (generic: other decimations, SF10-SF12 at decimation 2 / 4, LORA_HIP_NO_FAST).                                      */
 const char     *lora_hip_walker_kernel_name(const lora_hip_decoder_t *h);
 /* The payload pass of the last pass when it ran decoupled (LORA_HIP_FLAG_NO_DECOUPLED above): packets whose payload it took; how many of them
  * ended off the zero-drift grid (their symbols moved the symbol clock by a net amount: the job is split there and probed like a segment boundary);

@@ -40,6 +40,7 @@ for sf in 7 8 9; do for d in 4 2; do
 done; done
 LORA_HIP_NO_FAST=1 python bench.py --config 3 --sf 8 --packets 1024 --samp-rate 5e5 --steps 3 --warmup 1 --min-seconds 0.1 --no-cpu-baseline --no-grad-line 2>/dev/null | tail -1 > gpurun_out/sf8_d4_generic_line.json
 PROFILE_LINE_FLAGS="--no-cpu-baseline --no-grad-line" tools/profile_round.sh sf8_d4 --config 3 --sf 8 --packets 1024 --samp-rate 5e5
+{ for d in 8 4; do python tools/sf6_bench.py $d 2>/dev/null; LORA_HIP_NO_FAST=1 python tools/sf6_bench.py $d 2>/dev/null; done; } > gpurun_out/sf6_walker.txt   # SF6 (implicit header; 512 streams = 512 jobs): walker2's LD builds against the generic kernels
 tools/pmc_walker.sh sq_sf7
 tools/pmc_walker.sh sq_sf9 --config 3 --sf 9
 tools/pmc_walker.sh sq_sf12 --config 3 --sf 12
