@@ -923,6 +923,11 @@ struct DeviceEnv {
     void count_jobs(uint32_t n) { h->timing.jobs += n; h->last_kernel_jobs = 0; if (h->dec_backoff) h->dec_backoff--; } // (called once per pass, ahead of its main launch)
     void count_probes(uint32_t n) { h->timing.probes += n; }
     void count_slow_path() { h->timing.slow_path_relaunches++; }
+    void count_repair()
+    { // (a cut repaired in the probe launch - lora_stitch.hpp; reported under LORA_HIP_DEBUG only: lora_hip_timing_t is ABI)
+        static const bool dbg = getenv("LORA_HIP_DEBUG") != nullptr;
+        if (dbg) fprintf(stderr, "[lora_hip] cut repaired from the true header (no serial walk)\n");
+    }
     void note_plan(bool burst_aware, size_t n_segs)
     {
         h->last_plan_burst = burst_aware ? 1u : 0u; h->last_plan_segments = (uint32_t)n_segs;

@@ -10,7 +10,7 @@
 //   RunOut &run_out(int which);   (two reusable result holders)
 //   bool quiet_edges(const std::vector<StreamDesc> &, std::vector<std::vector<int64_t>> &);   (gap starts per stream, false = none)
 //   void publish(const AttemptRec &, StreamDesc &);   void append_trace(const RunOut &, uint32_t job, uint32_t cap, int64_t base);
-//   void count_jobs(uint32_t), count_probes(uint32_t), count_slow_path(), note_plan(bool burst_aware, size_t n_segments);   double walker_ms();
+//   void count_jobs(uint32_t), count_probes(uint32_t), count_slow_path(), count_repair(), note_plan(bool burst_aware, size_t n_segments);   double walker_ms();
 //   uint32_t resident_slots_alt();   (a second, smaller slot count when the kernel exists in two workgroup sizes; 0: none)
 //   bool early_probe();   (the jobs record their FIND_SFD entry states and their tail probes may stop behind the first one: Job.tail_stop_sfd)
 //   bool decoupled(size_t n_jobs);   (run this pass's segment jobs header-only and the payloads in the symbol-parallel payload pass)
@@ -716,6 +716,8 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
     std::vector<Probe> probes;
     std::vector<size_t> first_probe(streams.size() + 1, 0);
     std::vector<Job> pjobs;
+    std::vector<int> repair_of; // per probe: index into pjobs of the job that runs the rest of its target segment again from the true header, or -1
+    static const bool no_repair = getenv("LORA_HIP_NO_REPAIR") != nullptr; // (A/B: every mismatching cut takes the serial path, as until round 6)
     RunOut &R2 = env.run_out(1);
     for (int planning = 0; planning < 2; planning++) {
     probes.clear(); pjobs.clear();
@@ -782,10 +784,48 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
         probes[q].job = (int)pjobs.size(); probes[q].tail_of = -1;
         pjobs.push_back(j);
     }
+    // Tail probes that reached a header NO successor job entered at the same sample.  With any noise over the stream detect_upchirp's tie between adjacent
+    // shifts is decided by the noise, differently for two DETECT alignments: the speculative job then sits ONE sample beside the true trajectory, at about
+    // every second cut.  Walking such a segment serially, one workgroup at a time, is what a pass would then spend its time on (round 6: 263 -> 5 Gsamples/s
+    // at a noise floor 60 dB down); instead the REST of the target segment's job is run again from the true header - Job.start_at_header, the true d_phdr.cr, the
+    // job's own limits and tail probe - all such cuts in the one launch below.  The stitch adopts a repair's records as the true trajectory (which they are); where
+    // its end state is the speculative job's - fine_sync pulls the two together within a packet - the chain goes on, else the next cut's check falls back as before.
+    repair_of.assign(probes.size(), -1);
+    uint32_t rpj_launch = rpj2;
+    if (!tracing && !ctx.decoupled && !no_repair) {
+        for (size_t q = 0; q < probes.size(); q++) {
+            if (probes[q].job >= 0) continue; // (an explicit probe's result is not known yet: it keeps the serial path)
+            const size_t tj = (size_t)probes[q].tail_of;
+            const JobResult &jr = R1.res[tj];
+            if (!jr.tail_pad || jr.tail_n_attempts == 0u) continue;
+            const uint32_t li = std::min(jr.tail_first_rec, R1.cap) + jr.tail_n_attempts - 1u;
+            if (li >= R1.cap) continue;
+            const AttemptRec &L = R1.rec(tj, li);
+            if (L.status != kAttemptAtHeader || L.hdr_pos < 0) continue;
+            bool entered = false;
+            for (size_t k = first_seg[probes[q].stream] + 1; k <= probes[q].target && !entered; k++) {
+                const uint32_t nall = std::min(R1.res[k].n_attempts, R1.cap);
+                for (uint32_t a = 0; a < nall && !entered; a++) {
+                    const AttemptRec &r = R1.rec(k, a);
+                    entered = r.hdr_pos == L.hdr_pos && (r.status == kAttemptFrame || r.status == kAttemptOutOfData);
+                }
+            }
+            if (entered) continue; // (the stitch's own match - with its FEC-branch condition - decides)
+            const StreamDesc &sd = streams[probes[q].stream];
+            const Job &tjob = jobs[probes[q].target];
+            Job j{};
+            j.stream_off = sd.off; j.stream_len = sd.len; j.start = L.hdr_pos; j.start_at_header = 1; j.cr_prev = L.cr_prev;
+            j.scan_limit = tjob.scan_limit; j.probe_limit = tjob.probe_limit; j.tail_stop_sfd = 0;
+            j.stream_id = sd.id; j.max_attempts = 0; j.stop_at_header = 0;
+            repair_of[q] = (int)pjobs.size();
+            pjobs.push_back(j);
+            rpj_launch = std::max(rpj_launch, rpj1);
+        }
+    }
     R2.res.clear(); R2.recs.clear();
     if (!pjobs.empty()) {
         env.count_probes((uint32_t)pjobs.size());
-        s = env.run_jobs(pjobs, rpj2, 0, R2);
+        s = env.run_jobs(pjobs, rpj_launch, 0, R2);
         if (s != 0) return s;
     }
     if (!pround.open) break;
@@ -917,6 +957,23 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
                     }
                     match = (int)a; mk = k;
                     break;
+                }
+            }
+            if (match < 0 && q < repair_of.size() && repair_of[q] >= 0 && !at_sfd) { // the rest of the target segment, run again from the true header
+                const size_t rj = (size_t)repair_of[q];
+                const JobResult &rr = R2.res[rj];
+                const uint32_t nd = R2.n_done(rj);
+                if (nd >= 1u && R2.rec(rj, 0).hdr_pos == L.hdr_pos && rr.stop_reason != 2u) {
+                    sd.pwr.apply(L.npush, L.push_tail); // the true DETECT scan is the probe's, everything from the header on the repair's
+                    sd.pwr.determine_snr();
+                    if (R2.rec(rj, 0).status == kAttemptFrame) env.publish(R2.rec(rj, 0), sd);
+                    for (uint32_t a = 1; a < nd; a++) adopt(env, R2.rec(rj, a), sd);
+                    cur = Cursor{rr.final_pos, rr.final_cr};
+                    if (rr.pad) { sd.incomplete = true; break; }
+                    sd.pwr.apply(rr.npush, rr.push_tail);
+                    covered = std::max(covered, segs[pb.target].b1);
+                    env.count_repair();
+                    continue;
                 }
             }
             if (match < 0) {

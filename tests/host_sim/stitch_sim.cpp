@@ -152,6 +152,7 @@ struct SimEnv {
     void count_jobs(uint32_t n) { n_jobs += n; }
     void count_probes(uint32_t n) { n_probes += n; }
     void count_slow_path() { n_slow++; }
+    void count_repair() {}
     double walker_ms() const { return 0.0; }
 };
 } // namespace
