@@ -756,6 +756,7 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
     // Tail probes that stopped behind their first FIND_SFD step (Job.tail_stop_sfd) in a state NO header-bearing attempt of their successors
     // passed through - the successor triggered two or more chirps later, as happens when a cut falls inside a packet train: they are run to the
     // header after all, as explicit probe jobs in the one launch below (a mismatch must cost a probe, not a serial walk of the segment).
+    bool through = false; // some explicit probe of this launch walks its whole target segment (it needs a segment job's record capacity)
     for (size_t q = 0; q < probes.size(); q++) {
         if (probes[q].job >= 0) continue;
         const size_t tj = (size_t)probes[q].tail_of;
@@ -781,6 +782,13 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
         Job j{};
         j.stream_off = sd.off; j.stream_len = sd.len; j.start = probes[q].start.pos; j.scan_limit = jobs[tj].probe_limit;
         j.stream_id = sd.id; j.cr_prev = probes[q].start.cr; j.max_attempts = 0; j.stop_at_header = 1;
+        if (!tracing && !ctx.decoupled && !no_repair) {
+            // (round 6) ... and past it: the job walks the whole target segment from the true state - the true trajectory itself, adopted by the stitch as a probe that
+            // "ended without a header" at its limit; with noise over the stream such cuts are every second one, and a probe that stops at a header one sample beside the
+            // speculative job's would send the segment down the serial path
+            j.scan_limit = jobs[probes[q].target].scan_limit; j.stop_at_header = 0;
+            through = true;
+        }
         probes[q].job = (int)pjobs.size(); probes[q].tail_of = -1;
         pjobs.push_back(j);
     }
@@ -791,7 +799,7 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
     // job's own limits and tail probe - all such cuts in the one launch below.  The stitch adopts a repair's records as the true trajectory (which they are); where
     // its end state is the speculative job's - fine_sync pulls the two together within a packet - the chain goes on, else the next cut's check falls back as before.
     repair_of.assign(probes.size(), -1);
-    uint32_t rpj_launch = rpj2;
+    uint32_t rpj_launch = through ? std::max(rpj2, rpj1) : rpj2;
     if (!tracing && !ctx.decoupled && !no_repair) {
         for (size_t q = 0; q < probes.size(); q++) {
             if (probes[q].job >= 0) continue; // (an explicit probe's result is not known yet: it keeps the serial path)

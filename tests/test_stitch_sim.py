@@ -257,7 +257,9 @@ def test_early_stopping_tail_probes_equal_serial(sim, oracle_mod, seg):
         ref_stats = sim(st.iq, 7, seg=seg, slots=40)[2]
         # (a probe that stopped early finds no partner when its successor triggered more than a symbol later - cuts in mid-preamble, which
         # this adversarial grid produces and burst-aware cuts do not; the price is a serial fall-back, never a wrong frame)
-        assert stats["slow"] <= ref_stats["slow"] + 4, (stats, ref_stats)
+        # (round 6: the reference run's mismatching cuts - its tail probes ran to their headers - are repaired in the probe launch, lora_stitch.hpp; a
+        # probe that stopped early knows no header to repair from)
+        assert stats["slow"] <= ref_stats["slow"] + 6, (stats, ref_stats)
 
 
 @pytest.mark.parametrize("sf,cr,noise_db", [(8, 1, -32), (7, 2, -30), (9, 3, None)])

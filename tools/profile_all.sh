@@ -41,6 +41,12 @@ done; done
 LORA_HIP_NO_FAST=1 python bench.py --config 3 --sf 8 --packets 1024 --samp-rate 5e5 --steps 3 --warmup 1 --min-seconds 0.1 --no-cpu-baseline --no-grad-line 2>/dev/null | tail -1 > gpurun_out/sf8_d4_generic_line.json
 PROFILE_LINE_FLAGS="--no-cpu-baseline --no-grad-line" tools/profile_round.sh sf8_d4 --config 3 --sf 8 --packets 1024 --samp-rate 5e5
 { for d in 8 4; do python tools/sf6_bench.py $d 2>/dev/null; LORA_HIP_NO_FAST=1 python tools/sf6_bench.py $d 2>/dev/null; done; } > gpurun_out/sf6_walker.txt   # SF6 (implicit header; 512 streams = 512 jobs): walker2's LD builds against the generic kernels
+# noise over the stream, idle gaps included (LORA_BENCH_NOISE_DB: in-band SNR; BASELINE's workloads are noiseless): the cuts whose speculative job sits one sample beside the true trajectory are
+# repaired in the probe launch (lora_stitch.hpp, round 6); LORA_HIP_NO_REPAIR=1: the serial path for each of them, as before
+for n in 60 40 35 30; do LORA_BENCH_NOISE_DB=$n python bench.py --no-cpu-baseline --no-grad-line 2>/dev/null | tail -1 > gpurun_out/noise${n}_line.json; done
+LORA_HIP_NO_REPAIR=1 LORA_BENCH_NOISE_DB=60 python bench.py --no-cpu-baseline --no-grad-line --steps 3 --warmup 1 --min-seconds 0 2>/dev/null | tail -1 > gpurun_out/noise60_norepair_line.json
+for sf in 9 12; do LORA_BENCH_NOISE_DB=50 python bench.py --config 3 --sf $sf --no-cpu-baseline --no-grad-line 2>/dev/null | tail -1 > gpurun_out/noise50_sf${sf}_line.json; done
+LORA_HIP_NO_REPAIR=1 LORA_BENCH_NOISE_DB=50 python bench.py --config 3 --sf 9 --no-cpu-baseline --no-grad-line --steps 3 --warmup 1 --min-seconds 0 2>/dev/null | tail -1 > gpurun_out/noise50_sf9_norepair_line.json
 tools/pmc_walker.sh sq_sf7
 tools/pmc_walker.sh sq_sf9 --config 3 --sf 9
 tools/pmc_walker.sh sq_sf12 --config 3 --sf 12
