@@ -102,7 +102,8 @@ def make_gateway_workload(channels, seconds=2.0, sf=9):
             p = bytes(rng.integers(0, 256, int(rng.integers(16, 65)), dtype=np.uint8))
             payloads.append(p)
             n += (12.25 + 8 + synth.payload_symbol_count(len(p) + 2, sf, 4, False)) * cfg.sps
-        st = synth.build_stream(payloads, cfg, gaps=[2 * cfg.sps] + [0] * (len(payloads) - 1), tail_symbols=2.5)
+        st = synth.build_stream(payloads, cfg, gaps=[2 * cfg.sps] + [0] * (len(payloads) - 1), tail_symbols=2.5, rng=np.random.default_rng(7000 + ch),
+                                noise_sigma=(synth.awgn_sigma_for_snr(float(os.environ["LORA_BENCH_NOISE_DB"]), cfg) if "LORA_BENCH_NOISE_DB" in os.environ else 0.0))   # (LORA_BENCH_NOISE_DB: see _make_workload)
         pieces.append(st.iq)
         offs.append(off)
         lens.append(st.iq.size)

@@ -782,7 +782,7 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
         Job j{};
         j.stream_off = sd.off; j.stream_len = sd.len; j.start = probes[q].start.pos; j.scan_limit = jobs[tj].probe_limit;
         j.stream_id = sd.id; j.cr_prev = probes[q].start.cr; j.max_attempts = 0; j.stop_at_header = 1;
-        if (!tracing && !ctx.decoupled && !no_repair) {
+        if (!tracing && !no_repair) {
             // (round 6) ... and past it: the job walks the whole target segment from the true state - the true trajectory itself, adopted by the stitch as a probe that
             // "ended without a header" at its limit; with noise over the stream such cuts are every second one, and a probe that stops at a header one sample beside the
             // speculative job's would send the segment down the serial path
@@ -800,7 +800,7 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
     // its end state is the speculative job's - fine_sync pulls the two together within a packet - the chain goes on, else the next cut's check falls back as before.
     repair_of.assign(probes.size(), -1);
     uint32_t rpj_launch = through ? std::max(rpj2, rpj1) : rpj2;
-    if (!tracing && !ctx.decoupled && !no_repair) {
+    if (!tracing && !no_repair) {
         for (size_t q = 0; q < probes.size(); q++) {
             if (probes[q].job >= 0) continue; // (an explicit probe's result is not known yet: it keeps the serial path)
             const size_t tj = (size_t)probes[q].tail_of;
@@ -815,7 +815,7 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
                 const uint32_t nall = std::min(R1.res[k].n_attempts, R1.cap);
                 for (uint32_t a = 0; a < nall && !entered; a++) {
                     const AttemptRec &r = R1.rec(k, a);
-                    entered = r.hdr_pos == L.hdr_pos && (r.status == kAttemptFrame || r.status == kAttemptOutOfData);
+                    entered = r.hdr_pos == L.hdr_pos && (r.status == kAttemptFrame || r.status == kAttemptOutOfData || r.status == kAttemptHeaderOnly); // (header-only: a decoupled pass ahead of its payload_end)
                 }
             }
             if (entered) continue; // (the stitch's own match - with its FEC-branch condition - decides)
@@ -841,6 +841,44 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
     if (s < 0) return s;
     pguard.armed = false;
     if (s == 0) break; // (1: the pass was re-laid - its probes are planned again)
+    }
+    // ... and the same repair for EXPLICIT probes (a decoupled pass has no tail probes; the generic kernels none either): that a probe job reached a header no
+    // segment job entered is known only now, so these repairs take a launch of their own - one for all of them
+    RunOut R4;
+    std::vector<int> repair4_of(probes.size(), -1);
+    if (!tracing && !no_repair) {
+        std::vector<Job> rjobs4;
+        for (size_t q = 0; q < probes.size(); q++) {
+            if (probes[q].job < 0) continue;
+            const size_t pj = (size_t)probes[q].job;
+            if (!pjobs[pj].stop_at_header) continue; // (a probe that walks its whole target segment: nothing to match)
+            const JobResult &pr = R2.res[pj];
+            if (!pr.pad || pr.n_attempts == 0u || pr.n_attempts > R2.cap) continue;
+            const AttemptRec &L = R2.rec(pj, pr.n_attempts - 1u);
+            if (L.status != kAttemptAtHeader || L.hdr_pos < 0) continue;
+            bool entered = false;
+            for (size_t k = first_seg[probes[q].stream] + 1; k <= probes[q].target && !entered; k++) {
+                const uint32_t nall = std::min(R1.res[k].n_attempts, R1.cap);
+                for (uint32_t a = 0; a < nall && !entered; a++) {
+                    const AttemptRec &r = R1.rec(k, a);
+                    entered = r.hdr_pos == L.hdr_pos && (r.status == kAttemptFrame || r.status == kAttemptOutOfData || r.status == kAttemptHeaderOnly);
+                }
+            }
+            if (entered) continue;
+            const StreamDesc &sd = streams[probes[q].stream];
+            const Job &tjob = jobs[probes[q].target];
+            Job j{};
+            j.stream_off = sd.off; j.stream_len = sd.len; j.start = L.hdr_pos; j.start_at_header = 1; j.cr_prev = L.cr_prev;
+            j.scan_limit = tjob.scan_limit; j.probe_limit = tjob.probe_limit; j.tail_stop_sfd = 0;
+            j.stream_id = sd.id; j.max_attempts = 0; j.stop_at_header = 0;
+            repair4_of[q] = (int)rjobs4.size();
+            rjobs4.push_back(j);
+        }
+        if (!rjobs4.empty()) {
+            env.count_probes((uint32_t)rjobs4.size());
+            s = env.run_jobs(rjobs4, rpj1, 0, R4);
+            if (s != 0) return s;
+        }
     }
     if (dbg_jobs) {
         for (size_t k = 0; k < pjobs.size(); k++) {
@@ -967,15 +1005,17 @@ int decode_end(Env &env, std::vector<StreamDesc> &streams, PassCtx &ctx)
                     break;
                 }
             }
-            if (match < 0 && q < repair_of.size() && repair_of[q] >= 0 && !at_sfd) { // the rest of the target segment, run again from the true header
-                const size_t rj = (size_t)repair_of[q];
-                const JobResult &rr = R2.res[rj];
-                const uint32_t nd = R2.n_done(rj);
-                if (nd >= 1u && R2.rec(rj, 0).hdr_pos == L.hdr_pos && rr.stop_reason != 2u) {
+            const bool rep2 = q < repair_of.size() && repair_of[q] >= 0, rep4 = repair4_of[q] >= 0;
+            if (match < 0 && (rep2 || rep4) && !at_sfd) { // the rest of the target segment, run again from the true header
+                const RunOut &RR = rep2 ? R2 : R4;
+                const size_t rj = (size_t)(rep2 ? repair_of[q] : repair4_of[q]);
+                const JobResult &rr = RR.res[rj];
+                const uint32_t nd = RR.n_done(rj);
+                if (nd >= 1u && RR.rec(rj, 0).hdr_pos == L.hdr_pos && rr.stop_reason != 2u) {
                     sd.pwr.apply(L.npush, L.push_tail); // the true DETECT scan is the probe's, everything from the header on the repair's
                     sd.pwr.determine_snr();
-                    if (R2.rec(rj, 0).status == kAttemptFrame) env.publish(R2.rec(rj, 0), sd);
-                    for (uint32_t a = 1; a < nd; a++) adopt(env, R2.rec(rj, a), sd);
+                    if (RR.rec(rj, 0).status == kAttemptFrame) env.publish(RR.rec(rj, 0), sd);
+                    for (uint32_t a = 1; a < nd; a++) adopt(env, RR.rec(rj, a), sd);
                     cur = Cursor{rr.final_pos, rr.final_cr};
                     if (rr.pad) { sd.incomplete = true; break; }
                     sd.pwr.apply(rr.npush, rr.push_tail);

@@ -23,7 +23,7 @@ for tag in ("sq_sf7","sq_sf9","sq_sf12"):
 json.dump(out,open("profiles/%s_sq_counters.json" % RND,"w"),indent=1)
 for a,b in (("default_line","default_bench_line"),("default_grad_line","default_grad_bench_line"),("work_line","work_bench_line"),("cfg4_line","cfg4_bench_line"),("cfg4_8s_line","cfg4_8s_bench_line"),("cfg4_2s_line","cfg4_2s_bench_line"),("torchrun1_line","torchrun_world1_bench_line"),("streams1_line","streams1_bench_line"),("mux_cfg4_2s_line","mux_cfg4_2s_bench_line"),("split1_line","split_world1_bench_line"),("default_fast_sync_line","default_fast_sync_bench_line"),("cfg4_2s_ordinary_line","cfg4_2s_ordinary_bench_line"),("sf7_256_line","sf7_256_default_bench_line"),("sf8_256_line","sf8_256_default_bench_line"),("sf7_256_lanes2_line","sf7_256_lanes2_bench_line"),("sf8_256_lanes2_line","sf8_256_lanes2_bench_line"),("sf9_256_lanes2_line","sf9_256_lanes2_bench_line"),("cfg4_2s_lanes1_line","cfg4_2s_lanes1_bench_line"),("sf7_d4_line","sf7_d4_bench_line"),("sf7_d2_line","sf7_d2_bench_line"),("sf8_d4_line","sf8_d4_default_bench_line"),("sf8_d2_line","sf8_d2_bench_line"),("sf9_d4_line","sf9_d4_bench_line"),("sf9_d2_line","sf9_d2_bench_line"),("sf8_d4_generic_line","sf8_d4_generic_bench_line")):
     shutil.copy("gpurun_out/%s.json"%a,"profiles/%s_%s.json"%(RND,b))
-for f in ("noise60","noise40","noise35","noise30","noise60_norepair","noise50_sf9","noise50_sf12","noise50_sf9_norepair"):
+for f in ("noise60","noise40","noise35","noise30","noise60_norepair","noise50_sf9","noise50_sf12","noise50_sf9_norepair","noise50_cfg4_2s","noise50_cfg4_32s","noise50_cfg4_2s_norepair"):
     if os.path.exists("gpurun_out/%s_line.json"%f):
         shutil.copy("gpurun_out/%s_line.json"%f,"profiles/%s_%s_bench_line.json"%(RND,f)); d=json.load(open("gpurun_out/%s_line.json"%f)); print(f, d["value"], d["ms_per_step"])
 if os.path.exists("gpurun_out/sf6_walker.txt"): shutil.copy("gpurun_out/sf6_walker.txt","profiles/%s_sf6_walker.txt"%RND)

@@ -46,6 +46,8 @@ PROFILE_LINE_FLAGS="--no-cpu-baseline --no-grad-line" tools/profile_round.sh sf8
 for n in 60 40 35 30; do LORA_BENCH_NOISE_DB=$n python bench.py --no-cpu-baseline --no-grad-line 2>/dev/null | tail -1 > gpurun_out/noise${n}_line.json; done
 LORA_HIP_NO_REPAIR=1 LORA_BENCH_NOISE_DB=60 python bench.py --no-cpu-baseline --no-grad-line --steps 3 --warmup 1 --min-seconds 0 2>/dev/null | tail -1 > gpurun_out/noise60_norepair_line.json
 for sf in 9 12; do LORA_BENCH_NOISE_DB=50 python bench.py --config 3 --sf $sf --no-cpu-baseline --no-grad-line 2>/dev/null | tail -1 > gpurun_out/noise50_sf${sf}_line.json; done
+for sec in 2 32; do LORA_BENCH_NOISE_DB=50 python bench.py --config 4 --seconds $sec --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/noise50_cfg4_${sec}s_line.json; done   # decoupled passes: explicit probes, repaired in a launch of their own
+LORA_HIP_NO_REPAIR=1 LORA_BENCH_NOISE_DB=50 python bench.py --config 4 --seconds 2 --no-cpu-baseline --steps 5 --warmup 2 --min-seconds 0 2>/dev/null | tail -1 > gpurun_out/noise50_cfg4_2s_norepair_line.json
 LORA_HIP_NO_REPAIR=1 LORA_BENCH_NOISE_DB=50 python bench.py --config 3 --sf 9 --no-cpu-baseline --no-grad-line --steps 3 --warmup 1 --min-seconds 0 2>/dev/null | tail -1 > gpurun_out/noise50_sf9_norepair_line.json
 tools/pmc_walker.sh sq_sf7
 tools/pmc_walker.sh sq_sf9 --config 3 --sf 9
